@@ -1,0 +1,224 @@
+/*
+ * nerftex_hip.h -- C ABI of libnerftex_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the instant-ngp-style rendering hot path of
+ * yihua7/NeRF-Texture.  Every entry point replaces ONE function the reference's
+ * pybind11 modules export (cited per function as file:line under the reference
+ * checkout); the arguments keep the reference's order and meaning, with
+ *   at::Tensor      ->  raw device pointer (the caller allocates everything),
+ *   implicit stream ->  explicit `stream` (a hipStream_t passed as void*; NULL =
+ *                       the legacy default stream the reference launches on),
+ *   void / throw    ->  int status (0 = ok) + nerftex_last_error().
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless the parameter is named host_*.
+ *   - Every function only enqueues work on `stream`; nothing synchronises.
+ *   - Outputs that the reference requires the caller to pre-zero keep that
+ *     contract (flagged "pre-zeroed" below).
+ *   - dtype tags: NERFTEX_F32 = 0, NERFTEX_F16 = 1 (IEEE binary16).
+ *   - Error texts mirror the reference's (TORCH_CHECK / std::runtime_error
+ *     messages) so a Python shim can raise RuntimeError with the same string.
+ */
+#ifndef NERFTEX_HIP_H
+#define NERFTEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFTEX_OK 0
+#define NERFTEX_ERR_INVALID 1   /* bad argument (unsupported C/D/width ...)      */
+#define NERFTEX_ERR_HIP 2       /* a HIP runtime call / launch failed            */
+
+#define NERFTEX_F32 0
+#define NERFTEX_F16 1
+
+/* layout of the per-level feature tensor handed across the boundary */
+#define NERFTEX_LAYOUT_LBC 0    /* [L, B, C]  (reference native layout)          */
+#define NERFTEX_LAYOUT_BLC 1    /* [B, L*C]   (what grid.py returns to callers)  */
+
+/* thread-local text of the last error on this thread ("" if none) */
+const char* nerftex_last_error(void);
+/* library / build identification: "nerftex_hip <ver> gfx950" */
+const char* nerftex_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * gridencoder  (reference: gridencoder/src/bindings.cpp:5-8,
+ *               gridencoder/src/gridencoder.h:12-13, gridencoder.cu:419-474)
+ * ------------------------------------------------------------------------- */
+
+/* replaces _gridencoder.grid_encode_forward (gridencoder.cu:419-442).
+ *   inputs      [B, D]   float32 in [0,1]
+ *   embeddings  [rows,C] dtype
+ *   offsets     [L+1]    int32
+ *   outputs     layout LBC: [L,B,C] | BLC: [B,L*C]   dtype
+ *   dy_dx       [B, L*D*C] dtype (only touched when calc_grad_inputs)
+ *   S = log2(per_level_scale), H = base resolution, gridtype 0=hash 1=tiled
+ * errors: "GridEncoding: C must be 1, 2, 4, or 8." for bad C and bad D (sic). */
+int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+                                void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                                uint32_t gridtype, int align_corners, int dtype, int layout,
+                                void* stream);
+
+/* replaces _gridencoder.grid_encode_backward (gridencoder.cu:444-474).
+ *   grad            LBC: [L,B,C] | BLC: [B,L*C]   dtype
+ *   grad_embeddings [rows,C] dtype, pre-zeroed, accumulated with atomics
+ *   grad_inputs     [B,D] dtype (written iff calc_grad_inputs; uses dy_dx)      */
+int nerftex_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
+                                 const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 int calc_grad_inputs, const void* dy_dx, void* grad_inputs,
+                                 uint32_t gridtype, int align_corners, int dtype, int layout,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * shencoder  (reference: shencoder/src/bindings.cpp, shencoder.h:10,13,
+ *             shencoder.cu:386-440).  float32 only (the wrapper forces it,
+ *             shencoder/sphere_harmonics.py:16).
+ * ------------------------------------------------------------------------- */
+
+/* replaces _shencoder.sh_encode_forward.  inputs [B,3], outputs [B,C*C],
+ * dy_dx [B,3,C*C] (iff calc_grad_inputs).  C = degree in 1..8.               */
+int nerftex_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D,
+                              uint32_t C, int calc_grad_inputs, float* dy_dx, void* stream);
+
+/* replaces _shencoder.sh_encode_backward.  grad [B,C*C]; grad_inputs [B,3]
+ * pre-zeroed, accumulated into (+=) exactly like shencoder.cu:359-383.       */
+int nerftex_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D,
+                               uint32_t C, const float* dy_dx, float* grad_inputs, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * raymarching  (reference: raymarching/src/bindings.cpp:5-21,
+ *               raymarching.h:7-19).  All float tensors are float32 (every
+ *               wrapper uses custom_fwd(cast_inputs=float32)).
+ * ------------------------------------------------------------------------- */
+
+/* raymarching.cu:150-158.  aabb [6]; miss -> near = far = FLT_MAX.           */
+int nerftex_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb,
+                               uint32_t N, float min_near, float* nears, float* fars,
+                               void* stream);
+/* raymarching.cu:203-211.  coords [N,2] in [-1,1].                           */
+int nerftex_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N,
+                           float* coords, void* stream);
+/* raymarching.cu:231-234 / 259-262.  10 bits per axis.                       */
+int nerftex_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+int nerftex_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+/* raymarching.cu:294-302.  N = number of output BYTES; bit i of byte n is
+ * grid[8n+i] > density_thresh.                                               */
+int nerftex_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield,
+                     void* stream);
+
+/* raymarching.cu:485-494 (kernel :314-483).
+ *   grid     density bitfield [C*H^3/8] uint8
+ *   xyzs/dirs [M,3], deltas [M,2]  pre-zeroed
+ *   rays     [N,3] int32 (ray id, point offset, num_steps)
+ *   counter  [2] int32, ACCUMULATED into: counter[0] += total points,
+ *            counter[1] += N  (same end state as the reference's atomics)
+ *   perturb  0/1; the RNG is pcg32 seeded 42, advanced by the ray id.
+ * Unlike the reference (two global atomics per ray, arbitrary order) the ray
+ * records are emitted in ray order with prefix-sum offsets: deterministic.   */
+int nerftex_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid,
+                             float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                             uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                             const float* fars, float* xyzs, float* dirs, float* deltas,
+                             int32_t* rays, int32_t* counter, uint32_t perturb, void* stream);
+/* raymarching.cu:671-678 (kernel :506-669): as above + rays_ts [M] = t after
+ * each emitted step.                                                         */
+int nerftex_march_rays_train_differentiable(const float* rays_o, const float* rays_d,
+                                            const uint8_t* grid, float bound, float dt_gamma,
+                                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                            uint32_t M, const float* nears, const float* fars,
+                                            float* xyzs, float* dirs, float* deltas,
+                                            float* rays_ts, int32_t* rays, int32_t* counter,
+                                            uint32_t perturb, void* stream);
+/* raymarching.cu:780-788 (kernel :700-777).                                  */
+int nerftex_composite_rays_train_forward(const float* sigmas, const float* rgbs,
+                                         const float* deltas, const int32_t* rays, uint32_t M,
+                                         uint32_t N, float* weights_sum, float* depth,
+                                         float* image, void* stream);
+/* raymarching.cu:884-892 (kernel :802-881). grad_sigmas/grad_rgbs pre-zeroed. */
+int nerftex_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                          const float* sigmas, const float* rgbs,
+                                          const float* deltas, const int32_t* rays,
+                                          const float* weights_sum, const float* image, uint32_t M,
+                                          uint32_t N, float* grad_sigmas, float* grad_rgbs,
+                                          void* stream);
+/* raymarching.cu:1009-1017 (kernel :900-1006).  xyzs/dirs/deltas pre-zeroed;
+ * perturb doubles as the pcg32 seed.                                         */
+int nerftex_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
+                       const float* rays_t, const float* rays_o, const float* rays_d, float bound,
+                       float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                       const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                       float* dirs, float* deltas, uint32_t perturb, void* stream);
+/* raymarching.cu:1097-1104 (kernel :1021-1094).  In-place accumulate.        */
+int nerftex_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
+                           float* rays_t, const float* sigmas, const float* rgbs,
+                           const float* deltas, float* weights_sum, float* depth, float* image,
+                           void* stream);
+/* raymarching.cu:1136-1142 (kernel :1117-1134).  alive_counter[0] += number
+ * kept.  Order-preserving (ballot + prefix sum) instead of atomics order.    */
+int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old,
+                         float* rays_t, const float* rays_t_old, int32_t* alive_counter,
+                         void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * ffmlp  (reference: ffmlp/src/bindings.cpp:5-10, ffmlp.h:8-13,
+ *         ffmlp.cu:630-895).  fp16 storage; MFMA with fp32 accumulation.
+ *   weights  flat: [hidden,in] + (num_layers-1)*[hidden,hidden] + [out16,hidden],
+ *            each row-major [out,in]  (ffmlp.cu:632)
+ *   inputs [B,in] half, outputs [B,output_dim] half (output_dim = 16, padded)
+ *   forward_buffer / backward_buffer [num_layers, B, hidden] half
+ *   activation ids: 0 relu 1 exponential 2 sine 3 sigmoid 4 squareplus
+ *                   5 softplus 6 none  (ffmlp/ffmlp.py:89-96)
+ *   B must be a multiple of 128 (the Python module pads, ffmlp.py:157-159).
+ * ------------------------------------------------------------------------- */
+int nerftex_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                          uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                          uint32_t activation, uint32_t output_activation, void* forward_buffer,
+                          void* outputs, void* stream);
+int nerftex_ffmlp_inference(const void* inputs, const void* weights, uint32_t B,
+                            uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                            uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                            void* inference_buffer, void* outputs, void* stream);
+/* grad [B,output_dim] half; grad_weights flat half, pre-zeroed; grad_inputs
+ * [B,in] half (written iff calc_grad_inputs); backward_buffer pre-zeroed.    */
+int nerftex_ffmlp_backward(const void* grad, const void* inputs, const void* weights,
+                           const void* forward_buffer, uint32_t B, uint32_t input_dim,
+                           uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                           uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                           void* backward_buffer, void* grad_inputs, void* grad_weights,
+                           void* stream);
+/* ffmlp.cu:711-740: the reference creates side streams for its split-K wgrad
+ * GEMMs.  Here wgrad is reduced inside one launch, so these only size / drop
+ * the fp32 partial-sum workspace; kept so `FFMLP.__init__` binds unchanged.  */
+int nerftex_ffmlp_allocate_splitk(size_t size);
+int nerftex_ffmlp_free_splitk(void);
+
+/* ------------------------------------------------------------------------- *
+ * RayTracer / BVH  (reference: external/RayTracer/src/bindings.cpp:13-18,
+ *                   src/raytracer.cu:21-64, src/bvh.cu:527-721)
+ * ------------------------------------------------------------------------- */
+typedef struct nerftex_raytracer nerftex_raytracer;
+
+/* replaces _raytracing.create_raytracer: HOST arrays in, BVH-4 built on the
+ * host (median split on the max-variance axis, <= 8 triangles per leaf),
+ * nodes + reordered triangles uploaded.  *out owns the device memory.        */
+int nerftex_create_raytracer(const float* host_vertices, uint32_t n_vertices,
+                             const uint32_t* host_triangles, uint32_t n_triangles,
+                             nerftex_raytracer** out);
+int nerftex_destroy_raytracer(nerftex_raytracer* rt);
+/* replaces RayTracer.trace (raytracer.cu:45-58): closest hit per ray.
+ * positions/normals [N,3] (may alias rays_o/rays_d), depth [N] (10.0 on miss),
+ * face_idx [N] int64 pre-filled with -1 by the caller (left untouched on miss) */
+int nerftex_raytracer_trace(const nerftex_raytracer* rt, const float* rays_o, const float* rays_d,
+                            float* positions, float* normals, float* depth, int64_t* face_idx,
+                            uint32_t N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFTEX_HIP_H */

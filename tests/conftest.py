@@ -1,0 +1,34 @@
+"""pytest configuration: markers + import paths.
+
+`-m "not gpu"`: oracle vs golden vectors / known answers, host logic, C-ABI symbol check, gloo DP.
+`-m gpu`      : parity tests proper -- the HIP path (through the C ABI) against the oracle.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "nerf-texture_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as orc
+
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
