@@ -1,0 +1,53 @@
+// Shared host/device helpers of libnerftex_hip.so (gfx950 only; no CUDA / portability shims).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/nerftex_hip.h"
+
+namespace nerftex {
+
+// ---- error reporting: int status + thread-local text (include/nerftex_hip.h) -------------------
+void set_error(const char* fmt, ...);
+void clear_error();
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return NERFTEX_ERR_HIP;
+    }
+    return NERFTEX_OK;
+}
+
+#define NERFTEX_HIP_TRY(expr, what)                                                   \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            ::nerftex::set_error("%s: %s", what, hipGetErrorString(_e));              \
+            return NERFTEX_ERR_HIP;                                                   \
+        }                                                                             \
+    } while (0)
+
+template <typename T>
+constexpr T div_up(T a, T b) { return (a + b - 1) / b; }
+
+// ---- device-side types --------------------------------------------------------------------------
+using half_t = _Float16;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+}  // namespace nerftex

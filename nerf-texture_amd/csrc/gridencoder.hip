@@ -1,0 +1,498 @@
+// Multiresolution hash-grid encoder for gfx950 (MI355X).
+//
+// Replaces the reference's gridencoder/src/gridencoder.cu (kernel_grid :75-224,
+// kernel_grid_backward :227-314, kernel_input_backward :317-343) behind the C ABI
+// of include/nerftex_hip.h.  Not a translation: the launch geometry, the level
+// schedule and the data layout are chosen for CDNA4.
+//
+//  forward  : one thread per POINT walks all L levels (the reference launches one
+//             thread per (point, level) with level = blockIdx.y).  The input is read
+//             once instead of L times, the per-level scale/resolution are folded on
+//             the host into kernel arguments (no exp2f/ceil on the device -> the
+//             float pipeline is mul/fma/floor only and matches the oracle bit for
+//             bit in fp32), and the [B, L*C] row the Python caller wants is produced
+//             directly, removing the reference's permute + reshape copy
+//             (gridencoder/grid.py:52).  All co-resident workgroups start at level 0
+//             and advance in near lock-step, so the L2 working set stays about one
+//             level (<= 4 MiB) -- the property the reference buys with blockIdx.y.
+//  backward : (point, level) threads, level-major so one level's slice of the
+//             gradient table is the atomic working set; hardware float atomics
+//             (global_atomic_add_f32 / global_atomic_pk_add_f16), no CAS loops.
+//
+// Arithmetic contract (see oracle/src/orc_gridencoder.c): uint32 index math is
+// bit-exact; interpolation weights are products in dimension order; accumulation
+// is fmaf(w, g, acc) over corners 0..2^D-1 in fp32.  For fp16 tables the sum is
+// kept in fp32 and rounded once (the reference rounds to half after every corner).
+#include "common.hpp"
+
+#include <cmath>
+
+#pragma clang fp contract(off)
+
+namespace nerftex {
+namespace {
+
+constexpr int kMaxLevels = 32;
+
+struct LevelConsts {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+// host: gridencoder.cu:125-127, evaluated once per call instead of per thread
+LevelConsts make_level_consts(uint32_t L, float S, uint32_t H) {
+    LevelConsts lc{};
+    for (uint32_t l = 0; l < L && l < (uint32_t)kMaxLevels; l++) {
+        const float p = exp2f((float)l * S) * (float)H;
+        const float scale = p - 1.0f;
+        lc.scale[l] = scale;
+        lc.resolution[l] = (uint32_t)ceil((double)scale) + 1u;
+    }
+    return lc;
+}
+
+// uniform (per level) description of the index function, gridencoder.cu:54-72
+template <int D>
+struct IndexFn {
+    uint32_t stride[D];  // stride[d] used while the reference loop is still running
+    uint32_t ndense;     // number of dimensions the dense loop covers
+    bool hashed;
+    bool pow2;
+    uint32_t size;
+
+    __device__ IndexFn(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
+        uint32_t s = 1;
+        ndense = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            stride[d] = s;
+            if (s <= hashmap_size) {
+                ndense = d + 1;
+                s *= align_corners ? resolution : (resolution + 1);
+            }
+        }
+        hashed = (gridtype == 0) && (s > hashmap_size);
+        size = hashmap_size;
+        pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
+    }
+
+    __device__ __forceinline__ uint32_t operator()(const uint32_t (&p)[D]) const {
+        uint32_t index;
+        if (hashed) {
+            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+            index = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) index ^= p[d] * primes[d];
+        } else {
+            index = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if ((uint32_t)d < ndense) index += p[d] * stride[d];
+        }
+        if (pow2) return index & (size - 1);
+        return index >= size ? index % size : index;
+    }
+};
+
+template <typename T, int C>
+struct Vec;
+template <> struct Vec<float, 1> { using type = float; };
+template <> struct Vec<float, 2> { using type = float2_t; };
+template <> struct Vec<float, 4> { using type = float4_t; };
+template <> struct Vec<half_t, 1> { using type = half_t; };
+template <> struct Vec<half_t, 2> { using type = half2_t; };
+template <> struct Vec<half_t, 4> { using type = half4_t; };
+template <> struct Vec<half_t, 8> { using type = half8_t; };
+
+// load C consecutive features of one table row as floats (one vector load where a type exists)
+template <typename T, int C>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, float (&v)[C]) {
+    if constexpr (C == 8 && sizeof(T) == 4) {
+        const float4_t a = *reinterpret_cast<const float4_t*>(p);
+        const float4_t b = *reinterpret_cast<const float4_t*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = a[i]; v[4 + i] = b[i]; }
+    } else if constexpr (C == 1) {
+        v[0] = (float)p[0];
+    } else {
+        using V = typename Vec<T, C>::type;
+        const V a = *reinterpret_cast<const V*>(p);
+#pragma unroll
+        for (int i = 0; i < C; i++) v[i] = (float)a[i];
+    }
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]) {
+    if constexpr (C == 8 && sizeof(T) == 4) {
+        float4_t a, b;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = v[i]; b[i] = v[4 + i]; }
+        *reinterpret_cast<float4_t*>(p) = a;
+        *reinterpret_cast<float4_t*>(p + 4) = b;
+    } else if constexpr (C == 1) {
+        p[0] = (T)v[0];
+    } else {
+        using V = typename Vec<T, C>::type;
+        V a;
+#pragma unroll
+        for (int i = 0; i < C; i++) a[i] = (T)v[i];
+        *reinterpret_cast<V*>(p) = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: thread = point, loop over levels
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int C, bool BLC>
+__global__ __launch_bounds__(256) void grid_forward_kernel(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                           const int* __restrict__ offsets, T* __restrict__ outputs,
+                                                           const uint32_t B, const uint32_t L, const LevelConsts lc,
+                                                           const bool calc_grad_inputs, T* __restrict__ dy_dx,
+                                                           const uint32_t gridtype, const bool align_corners) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        if (x[d] < 0 || x[d] > 1) oob = true;
+    }
+
+    for (uint32_t level = 0; level < L; level++) {
+        T* out = BLC ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
+        T* dyd = dy_dx + ((size_t)b * L + level) * (D * C);  // [B, L, D, C]
+
+        if (oob) {  // gridencoder.cu:99-123
+            float z[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) z[c] = 0.0f;
+            store_row<T, C>(out, z);
+            if (calc_grad_inputs) {
+#pragma unroll
+                for (int d = 0; d < D; d++) store_row<T, C>(dyd + d * C, z);
+            }
+            continue;
+        }
+
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+        const float scale = lc.scale[level];
+        const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
+        const T* __restrict__ table = grid + (size_t)off * C;
+
+        float pos[D];
+        uint32_t pos_grid[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+            const float fl = floorf(pos[d]);
+            pos_grid[d] = (uint32_t)fl;
+            pos[d] -= (float)pos_grid[d];
+        }
+
+        // issue all 2^D gathers, then blend (corner order 0..2^D-1, fmaf -> matches the oracle)
+        float g[1 << D][C];
+        float w[1 << D];
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            float wi = 1;
+            uint32_t p[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                if ((idx & (1 << d)) == 0) {
+                    wi *= 1 - pos[d];
+                    p[d] = pos_grid[d];
+                } else {
+                    wi *= pos[d];
+                    p[d] = pos_grid[d] + 1;
+                }
+            }
+            w[idx] = wi;
+            load_row<T, C>(table + (size_t)index_of(p) * C, g[idx]);
+        }
+        float r[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) r[c] = 0.0f;
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) r[c] = fmaf(w[idx], g[idx][c], r[c]);
+        }
+        store_row<T, C>(out, r);
+
+        if (calc_grad_inputs) {  // gridencoder.cu:180-223; the 2^D corners are already in registers
+#pragma unroll
+            for (int gd = 0; gd < D; gd++) {
+                float rg[C];
+#pragma unroll
+                for (int c = 0; c < C; c++) rg[c] = 0.0f;
+#pragma unroll
+                for (int idx = 0; idx < (1 << (D - 1)); idx++) {
+                    float wi = scale;
+                    int corner = 0;
+#pragma unroll
+                    for (int nd = 0; nd < D - 1; nd++) {
+                        const int d = (nd >= gd) ? (nd + 1) : nd;
+                        if ((idx & (1 << nd)) == 0) {
+                            wi *= 1 - pos[d];
+                        } else {
+                            wi *= pos[d];
+                            corner |= 1 << d;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        float diff = g[corner | (1 << gd)][c] - g[corner][c];
+                        if constexpr (sizeof(T) == 2) diff = (float)(T)diff;  // half - half rounds to half
+                        rg[c] = fmaf(wi, diff, rg[c]);
+                    }
+                }
+                store_row<T, C>(dyd + gd * C, rg);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: scatter-add of w * grad into the table gradient
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
+__device__ __forceinline__ void atomic_add_h2(half_t* addr, float a, float b) {
+    __half2 v = __floats2half2_rn(a, b);
+    unsafeAtomicAdd(reinterpret_cast<__half2*>(addr), v);
+}
+
+template <typename T, int D, int C, int N_C, bool BLC>
+__global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                            const int* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                            const uint32_t B, const uint32_t L, const LevelConsts lc,
+                                                            const uint32_t gridtype, const bool align_corners) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t * N_C / C;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t ch = t * N_C - b * C;
+
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        if (x[d] < 0 || x[d] > 1) return;  // gridencoder.cu:248-253
+
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const float scale = lc.scale[level];
+    const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
+    T* __restrict__ table = grad_grid + (size_t)off * C;
+
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+    }
+
+    const T* gp = BLC ? grad + ((size_t)b * L + level) * C + ch : grad + ((size_t)level * B + b) * C + ch;
+    float gc[N_C];
+#pragma unroll
+    for (int c = 0; c < N_C; c++) gc[c] = (float)gp[c];
+
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1;
+        uint32_t p[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) {
+                w *= 1 - pos[d];
+                p[d] = pos_grid[d];
+            } else {
+                w *= pos[d];
+                p[d] = pos_grid[d] + 1;
+            }
+        }
+        T* dst = table + (size_t)index_of(p) * C + ch;
+        if constexpr (sizeof(T) == 2 && N_C == 2) {
+            atomic_add_h2(reinterpret_cast<half_t*>(dst), w * gc[0], w * gc[1]);  // :299-305
+        } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int c = 0; c < N_C; c++) atomic_add_f32(reinterpret_cast<float*>(dst) + c, w * gc[c]);
+        } else {
+            // fp16, C == 1: the reference's at::Half atomicAdd is an empty stub (gridencoder.cu:22-26),
+            // i.e. it silently adds nothing.  Emulate a scalar half add with a 32-bit CAS instead.
+            unsigned int* base = reinterpret_cast<unsigned int*>(reinterpret_cast<uintptr_t>(dst) & ~(uintptr_t)3);
+            const bool hi = (reinterpret_cast<uintptr_t>(dst) & 2) != 0;
+            unsigned int old = *base, assumed;
+            do {
+                assumed = old;
+                unsigned short hs = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+                half_t hv = __builtin_bit_cast(half_t, hs);
+                hv = (half_t)((float)hv + w * gc[0]);
+                unsigned short ns = __builtin_bit_cast(unsigned short, hv);
+                unsigned int repl = hi ? ((assumed & 0xffffu) | ((unsigned int)ns << 16)) : ((assumed & 0xffff0000u) | ns);
+                old = atomicCAS(base, assumed, repl);
+            } while (old != assumed);
+        }
+    }
+}
+
+// grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]    (gridencoder.cu:317-343)
+template <typename T, int D, int C, bool BLC>
+__global__ __launch_bounds__(256) void grid_input_backward_kernel(const T* __restrict__ grad, const T* __restrict__ dy_dx,
+                                                                  T* __restrict__ grad_inputs, const uint32_t B,
+                                                                  const uint32_t L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D;
+    const uint32_t d = t - b * D;
+    const T* dyd = dy_dx + (size_t)b * L * D * C;
+    float result = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        const T* gp = BLC ? grad + ((size_t)b * L + l) * C : grad + ((size_t)l * B + b) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) result = fmaf((float)gp[c], (float)dyd[(size_t)l * D * C + d * C + c], result);
+    }
+    grad_inputs[t] = (T)result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int C>
+int launch_forward(const float* inputs, const T* emb, const int* offsets, T* outputs, uint32_t B, uint32_t L,
+                   const LevelConsts& lc, bool calc_grad, T* dy_dx, uint32_t gridtype, bool align, int layout,
+                   hipStream_t st) {
+    if (B == 0) return NERFTEX_OK;
+    const dim3 grid(div_up(B, 256u)), block(256);
+    if (layout == NERFTEX_LAYOUT_BLC)
+        hipLaunchKernelGGL((grid_forward_kernel<T, D, C, true>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, lc,
+                           calc_grad, dy_dx, gridtype, align);
+    else
+        hipLaunchKernelGGL((grid_forward_kernel<T, D, C, false>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, lc,
+                           calc_grad, dy_dx, gridtype, align);
+    return check_launch("grid_encode_forward");
+}
+
+template <typename T, int D, int C>
+int launch_backward(const T* grad, const float* inputs, const int* offsets, T* grad_emb, uint32_t B, uint32_t L,
+                    const LevelConsts& lc, bool calc_grad, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool align,
+                    int layout, hipStream_t st) {
+    if (B == 0) return NERFTEX_OK;
+    constexpr int N_C = C < 2 ? C : 2;
+    const dim3 grid(div_up(B * (uint32_t)C / (uint32_t)N_C, 256u), L), block(256);
+    const bool blc = layout == NERFTEX_LAYOUT_BLC;
+    if (blc)
+        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, N_C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L,
+                           lc, gridtype, align);
+    else
+        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, N_C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B,
+                           L, lc, gridtype, align);
+    int rc = check_launch("grid_encode_backward");
+    if (rc != NERFTEX_OK) return rc;
+    if (calc_grad) {
+        const dim3 g2(div_up(B * (uint32_t)D, 256u));
+        if (blc)
+            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, true>), g2, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+        else
+            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, false>), g2, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+        rc = check_launch("grid_encode_backward(inputs)");
+    }
+    return rc;
+}
+
+const char* kBadC = "GridEncoding: C must be 1, 2, 4, or 8.";  // reference text for bad C *and* bad D
+
+template <typename T>
+int dispatch_forward(const float* inputs, const void* emb, const int* offsets, void* outputs, uint32_t B, uint32_t D,
+                     uint32_t C, uint32_t L, const LevelConsts& lc, bool calc_grad, void* dy_dx, uint32_t gridtype,
+                     bool align, int layout, hipStream_t st) {
+#define FWD(DD, CC)                                                                                                   \
+    return launch_forward<T, DD, CC>(inputs, (const T*)emb, offsets, (T*)outputs, B, L, lc, calc_grad, (T*)dy_dx, gridtype, \
+                                     align, layout, st)
+    if (D == 2) {
+        switch (C) { case 1: FWD(2, 1); case 2: FWD(2, 2); case 4: FWD(2, 4); case 8: FWD(2, 8); default: break; }
+    } else if (D == 3) {
+        switch (C) { case 1: FWD(3, 1); case 2: FWD(3, 2); case 4: FWD(3, 4); case 8: FWD(3, 8); default: break; }
+    }
+#undef FWD
+    set_error("%s", kBadC);
+    return NERFTEX_ERR_INVALID;
+}
+
+template <typename T>
+int dispatch_backward(const void* grad, const float* inputs, const int* offsets, void* grad_emb, uint32_t B, uint32_t D,
+                      uint32_t C, uint32_t L, const LevelConsts& lc, bool calc_grad, const void* dy_dx, void* grad_inputs,
+                      uint32_t gridtype, bool align, int layout, hipStream_t st) {
+#define BWD(DD, CC)                                                                                                      \
+    return launch_backward<T, DD, CC>((const T*)grad, inputs, offsets, (T*)grad_emb, B, L, lc, calc_grad, (const T*)dy_dx, \
+                                      (T*)grad_inputs, gridtype, align, layout, st)
+    if (D == 2) {
+        switch (C) { case 1: BWD(2, 1); case 2: BWD(2, 2); case 4: BWD(2, 4); case 8: BWD(2, 8); default: break; }
+    } else if (D == 3) {
+        switch (C) { case 1: BWD(3, 1); case 2: BWD(3, 2); case 4: BWD(3, 4); case 8: BWD(3, 8); default: break; }
+    }
+#undef BWD
+    set_error("%s", kBadC);
+    return NERFTEX_ERR_INVALID;
+}
+
+int check_common(uint32_t L, int dtype, int layout) {
+    if (L == 0 || L > (uint32_t)kMaxLevels) {
+        set_error("GridEncoding: num_levels must be in [1, %d], got %u", kMaxLevels, L);
+        return NERFTEX_ERR_INVALID;
+    }
+    if (dtype != NERFTEX_F32 && dtype != NERFTEX_F16) {
+        set_error("embeddings must be a floating tensor (float32 or float16)");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (layout != NERFTEX_LAYOUT_LBC && layout != NERFTEX_LAYOUT_BLC) {
+        set_error("GridEncoding: unknown layout %d", layout);
+        return NERFTEX_ERR_INVALID;
+    }
+    return NERFTEX_OK;
+}
+
+}  // namespace
+}  // namespace nerftex
+
+using namespace nerftex;
+
+extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                           int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                                           int layout, void* stream) {
+    clear_error();
+    int rc = check_common(L, dtype, layout);
+    if (rc != NERFTEX_OK) return rc;
+    const LevelConsts lc = make_level_consts(L, S, H);
+    if (dtype == NERFTEX_F32)
+        return dispatch_forward<float>(inputs, embeddings, offsets, outputs, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
+                                       gridtype, align_corners != 0, layout, as_stream(stream));
+    return dispatch_forward<half_t>(inputs, embeddings, offsets, outputs, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx, gridtype,
+                                    align_corners != 0, layout, as_stream(stream));
+}
+
+extern "C" int nerftex_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
+                                            const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                            uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
+                                            void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, int layout,
+                                            void* stream) {
+    (void)embeddings;  // the reference passes it but never reads it in backward
+    clear_error();
+    int rc = check_common(L, dtype, layout);
+    if (rc != NERFTEX_OK) return rc;
+    const LevelConsts lc = make_level_consts(L, S, H);
+    if (dtype == NERFTEX_F32)
+        return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
+                                        grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+    return dispatch_backward<half_t>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
+                                     grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+}

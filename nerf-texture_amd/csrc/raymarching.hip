@@ -1,0 +1,723 @@
+// Occupancy-grid ray marching + compositing for gfx950 (MI355X).
+//
+// Replaces the reference's raymarching/src/raymarching.cu (R1..R12, cited at each entry point)
+// behind include/nerftex_hip.h.  Design points that differ from the reference:
+//
+//  * march_rays_train: the reference reserves output space with two global atomicAdds per ray,
+//    so ray records and sample offsets come out in a different order on every run.  Here the
+//    count pass also reduces num_steps per workgroup (wave64 shuffle reduction), and the
+//    write pass rebuilds each ray's offset as  base + sum(earlier workgroups) + wave64 inclusive
+//    scan inside the workgroup.  No atomics, no extra launch, and the result is deterministic:
+//    record n describes ray n, offsets are the exclusive prefix sum of num_steps.
+//  * compact_rays: order-preserving wave64 ballot / prefix-sum compaction instead of one atomic
+//    per surviving ray.
+//  * Every float expression follows the oracle's tree (oracle/src/orc_raymarching.c): products
+//    that feed an add are explicit fmaf(), nothing else may fuse (#pragma clang fp contract(off)),
+//    the voxel coordinate keeps the reference's float->double->float promotion.  Per-ray step
+//    counts and sample positions are therefore bit-identical to the oracle.
+#include "common.hpp"
+#include "workspace.hpp"
+
+#pragma clang fp contract(off)
+
+namespace nerftex {
+namespace {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+constexpr uint32_t kBlock = 256;  // 4 waves: element-parallel utility kernels
+// ray-parallel kernels (DDA, per-ray compositing) are latency-bound and a training batch is only a
+// few thousand rays: one wave per workgroup spreads them over as many CUs / SIMDs as possible.
+constexpr uint32_t kRayBlock = 64;
+
+// ------------------------------------------------------------------------------------------------
+// PCG32 (pcg32.h:44-170 of the reference; O'Neill's pcg32 with Brown's log-step advance)
+// ------------------------------------------------------------------------------------------------
+struct Pcg32 {
+    uint64_t state, inc;
+    static constexpr uint64_t kMult = 0x5851f42d4c957f2dULL;
+
+    __host__ __device__ explicit Pcg32(uint64_t initstate, uint64_t initseq = 1) {
+        state = 0;
+        inc = (initseq << 1u) | 1u;
+        next_uint();
+        state += initstate;
+        next_uint();
+    }
+    __host__ __device__ uint32_t next_uint() {
+        const uint64_t old = state;
+        state = old * kMult + inc;
+        const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    __host__ __device__ float next_float() {
+        const uint32_t u = (next_uint() >> 9) | 0x3f800000u;
+        return __builtin_bit_cast(float, u) - 1.0f;
+    }
+    __host__ __device__ void advance(uint64_t delta) {
+        uint64_t cur_mult = kMult, cur_plus = inc, acc_mult = 1, acc_plus = 0;
+        while (delta > 0) {
+            if (delta & 1) {
+                acc_mult *= cur_mult;
+                acc_plus = acc_plus * cur_mult + cur_plus;
+            }
+            cur_plus = (cur_mult + 1) * cur_plus;
+            cur_mult *= cur_mult;
+            delta >>= 1;
+        }
+        state = acc_mult * state + acc_plus;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton3D_invert(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+__device__ __forceinline__ int frexp_exponent(float v) {
+    int e;
+    (void)frexpf(v, &e);
+    return e;
+}
+__device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    return (int)fminf(max_cascade - 1, fmaxf(0, (float)frexp_exponent(mx)));
+}
+__device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (float)((double)(dt * H) * 0.5);
+    return (int)fminf(max_cascade - 1, fmaxf(0, (float)frexp_exponent(mx)));
+}
+
+// wave64 inclusive scan / reductions with lane shuffles
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the DDA shared by R6 / R7 / R10 (raymarching.cu:362-403 / :430-482 / :954-1005)
+// ------------------------------------------------------------------------------------------------
+struct Dda {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, rH;
+    float bound, dt_gamma, dt_min, dt_max, far;
+    float Cf, Hf, sx, sy, sz, hi;
+    uint32_t H, H3;
+    double Hd;
+    const uint8_t* __restrict__ grid;
+
+    __device__ Dda(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps, uint32_t C, uint32_t H_,
+                   const uint8_t* grid_, float far_) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
+        rH = 1 / (float)H_;
+        bound = bound_; dt_gamma = dt_gamma_;
+        dt_min = 2 * kSqrt3 / (float)max_steps;
+        dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H_;
+        far = far_;
+        Cf = (float)C; Hf = (float)H_; H = H_; H3 = H_ * H_ * H_; Hd = (double)H_;
+        hi = (float)(H_ - 1);
+        sx = copysignf(1.0f, dx); sy = copysignf(1.0f, dy); sz = copysignf(1.0f, dz);
+        grid = grid_;
+    }
+
+    // One iteration at parameter t.  Occupied: returns true with the sample (x,y,z,dt), t untouched.
+    // Empty: advances t past the voxel and returns false.
+    __device__ __forceinline__ bool step(float& t, float& x, float& y, float& z, float& dt) const {
+        x = clampf(fmaf(t, dx, ox), -bound, bound);
+        y = clampf(fmaf(t, dy, oy), -bound, bound);
+        z = clampf(fmaf(t, dz, oz), -bound, bound);
+        dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const int la = mip_from_pos(x, y, z, Cf), lb = mip_from_dt(dt, Hf, Cf);
+        const int level = la > lb ? la : lb;
+        const float mip_bound = fminf((float)(1 << level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        const int nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * Hd), 0.0f, hi);
+        const int ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * Hd), 0.0f, hi);
+        const int nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * Hd), 0.0f, hi);
+        const uint32_t index = (uint32_t)level * H3 + morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+        const bool occ = grid[index >> 3] & (1u << (index & 7u));
+        if (occ) return true;
+        const float tx = fmaf(fmaf(fmaf(0.5f, sx, (float)nx + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
+        const float ty = fmaf(fmaf(fmaf(0.5f, sy, (float)ny + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
+        const float tz = fmaf(fmaf(fmaf(0.5f, sz, (float)nz + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += clampf(t * dt_gamma, dt_min, dt_max);
+        } while (t < tt);
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// R1 .. R5
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void near_far_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                          const float* __restrict__ aabb, uint32_t N, float min_near,
+                                                          float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
+    const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    constexpr float kMax = 3.402823466e+38f;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
+    if (near > far) { tmp = near; near = far; far = tmp; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { tmp = near_y; near_y = far_y; far_y = tmp; }
+    if (near > far_y || near_y > far) { nears[n] = fars[n] = kMax; return; }
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { tmp = near_z; near_z = far_z; far_z = tmp; }
+    if (near > far_z || near_z > far) { nears[n] = fars[n] = kMax; return; }
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    nears[n] = near;
+    fars[n] = far;
+}
+
+__global__ __launch_bounds__(kBlock) void polar_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       float radius, uint32_t N, float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
+    const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
+    const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float Bh = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+    const float Cc = fmaf(-radius, radius, fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
+    const float t = (-Bh + sqrtf(fmaf(Bh, Bh, -(A * Cc)))) / A;
+    const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+    const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+    const float phi = atan2f(z, x);
+    coords[2 * (size_t)n] = fmaf(2 * theta, kRPi, -1.0f);
+    coords[2 * (size_t)n + 1] = phi * kRPi;
+}
+
+__global__ __launch_bounds__(kBlock) void morton3D_kernel(const int* __restrict__ coords, uint32_t N, int* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int)morton3D((uint32_t)coords[3 * (size_t)n], (uint32_t)coords[3 * (size_t)n + 1], (uint32_t)coords[3 * (size_t)n + 2]);
+}
+
+__global__ __launch_bounds__(kBlock) void morton3D_invert_kernel(const int* __restrict__ indices, uint32_t N, int* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int ind = indices[n];
+    coords[3 * (size_t)n + 0] = (int)morton3D_invert((uint32_t)(ind >> 0));
+    coords[3 * (size_t)n + 1] = (int)morton3D_invert((uint32_t)(ind >> 1));
+    coords[3 * (size_t)n + 2] = (int)morton3D_invert((uint32_t)(ind >> 2));
+}
+
+// one thread per output byte: two 16-byte loads, 8 compares
+__global__ __launch_bounds__(kBlock) void packbits_kernel(const float* __restrict__ grid, uint32_t N, float thresh,
+                                                          uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4_t a = *reinterpret_cast<const float4_t*>(grid + (size_t)n * 8);
+    const float4_t b = *reinterpret_cast<const float4_t*>(grid + (size_t)n * 8 + 4);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        bits |= (a[i] > thresh) ? (1u << i) : 0u;
+        bits |= (b[i] > thresh) ? (1u << (4 + i)) : 0u;
+    }
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// R6 / R7: march_rays_train
+// ------------------------------------------------------------------------------------------------
+// ws layout (uint32): [0] base (old counter[0]), [1 .. 1+nblocks) per-workgroup step totals
+__device__ __forceinline__ float ray_t0(const Dda& s, float near, uint32_t perturb, uint32_t n, uint64_t seed) {
+    float t0 = near;
+    if (perturb) {
+        Pcg32 rng(seed);
+        rng.advance((uint64_t)n);
+        t0 = fmaf(s.dt_min, rng.next_float(), t0);
+    }
+    return t0;
+}
+
+__global__ __launch_bounds__(kRayBlock) void march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                             const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                             const float* __restrict__ nears, const float* __restrict__ fars,
+                                                             int* __restrict__ rays, const int* __restrict__ counter,
+                                                             uint32_t* __restrict__ ws, uint32_t perturb) {
+    __shared__ uint32_t wave_tot[kRayBlock / kWave];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t num_steps = 0;
+    if (n < N) {
+        const Dda s(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid, fars[n]);
+        float t = ray_t0(s, nears[n], perturb, n, 42);
+        float x, y, z, dt;
+        while (t < s.far && num_steps < max_steps) {
+            if (s.step(t, x, y, z, dt)) {
+                num_steps++;
+                t += dt;
+            }
+        }
+        rays[3 * (size_t)n + 2] = (int)num_steps;
+    }
+    const uint32_t wsum = wave_sum(num_steps);
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_tot[threadIdx.x / kWave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kRayBlock / kWave; i++) tot += wave_tot[i];
+        ws[1 + blockIdx.x] = tot;
+        if (blockIdx.x == 0) ws[0] = (uint32_t)counter[0];
+    }
+}
+
+template <bool WITH_TS>
+__global__ __launch_bounds__(kRayBlock) void march_write_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                             const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                             const float* __restrict__ nears, const float* __restrict__ fars,
+                                                             float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                             float* __restrict__ deltas, float* __restrict__ rays_ts,
+                                                             int* __restrict__ rays, int* __restrict__ counter,
+                                                             const uint32_t* __restrict__ ws, uint32_t perturb) {
+    __shared__ uint32_t red[kRayBlock / kWave];
+    __shared__ uint32_t wave_tot[kRayBlock / kWave];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+
+    // (1) steps emitted by all earlier workgroups
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kRayBlock) part += ws[1 + j];
+    part = wave_sum(part);
+    if (lane == 0) red[wid] = part;
+
+    // (2) exclusive scan of num_steps inside the workgroup
+    const uint32_t num_steps = n < N ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
+    const uint32_t incl = wave_inclusive_scan(num_steps);
+    if (lane == kWave - 1) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t before = ws[0];
+#pragma unroll
+    for (uint32_t i = 0; i < kRayBlock / kWave; i++) {
+        before += red[i];
+        if (i < wid) before += wave_tot[i];
+    }
+    const uint32_t point_index = before + incl - num_steps;
+
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kRayBlock - 1) {
+        // last thread of the last workgroup sees the grand total
+        counter[0] = (int)(point_index + num_steps);
+        counter[1] = counter[1] + (int)N;
+    }
+    if (n >= N) return;
+
+    rays[3 * (size_t)n] = (int)n;
+    rays[3 * (size_t)n + 1] = (int)point_index;
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) return;  // raymarching.cu:419: silently dropped
+
+    const Dda s(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid, fars[n]);
+    float t = ray_t0(s, nears[n], perturb, n, 42);
+    float last_t = t, x, y, z, dt;
+    float* px = xyzs + (size_t)point_index * 3;
+    float* pd = dirs + (size_t)point_index * 3;
+    float* pl = deltas + (size_t)point_index * 2;
+    float* pt = WITH_TS ? rays_ts + point_index : nullptr;
+    uint32_t step = 0;
+    while (t < s.far && step < num_steps) {
+        if (s.step(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = s.dx; pd[1] = s.dy; pd[2] = s.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            if constexpr (WITH_TS) { pt[0] = t; pt++; }
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R8 / R9: composite_rays_train (one thread per ray record, serial over its samples)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }  // v_exp_f32 path, as the reference's __expf
+
+__global__ __launch_bounds__(kRayBlock) void composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                     const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                     uint32_t M, uint32_t N, float* __restrict__ weights_sum,
+                                                                     float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
+                   num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        weights_sum[index] = 0;
+        depth[index] = 0;
+        image[3 * (size_t)index] = 0; image[3 * (size_t)index + 1] = 0; image[3 * (size_t)index + 2] = 0;
+        return;
+    }
+    const float* sg = sigmas + offset;
+    const float* c = rgbs + (size_t)offset * 3;
+    const float* dl = deltas + (size_t)offset * 2;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float alpha = 1.0f - fast_exp(-sg[0] * dl[0]);
+        const float weight = alpha * T;
+        r = fmaf(weight, c[0], r);
+        g = fmaf(weight, c[1], g);
+        b = fmaf(weight, c[2], b);
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        ws += weight;
+        T *= 1.0f - alpha;
+        sg++; c += 3; dl += 2;
+    }
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+__global__ __launch_bounds__(kRayBlock) void composite_train_bwd_kernel(const float* __restrict__ grad_weights_sum,
+                                                                     const float* __restrict__ grad_image,
+                                                                     const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                     const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                     const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                     uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
+                                                                     float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
+                   num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[3 * (size_t)index], gi1 = grad_image[3 * (size_t)index + 1], gi2 = grad_image[3 * (size_t)index + 2];
+    const float r_final = image[3 * (size_t)index], g_final = image[3 * (size_t)index + 1], b_final = image[3 * (size_t)index + 2];
+    const float ws_final = weights_sum[index];
+    const float* sg = sigmas + offset;
+    const float* c = rgbs + (size_t)offset * 3;
+    const float* dl = deltas + (size_t)offset * 2;
+    float* gs = grad_sigmas + offset;
+    float* gc = grad_rgbs + (size_t)offset * 3;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float alpha = 1.0f - fast_exp(-sg[0] * dl[0]);
+        const float weight = alpha * T;
+        r = fmaf(weight, c[0], r);
+        g = fmaf(weight, c[1], g);
+        b = fmaf(weight, c[2], b);
+        ws += weight;
+        T *= 1.0f - alpha;
+        gc[0] = gi0 * weight; gc[1] = gi1 * weight; gc[2] = gi2 * weight;
+        float acc = gi0 * fmaf(T, c[0], -(r_final - r));
+        acc = fmaf(gi1, fmaf(T, c[1], -(g_final - g)), acc);
+        acc = fmaf(gi2, fmaf(T, c[2], -(b_final - b)), acc);
+        acc = fmaf(gws, T - (ws_final - ws), acc);
+        gs[0] = dl[0] * acc;
+        sg++; c += 3; dl += 2; gs++; gc += 3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R10 / R11 / R12: inference
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                            const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                            uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                            const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                            float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const Dda s(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
+    float t = ray_t0(s, rays_t[n], perturb, n, (uint64_t)perturb);
+    float last_t = t, x, y, z, dt;
+    float* px = xyzs + (size_t)n * n_step * 3;
+    float* pd = dirs + (size_t)n * n_step * 3;
+    float* pl = deltas + (size_t)n * n_step * 2;
+    uint32_t step = 0;
+    while (t < s.far && step < n_step) {
+        if (s.step(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = s.dx; pd[1] = s.dy; pd[2] = s.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            step++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+                                                                float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                                float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    float t = rays_t[n];
+    const float* sg = sigmas + (size_t)n * n_step;
+    const float* c = rgbs + (size_t)n * n_step * 3;
+    const float* dl = deltas + (size_t)n * n_step * 2;
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - fast_exp(-sg[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        r = fmaf(weight, c[0], r);
+        g = fmaf(weight, c[1], g);
+        b = fmaf(weight, c[2], b);
+        if ((double)T < 1e-4) break;
+        sg++; c += 3; dl += 2;
+        step++;
+    }
+    rays_t[n] = (step < n_step) ? -1.0f : t;
+    weights_sum[index] = weight_sum;
+    depth[index] = d;
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+// pass 1: survivors per workgroup.  ws layout (uint32): [0] base (old alive_counter[0]), [1..] totals
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(uint32_t n_alive, const float* __restrict__ rays_t_old,
+                                                               const int* __restrict__ alive_counter, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t wave_tot[kBlock / kWave];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool keep = n < n_alive && rays_t_old[n] >= 0;
+    const uint64_t mask = __ballot(keep);
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_tot[threadIdx.x / kWave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kBlock / kWave; i++) tot += wave_tot[i];
+        ws[1 + blockIdx.x] = tot;
+        if (blockIdx.x == 0) ws[0] = (uint32_t)alive_counter[0];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive, int* __restrict__ rays_alive,
+                                                               const int* __restrict__ rays_alive_old, float* __restrict__ rays_t,
+                                                               const float* __restrict__ rays_t_old, int* __restrict__ alive_counter,
+                                                               const uint32_t* __restrict__ ws) {
+    __shared__ uint32_t red[kBlock / kWave];
+    __shared__ uint32_t wave_tot[kBlock / kWave];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) part += ws[1 + j];
+    part = wave_sum(part);
+    if (lane == 0) red[wid] = part;
+
+    const float t_old = n < n_alive ? rays_t_old[n] : -1.0f;
+    const bool keep = n < n_alive && t_old >= 0;
+    const uint64_t mask = __ballot(keep);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));  // survivors in lower lanes
+    if (lane == 0) wave_tot[wid] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = ws[0];
+    uint32_t block_total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kBlock / kWave; i++) {
+        before += red[i];
+        if (i < wid) before += wave_tot[i];
+        block_total += wave_tot[i];
+    }
+    if (keep) {
+        const uint32_t dst = before + rank;
+        rays_alive[dst] = rays_alive_old[n];
+        rays_t[dst] = t_old;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint32_t prior = ws[0];
+#pragma unroll
+        for (uint32_t i = 0; i < kBlock / kWave; i++) prior += red[i];
+        alive_counter[0] = (int)(prior + block_total);
+    }
+}
+
+inline dim3 grid_for(uint32_t n) { return dim3(div_up(n, kBlock)); }
+inline dim3 ray_grid_for(uint32_t n) { return dim3(div_up(n, kRayBlock)); }
+
+template <bool WITH_TS>
+int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars,
+                     float* xyzs, float* dirs, float* deltas, float* rays_ts, int32_t* rays, int32_t* counter, uint32_t perturb,
+                     void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    if (C == 0 || C > 16) {
+        set_error("march_rays_train: cascade count C=%u out of range", C);
+        return NERFTEX_ERR_INVALID;
+    }
+    const uint32_t nblocks = div_up(N, kRayBlock);
+    uint32_t* ws = static_cast<uint32_t*>(workspace(kWsMarch, sizeof(uint32_t) * (1 + (size_t)nblocks)));
+    if (!ws) return NERFTEX_ERR_HIP;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                       C, H, nears, fars, rays, counter, ws, perturb);
+    int rc = check_launch("march_rays_train(count)");
+    if (rc != NERFTEX_OK) return rc;
+    hipLaunchKernelGGL((march_write_kernel<WITH_TS>), dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                       max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb);
+    return check_launch("march_rays_train(write)");
+}
+
+}  // namespace
+}  // namespace nerftex
+
+using namespace nerftex;
+
+extern "C" int nerftex_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                                          float* nears, float* fars, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(near_far_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch("near_far_from_aabb");
+}
+
+extern "C" int nerftex_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(polar_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, radius, N, coords);
+    return check_launch("polar_from_ray");
+}
+
+extern "C" int nerftex_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(morton3D_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), coords, N, indices);
+    return check_launch("morton3D");
+}
+
+extern "C" int nerftex_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(morton3D_invert_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), indices, N, coords);
+    return check_launch("morton3D_invert");
+}
+
+extern "C" int nerftex_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(packbits_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), grid, N, density_thresh, bitfield);
+    return check_launch("packbits");
+}
+
+extern "C" int nerftex_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                        const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                        uint32_t perturb, void* stream) {
+    return march_train_impl<false>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                                   nullptr, rays, counter, perturb, stream);
+}
+
+extern "C" int nerftex_march_rays_train_differentiable(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                                       float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                       uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
+                                                       float* deltas, float* rays_ts, int32_t* rays, int32_t* counter,
+                                                       uint32_t perturb, void* stream) {
+    return march_train_impl<true>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                                  rays_ts, rays, counter, perturb, stream);
+}
+
+extern "C" int nerftex_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                                    uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image,
+                                                    void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(composite_train_fwd_kernel, ray_grid_for(N), dim3(kRayBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
+                       weights_sum, depth, image);
+    return check_launch("composite_rays_train_forward");
+}
+
+extern "C" int nerftex_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                                     const float* rgbs, const float* deltas, const int32_t* rays,
+                                                     const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                                     float* grad_sigmas, float* grad_rgbs, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(composite_train_bwd_kernel, ray_grid_for(N), dim3(kRayBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
+                       sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    return check_launch("composite_rays_train_backward");
+}
+
+extern "C" int nerftex_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                  uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                                  float* dirs, float* deltas, uint32_t perturb, void* stream) {
+    (void)nears;  // read by the reference kernel but unused (raymarching.cu:940)
+    clear_error();
+    if (n_alive == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(march_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    return check_launch("march_rays");
+}
+
+extern "C" int nerftex_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
+                                      const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                                      float* image, void* stream) {
+    clear_error();
+    if (n_alive == 0) return NERFTEX_OK;
+    hipLaunchKernelGGL(composite_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive,
+                       rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return check_launch("composite_rays");
+}
+
+extern "C" int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
+                                    const float* rays_t_old, int32_t* alive_counter, void* stream) {
+    clear_error();
+    if (n_alive == 0) return NERFTEX_OK;
+    const uint32_t nblocks = div_up(n_alive, kBlock);
+    uint32_t* ws = static_cast<uint32_t*>(workspace(kWsCompact, sizeof(uint32_t) * (1 + (size_t)nblocks)));
+    if (!ws) return NERFTEX_ERR_HIP;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_t_old, alive_counter, ws);
+    int rc = check_launch("compact_rays(count)");
+    if (rc != NERFTEX_OK) return rc;
+    hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_alive, rays_alive_old, rays_t,
+                       rays_t_old, alive_counter, ws);
+    return check_launch("compact_rays(write)");
+}

@@ -1,0 +1,119 @@
+"""`ffmlp.ffmlp` -- drop-in for the reference's ffmlp/ffmlp.py, backed by the MFMA kernels of libnerftex_hip.so.
+
+`ffmlp_forward(inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation,
+output_activation, inference=False, calc_grad_inputs=False)` (ffmlp.py:16-85) and
+`FFMLP(input_dim, output_dim, hidden_dim, num_layers, activation='relu').forward(inputs, force_grad=False)`
+(:99-168): flat fp16-computed weight vector `[hidden*in | (num_layers-1)*hidden*hidden | 16*hidden]`, batch
+padded up past the next multiple of 128 (a whole extra block when already aligned, :157-159), output padded
+to 16 columns, `torch.manual_seed(42)` side effect of reset_parameters (:141-144) -- all kept.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from nerftex_hip import check, lib, ptr, stream, timer
+
+
+class _ffmlp_forward(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.half)
+    def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference=False,
+                calc_grad_inputs=False):
+        if not inputs.is_cuda:
+            raise RuntimeError("inputs must be a CUDA tensor")
+        if inputs.dtype != torch.half or weights.dtype != torch.half:
+            # outside autocast custom_fwd does not cast; the kernels are fp16-storage only (utils.h:23 CHECK_IS_HALF)
+            inputs, weights = inputs.half(), weights.half()
+        B = inputs.shape[0]
+        inputs, weights = inputs.contiguous(), weights.contiguous()
+        outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
+        if not inference:
+            forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            tok = timer.start("ffmlp_forward")
+            check(lib.nerftex_ffmlp_forward(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                            output_activation, ptr(forward_buffer), ptr(outputs), stream()))
+            timer.stop(tok)
+            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
+            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
+        else:
+            inference_buffer = torch.empty(B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            tok = timer.start("ffmlp_inference")
+            check(lib.nerftex_ffmlp_inference(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                              output_activation, ptr(inference_buffer), ptr(outputs), stream()))
+            timer.stop(tok)
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        B = grad.shape[0]
+        grad = grad.contiguous().half()
+        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
+        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
+        grad_inputs = torch.zeros_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
+        grad_weights = torch.zeros_like(weights)
+        backward_buffer = torch.zeros(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        tok = timer.start("ffmlp_backward")
+        check(lib.nerftex_ffmlp_backward(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim, output_dim, hidden_dim,
+                                         num_layers, activation, output_activation, int(bool(calc_grad_inputs)), ptr(backward_buffer),
+                                         ptr(grad_inputs), ptr(grad_weights), stream()))
+        timer.stop(tok)
+        return (grad_inputs if calc_grad_inputs else None), grad_weights, None, None, None, None, None, None, None, None
+
+
+ffmlp_forward = _ffmlp_forward.apply
+
+_ACTIVATIONS = {"relu": 0, "exponential": 1, "sine": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5}
+
+
+def convert_activation(act):
+    return _ACTIVATIONS.get(act, 6)  # anything else -> none (ffmlp.py:89-96)
+
+
+class FFMLP(nn.Module):
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu"):
+        super().__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.activation = convert_activation(activation)
+        self.output_activation = convert_activation("none")
+        self.tensorcore_width = 16
+
+        assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
+        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
+        assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
+        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
+
+        self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
+        self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
+        self.weights = nn.Parameter(torch.zeros(self.num_parameters))
+        self.reset_parameters()
+        check(lib.nerftex_ffmlp_allocate_splitk(self.num_layers + 1))
+
+    def cleanup(self):
+        check(lib.nerftex_ffmlp_free_splitk())
+
+    def __repr__(self):
+        return (f"FFMLP: input_dim={self.input_dim} output_dim={self.output_dim} hidden_dim={self.hidden_dim} "
+                f"num_layers={self.num_layers} activation={self.activation}")
+
+    def reset_parameters(self):
+        torch.manual_seed(42)
+        bound = math.sqrt(3 / self.hidden_dim)
+        self.weights.data.uniform_(-bound, bound)
+
+    def forward(self, inputs, force_grad=False):
+        B, C = inputs.shape
+        pad = 128 - (B % 128)  # always >= 1 block of padding, like the reference
+        if pad > 0:
+            inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
+        outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                                self.activation, self.output_activation, (not self.training) and (not force_grad), inputs.requires_grad)
+        if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
+            outputs = outputs[:B, : self.output_dim]
+        return outputs

@@ -1,0 +1,135 @@
+"""ctypes binding of libnerftex_hip.so (C ABI: include/nerftex_hip.h).
+
+This is plumbing: device memory, streams and autograd come from PyTorch-ROCm, every kernel comes from
+the hand-written HIP library.  There is NO fallback: if the library is missing or a GPU op is invoked
+without it, importing / calling fails loudly (a CPU or eager-PyTorch substitute would void parity).
+
+    from nerftex_hip import lib, ptr, stream, check
+    check(lib.nerftex_packbits(ptr(grid), N, thresh, ptr(bitfield), stream()))
+"""
+import ctypes as C
+import os
+
+from ._build import CSRC, LIB_PATH, PKG_ROOT  # noqa: F401
+
+F32, F16 = 0, 1
+LAYOUT_LBC, LAYOUT_BLC = 0, 1
+
+
+from ._build import build  # noqa: E402,F401
+
+
+_u32, _f32, _i, _vp, _sz = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> argument ctypes, in the order of include/nerftex_hip.h
+_SIGNATURES = {
+    "nerftex_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _u32, _i, _i, _i, _vp],
+    "nerftex_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _vp],
+    "nerftex_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _i, _vp, _vp],
+    "nerftex_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_near_far_from_aabb": [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
+    "nerftex_polar_from_ray": [_vp, _vp, _f32, _u32, _vp, _vp],
+    "nerftex_morton3D": [_vp, _u32, _vp, _vp],
+    "nerftex_morton3D_invert": [_vp, _u32, _vp, _vp],
+    "nerftex_packbits": [_vp, _u32, _f32, _vp, _vp],
+    "nerftex_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "nerftex_march_rays_train_differentiable": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "nerftex_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "nerftex_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "nerftex_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_compact_rays": [_u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i, _vp, _vp, _vp, _vp],
+    "nerftex_ffmlp_allocate_splitk": [_sz],
+    "nerftex_ffmlp_free_splitk": [],
+    "nerftex_create_raytracer": [_vp, _u32, _vp, _u32, C.POINTER(_vp)],
+    "nerftex_destroy_raytracer": [_vp],
+    "nerftex_raytracer_trace": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+}
+EXPORTS = ["nerftex_last_error", "nerftex_version"] + list(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU / eager fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.nerftex_last_error.restype = C.c_char_p
+    lib.nerftex_version.restype = C.c_char_p
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == a symbol the header declares is not exported
+        fn.argtypes = args
+        fn.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    """Raise RuntimeError with the library's message (mirrors the reference's TORCH_CHECK / runtime_error texts)."""
+    if rc != 0:
+        msg = lib.nerftex_last_error().decode() or f"nerftex_hip call failed with status {rc}"
+        raise RuntimeError(msg)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    """torch's current HIP stream as the void* the C ABI expects."""
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def require_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+# ---- optional per-op device timing (bench.py turns it on to measure the roofline kernel live) ----
+class _Timer:
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def start(self, name):
+        if not self.enabled:
+            return None
+        import torch
+
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        return (name, a, b)
+
+    def stop(self, tok):
+        if tok is None:
+            return
+        name, a, b = tok
+        b.record()
+        self.records.setdefault(name, []).append((a, b))
+
+    def summary(self, reset=True):
+        import torch
+
+        torch.cuda.synchronize()
+        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in self.records.items()}
+        if reset:
+            self.records = {}
+        return out
+
+
+timer = _Timer()

@@ -1,0 +1,515 @@
+"""Parity tests proper: the HIP path (through the C ABI / the drop-in Python packages) vs the oracle.
+
+Bars: bit-exact for integer / index work and for the fp32 DDA + fp32 hash-grid interpolation (same
+expression trees as the oracle); stated tolerances where an order of summation or a hardware
+transcendental differs (atomics, v_exp_f32, fp16 tables).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import nerftex_hip  # noqa: F401  (fails loudly if the HIP library is missing)
+
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# =================================================================================================== gridencoder
+GRID_CASES = [
+    # name, D, L, C, base, log2T, per_level_scale, gridtype, align
+    ("fox_L16_C2", 3, 16, 2, 16, 19, 1.4472692374403782, 0, False),
+    ("curved_L8_align", 3, 8, 2, 64, 15, 1.1040895136738123, 0, True),
+    ("tiled_2d_C4", 2, 8, 4, 16, 12, 2.0, 1, False),
+    ("small_C1", 3, 6, 1, 4, 10, 1.5, 0, True),
+    ("C8_hash", 3, 4, 8, 8, 12, 2.0, 0, False),
+    ("tiled_3d_C2", 3, 5, 2, 8, 11, 1.7, 1, False),
+]
+
+
+def _grid_setup(oracle, case, B, seed, dtype):
+    name, D, L, C, base, log2T, pls, gridtype, align = case
+    rng = np.random.default_rng(seed)
+    offsets, rows = oracle.grid_offsets(D, L, pls, base, log2T, align)
+    emb = rng.uniform(-1.0, 1.0, size=(rows, C)).astype(np.float32)
+    x = rng.uniform(0.0, 1.0, size=(B, D)).astype(np.float32)
+    # edge cases: exact 0 / 1, out-of-range rows, a clustered run (same cell)
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, 0] = -0.25
+    x[3, D - 1] = 1.5
+    x[4:12] = x[12] + rng.uniform(0, 1e-4, size=(8, D)).astype(np.float32)
+    x[4:12] = np.clip(x[4:12], 0, 1)
+    return dict(D=D, L=L, C=C, base=base, S=float(np.log2(pls)), pls=pls, gridtype=gridtype, align=align, offsets=offsets, rows=rows,
+                emb=emb.astype(dtype), x=x)
+
+
+def _hip_grid_forward(s, dev, calc_grad, layout):
+    from nerftex_hip import F16, F32, check, lib, ptr, stream
+
+    emb = t(s["emb"], dev)
+    x = t(s["x"], dev)
+    off = t(s["offsets"], dev)
+    B, D, L, C = x.shape[0], s["D"], s["L"], s["C"]
+    out = torch.full((L, B, C) if layout == 0 else (B, L * C), 7.0, dtype=emb.dtype, device=dev)
+    dyd = torch.full((B, L * D * C), 7.0, dtype=emb.dtype, device=dev) if calc_grad else torch.empty(1, dtype=emb.dtype, device=dev)
+    tag = F16 if emb.dtype == torch.float16 else F32
+    check(lib.nerftex_grid_encode_forward(ptr(x), ptr(emb), ptr(off), ptr(out), B, D, C, L, s["S"], s["base"], int(calc_grad), ptr(dyd),
+                                          s["gridtype"], int(s["align"]), tag, layout, stream()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), (dyd.cpu().numpy() if calc_grad else None)
+
+
+@pytest.mark.parametrize("case", GRID_CASES, ids=[c[0] for c in GRID_CASES])
+def test_grid_forward_fp32_bit_exact(oracle, dev, case):
+    s = _grid_setup(oracle, case, 2000, 11, np.float32)
+    want, want_dyd = oracle.grid_encode_forward(s["x"], s["emb"], s["offsets"], s["S"], s["base"], True, s["gridtype"], s["align"])
+    got, got_dyd = _hip_grid_forward(s, dev, True, 0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "outputs [L,B,C] must be bit-exact in fp32"
+    assert np.array_equal(got_dyd.view(np.uint32), want_dyd.view(np.uint32)), "dy_dx must be bit-exact in fp32"
+    # [B, L*C] layout is the same numbers permuted
+    got_blc, _ = _hip_grid_forward(s, dev, False, 1)
+    B = s["x"].shape[0]
+    assert np.array_equal(got_blc, want.transpose(1, 0, 2).reshape(B, -1))
+
+
+@pytest.mark.parametrize("case", [GRID_CASES[0], GRID_CASES[2], GRID_CASES[4]], ids=lambda c: c[0])
+def test_grid_forward_fp16(oracle, dev, case):
+    s = _grid_setup(oracle, case, 1500, 12, np.float16)
+    want, want_dyd = oracle.grid_encode_forward(s["x"], s["emb"], s["offsets"], s["S"], s["base"], True, s["gridtype"], s["align"])
+    got, got_dyd = _hip_grid_forward(s, dev, True, 0)
+    # table values are O(1): the reference rounds to half after each of the 2^D corners, the HIP kernel once.
+    np.testing.assert_allclose(got.astype(np.float32), want.astype(np.float32), atol=4e-3, rtol=0)
+    # exact reference: the fp32 interpolation of the half table, rounded once
+    f32, _ = oracle.grid_encode_forward(s["x"], s["emb"].astype(np.float32), s["offsets"], s["S"], s["base"], False, s["gridtype"], s["align"])
+    assert np.array_equal(got, f32.astype(np.float16)), "fp16 output == half(fp32 interpolation)"
+    scale = float(np.abs(want_dyd.astype(np.float32)).max())
+    np.testing.assert_allclose(got_dyd.astype(np.float32), want_dyd.astype(np.float32), atol=4e-3 * scale, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", [GRID_CASES[0], GRID_CASES[2], GRID_CASES[3], GRID_CASES[4]], ids=lambda c: c[0])
+def test_grid_backward(oracle, dev, case, dtype):
+    from nerftex_hip import F16, F32, check, lib, ptr, stream
+
+    s = _grid_setup(oracle, case, 3000, 13, dtype)
+    if dtype == np.float16 and s["C"] == 1:
+        pytest.skip("reference has no working fp16 C=1 backward (empty at::Half atomicAdd stub)")
+    rng = np.random.default_rng(14)
+    B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
+    grad_lbc = (rng.standard_normal((L, B, C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)
+    want = oracle.grid_encode_backward(grad_lbc, s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
+    x, off = t(s["x"], dev), t(s["offsets"], dev)
+    tag = F16 if dtype == np.float16 else F32
+    for layout, g in ((0, grad_lbc), (1, np.ascontiguousarray(grad_lbc.transpose(1, 0, 2).reshape(B, L * C)))):
+        ge = torch.zeros(s["rows"], C, dtype=torch.float16 if dtype == np.float16 else torch.float32, device=dev)
+        gt = t(g, dev)
+        dummy = torch.zeros(1, dtype=ge.dtype, device=dev)
+        check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), B, D, C, L, s["S"], s["base"], 0, ptr(dummy),
+                                               ptr(dummy), s["gridtype"], int(s["align"]), tag, layout, stream()))
+        torch.cuda.synchronize()
+        got = ge.cpu().numpy().astype(np.float64)
+        if dtype == np.float32:  # float atomics: order-dependent rounding only
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+        else:  # packed-half atomics: every add rounds to half; error grows with the per-row hit count
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-2 * max(1e-3, np.abs(want).max()))
+        assert np.count_nonzero(got) > 0
+
+
+def test_grid_input_backward_fp32_bit_exact(oracle, dev):
+    from nerftex_hip import F32, check, lib, ptr, stream
+
+    s = _grid_setup(oracle, GRID_CASES[0], 777, 15, np.float32)
+    B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
+    _, dyd = oracle.grid_encode_forward(s["x"], s["emb"], s["offsets"], s["S"], s["base"], True, s["gridtype"], s["align"])
+    grad = np.random.default_rng(16).standard_normal((L, B, C)).astype(np.float32)
+    want = oracle.grid_input_backward(grad, dyd, D)
+    ge = torch.zeros(s["rows"], C, device=dev)
+    gi = torch.zeros(B, D, device=dev)
+    check(lib.nerftex_grid_encode_backward(ptr(t(grad, dev)), ptr(t(s["x"], dev)), None, ptr(t(s["offsets"], dev)), ptr(ge), B, D, C, L,
+                                           s["S"], s["base"], 1, ptr(t(dyd, dev)), ptr(gi), s["gridtype"], int(s["align"]), F32, 0, stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(gi.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_grid_errors_and_empty(dev):
+    from nerftex_hip import F32, lib, ptr, stream
+
+    x = torch.zeros(4, 3, device=dev)
+    emb = torch.zeros(64, 3, device=dev)
+    off = torch.tensor([0, 64], dtype=torch.int32, device=dev)
+    out = torch.zeros(4, 3, device=dev)
+    rc = lib.nerftex_grid_encode_forward(ptr(x), ptr(emb), ptr(off), ptr(out), 4, 3, 3, 1, 1.0, 4, 0, None, 0, 0, F32, 1, stream())
+    assert rc != 0 and lib.nerftex_last_error().decode() == "GridEncoding: C must be 1, 2, 4, or 8."
+    rc = lib.nerftex_grid_encode_forward(ptr(x), ptr(emb), ptr(off), ptr(out), 4, 4, 2, 1, 1.0, 4, 0, None, 0, 0, F32, 1, stream())
+    assert rc != 0 and lib.nerftex_last_error().decode() == "GridEncoding: C must be 1, 2, 4, or 8."  # bad D, same text (sic)
+    rc = lib.nerftex_grid_encode_forward(ptr(x), ptr(emb), ptr(off), ptr(out), 0, 3, 2, 1, 1.0, 4, 0, None, 0, 0, F32, 1, stream())
+    assert rc == 0  # empty batch is a no-op
+
+
+def test_grid_module_autograd(oracle, dev):
+    """GridEncoder module end to end (fp32): forward == oracle, table gradient == oracle scatter, input gradient == G3."""
+    from gridencoder import GridEncoder
+
+    torch.manual_seed(0)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096).to(dev)
+    enc.embeddings.data.uniform_(-1, 1)
+    bound = 2.0
+    xyz = (torch.rand(1000, 3, device=dev) * 2 - 1) * bound
+    xyz.requires_grad_(True)
+    out = enc(xyz, bound=bound)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+
+    x01 = ((xyz.detach() + bound) / (2 * bound)).cpu().numpy()
+    emb = enc.embeddings.detach().cpu().numpy()
+    off = enc.offsets.cpu().numpy()
+    S = float(np.log2(enc.per_level_scale))
+    want, dyd = oracle.grid_encode_forward(x01, emb, off, S, 16, True)
+    assert np.array_equal(out.detach().cpu().numpy(), want.transpose(1, 0, 2).reshape(1000, -1))
+    g_lbc = np.ascontiguousarray(w.cpu().numpy().reshape(1000, 16, 2).transpose(1, 0, 2))
+    want_ge = oracle.grid_encode_backward(g_lbc, x01, emb.shape[0], off, S, 16)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), want_ge, rtol=2e-5, atol=1e-5 * np.abs(want_ge).max())
+    want_gi = oracle.grid_input_backward(g_lbc, dyd, 3) / (2 * bound)  # chain rule through (x+bound)/(2 bound)
+    np.testing.assert_allclose(xyz.grad.cpu().numpy(), want_gi, rtol=1e-5, atol=1e-4 * np.abs(want_gi).max())
+
+
+# =================================================================================================== shencoder
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_forward_backward(oracle, dev, degree):
+    from shencoder import sh_encode
+
+    rng = np.random.default_rng(20 + degree)
+    x = rng.uniform(-1, 1, size=(1031, 3)).astype(np.float32)
+    x[:500] /= np.linalg.norm(x[:500], axis=1, keepdims=True)
+    want, want_dyd = oracle.sh_encode_forward(x, degree, True)
+    xt = t(x, dev).requires_grad_(True)
+    out = sh_encode(xt, degree, True)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(t(g, dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=2e-6, atol=3e-6)
+    want_gi = oracle.sh_encode_backward(g, degree, want_dyd)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), want_gi, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(want_gi).max()))
+
+
+def test_sh_golden_from_reference_text(dev, golden_dir):
+    """Direct check of the HIP kernel against vectors evaluated from the reference's own polynomials."""
+    import os
+
+    from nerftex_hip import check, lib, ptr, stream
+
+    g = np.load(os.path.join(golden_dir, "sh_golden.npz"))
+    x = t(g["inputs"], dev)
+    B = x.shape[0]
+    for degree in (4, 6, 8):
+        n = degree * degree
+        out = torch.empty(B, n, device=dev)
+        dyd = torch.empty(B, 3 * n, device=dev)
+        check(lib.nerftex_sh_encode_forward(ptr(x), ptr(out), B, 3, degree, 1, ptr(dyd), stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), g["outputs"][:, :n], rtol=3e-6, atol=3e-6)
+        d = dyd.cpu().numpy().reshape(B, 3, n)
+        for k, name in enumerate(("dx", "dy", "dz")):
+            want = g[name][:, :n]
+            np.testing.assert_allclose(d[:, k], want, rtol=5e-6, atol=5e-6 * max(1.0, np.abs(want).max()))
+
+
+def test_sh_bad_degree(dev):
+    from nerftex_hip import lib, ptr, stream
+
+    x = torch.zeros(4, 3, device=dev)
+    out = torch.zeros(4, 81, device=dev)
+    assert lib.nerftex_sh_encode_forward(ptr(x), ptr(out), 4, 3, 9, 0, None, stream()) != 0
+    assert "degree" in lib.nerftex_last_error().decode()
+
+
+# =================================================================================================== raymarching
+@pytest.fixture(scope="module")
+def scene_data():
+    from ngp_harness import scene
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, thresh, bits = sc.bitfield()
+    return sc, grid, thresh, bits
+
+
+def _rays(n, seed, radius=2.0):
+    from ngp_harness import scene
+
+    o, d = scene.train_batch(n, radius=radius, seed=seed, n_views=3)
+    # a few degenerate rays: axis-aligned (1/0 = inf is relied upon), pointing away, starting inside
+    d[0] = [0, 0, -1]
+    o[0] = [0.1, 0.2, 1.9]
+    d[1] = [1, 0, 0]
+    o[1] = [-3, 0.3, 0.1]
+    d[2] = -d[2]
+    o[3] = [0.05, -0.1, 0.02]
+    return o, d
+
+
+def test_utils_bit_exact(oracle, dev, scene_data):
+    import raymarching
+
+    sc, grid, thresh, bits = scene_data
+    o, d = _rays(5000, 3)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = raymarching.near_far_from_aabb(t(o, dev), t(d, dev), t(aabb, dev), 0.2)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    assert np.array_equal(nears.cpu().numpy().view(np.uint32), wn.view(np.uint32))
+    assert np.array_equal(fars.cpu().numpy().view(np.uint32), wf.view(np.uint32))
+    assert (wn == np.float32(3.402823466e38)).sum() > 0, "case must contain missing rays"
+
+    rng = np.random.default_rng(4)
+    c = rng.integers(0, 128, size=(100000, 3)).astype(np.int32)
+    m = raymarching.morton3D(t(c, dev))
+    assert np.array_equal(m.cpu().numpy(), oracle.morton3D(c))
+    assert np.array_equal(raymarching.morton3D_invert(m).cpu().numpy(), c)
+
+    pb = raymarching.packbits(t(grid, dev), float(thresh))
+    assert np.array_equal(pb.cpu().numpy(), bits)
+    grid2 = grid.copy()
+    grid2[0, :64] = -1.0
+    grid2[1, 100] = thresh  # equal -> not set
+    assert np.array_equal(raymarching.packbits(t(grid2, dev), float(thresh)).cpu().numpy(), oracle.packbits(grid2, thresh))
+
+    coords = raymarching.polar_from_ray(t(o * 0.2, dev), t(d, dev), 3.0).cpu().numpy()
+    np.testing.assert_allclose(coords, oracle.polar_from_ray(o * 0.2, d, 3.0), atol=2e-6)
+
+
+@pytest.mark.parametrize("perturb", [False, True], ids=["noperturb", "perturb"])
+@pytest.mark.parametrize("cfg", [dict(bound=2.0, dt_gamma=1 / 128, N=4096), dict(bound=1.0, dt_gamma=0.0, N=1500)], ids=["fox", "bound1"])
+def test_march_rays_train_bit_exact(oracle, dev, cfg, perturb):
+    import raymarching
+    from ngp_harness import scene
+
+    sc = scene.Scene(bound=cfg["bound"], seed=1)
+    _, _, bits = sc.bitfield()
+    N = cfg["N"]
+    o, d = _rays(N, 5, radius=1.5 if cfg["bound"] == 1.0 else 2.0)
+    b = cfg["bound"]
+    aabb = np.array([-b, -b, -b, b, b, b], np.float32)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    M = N * 1024
+    wx, wd, wl, wr, wc, wts = oracle.march_rays_train(o, d, b, bits, sc.cascade, 128, wn, wf, M, perturb, cfg["dt_gamma"], 1024, with_ts=True)
+
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(t(o, dev), t(d, dev), b, t(bits, dev), sc.cascade, 128, t(wn, dev), t(wf, dev),
+                                                            counter, -1, perturb, 128, False, cfg["dt_gamma"], 1024)
+    torch.cuda.synchronize()
+    assert counter.cpu().tolist() == wc.tolist()
+    assert np.array_equal(rays.cpu().numpy(), wr), "per-ray (id, offset, num_steps) must be bit-exact"
+    m = int(wc[0])
+    assert m > 20 * N // 4
+    assert xyzs.shape[0] == m + 128 - m % 128
+    for got, want in ((xyzs, wx), (dirs, wd), (deltas, wl)):
+        got = got.cpu().numpy()
+        assert np.array_equal(got[:m].view(np.uint32), want[:m].view(np.uint32))
+        assert not got[m:].any()
+
+    # differentiable variant: same + rays_ts
+    counter.zero_()
+    from nerftex_hip import check, lib, ptr, stream
+
+    x2 = torch.zeros(m + 1, 3, device=dev); d2 = torch.zeros(m + 1, 3, device=dev); l2 = torch.zeros(m + 1, 2, device=dev)
+    ts = torch.zeros(m + 1, 1, device=dev); r2 = torch.zeros(N, 3, dtype=torch.int32, device=dev)
+    check(lib.nerftex_march_rays_train_differentiable(ptr(t(o, dev)), ptr(t(d, dev)), ptr(t(bits, dev)), b, cfg["dt_gamma"], 1024, N,
+                                                      sc.cascade, 128, m + 1, ptr(t(wn, dev)), ptr(t(wf, dev)), ptr(x2), ptr(d2), ptr(l2),
+                                                      ptr(ts), ptr(r2), ptr(counter), int(perturb), stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(ts.cpu().numpy()[:m].view(np.uint32), wts[:m].view(np.uint32))
+    assert np.array_equal(x2.cpu().numpy()[:m], wx[:m])
+
+
+def test_march_rays_train_overflow_drop_rule(oracle, dev, scene_data):
+    """M smaller than the demand: rays whose span reaches M are dropped (offset+steps >= M), the rest are intact."""
+    import raymarching
+
+    sc, _, _, bits = scene_data
+    N = 2048
+    o, d = _rays(N, 6)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    full = oracle.march_rays_train(o, d, 2.0, bits, sc.cascade, 128, wn, wf, N * 1024, False, 1 / 128, 1024)
+    total = int(full[4][0])
+    M = (total // 2) // 128 * 128  # the wrapper rounds mean_count up past a multiple of 128
+    wx, wd, wl, wr, wc, _ = oracle.march_rays_train(o, d, 2.0, bits, sc.cascade, 128, wn, wf, M + 128, False, 1 / 128, 1024)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(t(o, dev), t(d, dev), 2.0, t(bits, dev), sc.cascade, 128, t(wn, dev), t(wf, dev),
+                                                            counter, M, False, 128, False, 1 / 128, 1024)
+    torch.cuda.synchronize()
+    assert xyzs.shape[0] == M + 128
+    assert counter.cpu().tolist() == wc.tolist() and int(wc[0]) == total  # the counter still reports the full demand
+    assert np.array_equal(rays.cpu().numpy(), wr)
+    assert np.array_equal(xyzs.cpu().numpy(), wx) and np.array_equal(deltas.cpu().numpy(), wl)
+    dropped = (wr[:, 1] + wr[:, 2] >= M + 128) & (wr[:, 2] > 0)
+    assert dropped.sum() > 0
+
+    # composite must zero the dropped rays and ignore their (absent) samples
+    m = M + 128
+    rng = np.random.default_rng(7)
+    sig = rng.uniform(0, 30, size=m).astype(np.float32)
+    rgb = rng.uniform(0, 1, size=(m, 3)).astype(np.float32)
+    ws, dep, img = raymarching.composite_rays_train(t(sig, dev), t(rgb, dev), deltas, rays)
+    w_ws, w_dep, w_img = oracle.composite_rays_train_forward(sig, rgb, wl, wr)
+    np.testing.assert_allclose(ws.cpu().numpy(), w_ws, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(img.cpu().numpy(), w_img, rtol=2e-5, atol=1e-6)
+    assert not ws.cpu().numpy()[dropped].any()
+
+
+def test_composite_train_forward_backward(oracle, dev, scene_data):
+    import raymarching
+
+    sc, _, _, bits = scene_data
+    N = 3000
+    o, d = _rays(N, 8)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    _, _, wl, wr, wc, _ = oracle.march_rays_train(o, d, 2.0, bits, sc.cascade, 128, wn, wf, N * 1024, True, 1 / 128, 1024)
+    m = int(wc[0]) + 1
+    wl = wl[:m]
+    rng = np.random.default_rng(9)
+    sig = rng.gamma(1.0, 8.0, size=m).astype(np.float32)
+    rgb = rng.uniform(0, 1, size=(m, 3)).astype(np.float32)
+    w_ws, w_dep, w_img = oracle.composite_rays_train_forward(sig, rgb, wl, wr)
+
+    sg = t(sig, dev).requires_grad_(True)
+    cg = t(rgb, dev).requires_grad_(True)
+    ws, dep, img = raymarching.composite_rays_train(sg, cg, t(wl, dev), t(wr, dev))
+    # 1e-4 rel class (v_exp_f32 vs libm expf); observed far tighter
+    np.testing.assert_allclose(ws.detach().cpu().numpy(), w_ws, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep.detach().cpu().numpy(), w_dep, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), w_img, rtol=1e-5, atol=1e-6)
+
+    # closed form of the reference's Python renderer (nerf/renderer.py:269-271): alpha * cumprod(1 - alpha)
+    k = int(np.argmax(wr[:, 2]))
+    off, cnt = int(wr[k, 1]), int(wr[k, 2])
+    a = 1 - np.exp(-sig[off:off + cnt].astype(np.float64) * wl[off:off + cnt, 0])
+    wts = a * np.cumprod(np.concatenate([[1.0], 1 - a]))[:-1]
+    np.testing.assert_allclose(ws.detach().cpu().numpy()[int(wr[k, 0])], wts.sum(), rtol=1e-5)
+    np.testing.assert_allclose(img.detach().cpu().numpy()[int(wr[k, 0])], (wts[:, None] * rgb[off:off + cnt]).sum(0), rtol=1e-5, atol=1e-6)
+
+    g_ws = rng.standard_normal(N).astype(np.float32)
+    g_img = rng.standard_normal((N, 3)).astype(np.float32)
+    (ws * t(g_ws, dev)).sum().backward(retain_graph=True)
+    gs1 = sg.grad.clone(); sg.grad = None; cg.grad = None
+    ((ws * t(g_ws, dev)).sum() + (img * t(g_img, dev)).sum() + dep.sum()).backward()  # grad_depth is ignored by design
+    w_gs, w_gc = oracle.composite_rays_train_backward(g_ws, g_img, sig, rgb, wl, wr, w_ws, w_img)
+    scale = np.abs(w_gs).max()
+    np.testing.assert_allclose(sg.grad.cpu().numpy(), w_gs, rtol=2e-4, atol=2e-6 * scale)
+    np.testing.assert_allclose(cg.grad.cpu().numpy(), w_gc, rtol=1e-5, atol=1e-7)
+    assert gs1.abs().sum() > 0
+
+
+def test_inference_loop_matches_oracle(oracle, dev, scene_data):
+    """march_rays -> composite_rays -> compact_rays, driven exactly like nerf/renderer.py:436-487, on both sides."""
+    import raymarching
+
+    sc, _, _, bits = scene_data
+    N = 4000
+    o, d = _rays(N, 10)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    rng = np.random.default_rng(11)
+
+    def field(xyzs):  # deterministic stand-in for the network, evaluated on the host for both sides
+        sig = sc.density(xyzs).astype(np.float32)
+        rgb = (0.5 + 0.5 * np.sin(xyzs * 3.0)).astype(np.float32)
+        return sig, rgb
+
+    # ---- oracle side
+    ws_o = np.zeros(N, np.float32); dep_o = np.zeros(N, np.float32); img_o = np.zeros((N, 3), np.float32)
+    alive = [np.arange(N, dtype=np.int32), np.zeros(N, np.int32)]
+    tt = [wn.copy(), np.zeros(N, np.float32)]
+    # ---- HIP side
+    ot, dt_, bt, nt, ft = t(o, dev), t(d, dev), t(bits, dev), t(wn, dev), t(wf, dev)
+    ws = torch.zeros(N, device=dev); dep = torch.zeros(N, device=dev); img = torch.zeros(N, 3, device=dev)
+    rays_alive = torch.zeros(2, N, dtype=torch.int32, device=dev)
+    rays_t = torch.zeros(2, N, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    n_alive, step, i = N, 0, 0
+    iters = 0
+    while step < 1024:
+        if step == 0:
+            torch.arange(N, out=rays_alive[0]); rays_t[0] = nt
+        else:
+            cnt.zero_()
+            raymarching.compact_rays(n_alive, rays_alive[i % 2], rays_alive[(i + 1) % 2], rays_t[i % 2], rays_t[(i + 1) % 2], cnt)
+            ra, rt, k = oracle.compact_rays(n_alive, alive[(i + 1) % 2], tt[(i + 1) % 2], N)
+            alive[i % 2], tt[i % 2] = ra, rt
+            n_new = int(cnt.item())
+            assert n_new == k
+            assert np.array_equal(rays_alive[i % 2][:k].cpu().numpy(), ra[:k]), "compaction must be order-preserving"
+            assert np.array_equal(rays_t[i % 2][:k].cpu().numpy().view(np.uint32), rt[:k].view(np.uint32))
+            n_alive = n_new
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xo, do, lo = oracle.march_rays(n_alive, n_step, alive[i % 2], tt[i % 2], o, d, 2.0, bits, sc.cascade, 128, wn, wf, 128, 0, 1 / 128, 1024)
+        xg, dg, lg = raymarching.march_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], ot, dt_, 2.0, bt, sc.cascade, 128, nt, ft, 128,
+                                            False, 1 / 128, 1024)
+        assert np.array_equal(xg.cpu().numpy().view(np.uint32), xo.view(np.uint32))
+        assert np.array_equal(lg.cpu().numpy().view(np.uint32), lo.view(np.uint32))
+        assert np.array_equal(dg.cpu().numpy(), do)
+        sig, rgb = field(xo)
+        oracle.composite_rays(n_alive, n_step, alive[i % 2], tt[i % 2], sig, rgb, lo, ws_o, dep_o, img_o)
+        raymarching.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], t(sig, dev), t(rgb, dev), lg, ws, dep, img)
+        # termination decisions (rays_t == -1) must agree; t itself is bit-exact (sums of deltas)
+        assert np.array_equal(rays_t[i % 2][:n_alive].cpu().numpy().view(np.uint32), tt[i % 2][:n_alive].view(np.uint32))
+        step += n_step
+        i += 1
+        iters += 1
+    assert iters > 5
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_o, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(img.cpu().numpy(), img_o, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep.cpu().numpy(), dep_o, rtol=1e-5, atol=1e-5)
+    assert (ws_o > 0.5).mean() > 0.2
+
+
+def test_march_rays_perturb_seed(oracle, dev, scene_data):
+    import raymarching
+
+    sc, _, _, bits = scene_data
+    N = 1000
+    o, d = _rays(N, 12)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    alive = np.arange(N, dtype=np.int32)[::-1].copy()
+    xo, _, lo = oracle.march_rays(N, 4, alive, wn[alive], o, d, 2.0, bits, sc.cascade, 128, wn, wf, 128, 7, 1 / 128, 1024)
+    xg, _, lg = raymarching.march_rays(N, 4, t(alive, dev), t(wn[alive], dev), t(o, dev), t(d, dev), 2.0, t(bits, dev), sc.cascade, 128,
+                                       t(wn, dev), t(wf, dev), 128, 7, 1 / 128, 1024)
+    assert np.array_equal(xg.cpu().numpy().view(np.uint32), xo.view(np.uint32))
+    assert np.array_equal(lg.cpu().numpy().view(np.uint32), lo.view(np.uint32))
+
+
+def test_empty_and_ragged(dev):
+    import raymarching
+
+    z3 = torch.zeros(0, 3, device=dev)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev)
+    n, f = raymarching.near_far_from_aabb(z3, z3, aabb, 0.2)
+    assert n.shape == (0,) and f.shape == (0,)
+    assert raymarching.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=dev)).shape == (0,)
+    ws, dep, img = raymarching.composite_rays_train(torch.zeros(5, device=dev), torch.zeros(5, 3, device=dev), torch.zeros(5, 2, device=dev),
+                                                    torch.zeros(0, 3, dtype=torch.int32, device=dev))
+    assert ws.shape == (0,) and img.shape == (0, 3)
+    # a batch that is not a multiple of the wave / workgroup size, all rays missing the box
+    o = torch.full((77, 3), 10.0, device=dev)
+    d = torch.tensor([[1.0, 0, 0]], device=dev).repeat(77, 1)
+    n, f = raymarching.near_far_from_aabb(o, d, aabb, 0.2)
+    bits = torch.full((128 ** 3 // 8,), 255, dtype=torch.uint8, device=dev)
+    c = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, n, f, c, -1, False, 128, False, 0, 1024)
+    assert c.cpu().tolist() == [0, 77] and rays[:, 2].sum().item() == 0 and xyzs.shape[0] == 128
