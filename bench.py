@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-samples/s (train) of the NeRF-Texture rendering hot path on MI355X, + rendered Mpix/s.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full pass of the hot path over one batch of synthetic rays, exactly the sequence of
+nerf/utils.py:1011-1022 + nerf/renderer.py:338-425 of the reference:
+    near_far_from_aabb -> march_rays_train -> hash-grid encode -> sigma MLP -> SH encode -> colour MLP ->
+    composite_rays_train -> MSE loss -> backward through the same chain -> (N>1: one RCCL all-reduce of the flat
+    gradient) -> GradScaler.step(Adam) -> every 16 steps the `mean_count` read-back of update_extra_state.
+Workload = BASELINE.json configs[1]: fox-style scene, L=16 F=2 hash grid (T=2^19, desired 2048*bound, bound 2),
+HIP gridencoder + raymarching + shencoder, MLPs (2x64 / 3x64, nn.Linear) on PyTorch-ROCm, 800x800 random-pose
+pixels, 4096 rays per batch per GPU, fp16 autocast like the reference's `-O`.  `--mlp ffmlp --rays 8192` is
+configs[2].  Inputs are resident in HBM before the timed region; data = synthetic, weights = seeded random init.
+
+Prints ONE JSON line (rank 0).  `value` = ray samples actually marched (sum over steps and ranks of the
+march_rays_train counter) / max-over-ranks wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "nerf-texture_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per batch PER GPU (weak scaling)")
+    ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="torch")
+    ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
+    ap.add_argument("--bound", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args, sc, bits, field_state, n_rays):
+    """The oracle port of ONE training step (forward + backward) on the host, single thread, on a bounded sample.
+
+    R1 + R6 + G1 + MLPs + S1 + R8 forward, R9 + MLP + G2 backward: oracle C for every op the reference implements
+    natively, torch-CPU (1 thread) autograd for the two small MLPs (the reference's "MLP still PyTorch")."""
+    from ngp_harness import scene
+    from oracle import oracle as orc
+
+    torch.set_num_threads(1)
+    o, d = scene.train_batch(n_rays, seed=1234)
+    b = args.bound
+    aabb = np.array([-b, -b, -b, b, b, b], np.float32)
+    emb = field_state["emb"]
+    offsets = field_state["offsets"]
+    S = field_state["S"]
+    sig_w = [torch.from_numpy(w) for w in field_state["sigma_w"]]
+    col_w = [torch.from_numpy(w) for w in field_state["color_w"]]
+    cascade = sc.cascade
+
+    def step():
+        nears, fars = orc.near_far_from_aabb(o, d, aabb, 0.2)
+        xyzs, dirs, deltas, rays, counter, _ = orc.march_rays_train(o, d, b, bits, cascade, 128, nears, fars, n_rays * 1024, True, 1 / 128, 1024)
+        m = int(counter[0])
+        m_pad = m + 128 - m % 128
+        xyzs, dirs, deltas = xyzs[:m_pad], dirs[:m_pad], deltas[:m_pad]
+        x01 = (xyzs + b) / (2 * b)
+        feat_lbc, _ = orc.grid_encode_forward(x01, emb, offsets, S, 16, False, 0, True)
+        feat = torch.from_numpy(np.ascontiguousarray(feat_lbc.transpose(1, 0, 2).reshape(m_pad, -1))).requires_grad_(True)
+        sh, _ = orc.sh_encode_forward(dirs, 4)
+        ws_ = [w.clone().requires_grad_(True) for w in sig_w + col_w]
+        h = feat
+        for i, w in enumerate(ws_[: len(sig_w)]):
+            h = h @ w.t()
+            if i != len(sig_w) - 1:
+                h = torch.relu(h)
+        sigma = torch.exp(h[:, 0])
+        hc = torch.cat([torch.from_numpy(sh), h[:, 1:]], dim=-1)
+        for i, w in enumerate(ws_[len(sig_w):]):
+            hc = hc @ w.t()
+            if i != len(col_w) - 1:
+                hc = torch.relu(hc)
+        rgb = torch.sigmoid(hc)
+        sg, cg = sigma.detach().numpy(), rgb.detach().numpy()
+        wsum, depth, image = orc.composite_rays_train_forward(sg, cg, deltas, rays)
+        pred = image + (1 - wsum)[:, None]
+        g_img = (2.0 / pred.size) * (pred - 0.5)
+        g_ws = -g_img.sum(-1)
+        gs, gc = orc.composite_rays_train_backward(g_ws.astype(np.float32), g_img.astype(np.float32), sg, cg, deltas, rays, wsum, image)
+        torch.autograd.backward([sigma, rgb], [torch.from_numpy(gs), torch.from_numpy(gc)])
+        g_lbc = np.ascontiguousarray(feat.grad.numpy().reshape(m_pad, 16, 2).transpose(1, 0, 2))
+        orc.grid_encode_backward(g_lbc, x01, emb.shape[0], offsets, S, 16, 0, True)
+        return m
+
+    step()  # warm caches / page in the table
+    t0 = time.perf_counter()
+    total, reps = 0, 0
+    while time.perf_counter() - t0 < 10.0 and reps < 50:
+        total += step()
+        reps += 1
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    return {
+        "value": total / dt,
+        "unit": "ray-samples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} training steps (fwd+bwd, no optimizer) of {n_rays} rays / ~{total // max(reps, 1)} samples each, oracle C + 1-thread torch MLPs, "
+                  f"host has {os.cpu_count()} hardware threads",
+    }
+
+
+# ----------------------------------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    from ngp_harness import dp, scene
+
+    rank, world, local = dp.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import nerftex_hip
+    from ngp_harness.model import NGPField, Renderer
+
+    # ---- scene + inputs, resident in HBM before anything is timed
+    sc = scene.Scene(bound=args.bound, seed=0)
+    grid, thresh, bits = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=args.bound, mlp=args.mlp).to(dev)
+    torch.manual_seed(1)  # FFMLP.reset_parameters reseeds with 42; give the table its own stream
+    field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
+    renderer.set_occupancy(torch.from_numpy(grid).to(dev))
+    assert np.array_equal(renderer.density_bitfield.cpu().numpy(), bits), "packbits parity (HIP vs numpy)"
+
+    n_pool = 8
+    n_global = args.rays * world
+    pool = []
+    for k in range(n_pool):
+        o, d = scene.train_batch(n_global, seed=100 + k, n_views=4)
+        lo, hi = dp.shard(n_global, rank, world)
+        pool.append((torch.from_numpy(o[lo:hi]).to(dev), torch.from_numpy(d[lo:hi]).to(dev)))
+    gt = torch.rand(n_pool, args.rays, 3, device=dev)
+
+    opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    reducer = dp.FlatGradAllReduce(field.parameters())
+    reducer.broadcast_parameters()
+    use_amp = args.dtype == "fp16"
+    scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
+    total_samples = torch.zeros((), dtype=torch.int64, device=dev)
+    dt_gamma = 1 / 128
+
+    field.train()
+
+    def train_step(k, count=True):
+        ro, rd = pool[k % n_pool]
+        reducer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+            image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024)
+            loss = torch.nn.functional.mse_loss(image, gt[k % n_pool])
+        scaler.scale(loss).backward()
+        reducer.all_reduce()
+        scaler.step(opt)
+        scaler.update()
+        if count:
+            total_samples.add_(counter[0].to(torch.int64))
+        if renderer.local_step == 16:  # update_extra_state cadence (nerf/utils.py:1011): mean_count read-back
+            renderer.update_mean_count()
+            renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
+
+    # ---- priming = the reference's first 16 "epoch-0" steps: full-size buffers until a mean sample count exists
+    for k in range(2):
+        train_step(k, count=False)
+    renderer.update_mean_count()
+    renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
+    for k in range(args.warmup):
+        train_step(k, count=False)
+
+    nerftex_hip.timer.enabled = True
+    nerftex_hip.timer.only = {"grid_encode_forward", "grid_encode_backward"}
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        train_step(k)
+    torch.cuda.synchronize()
+    dp.barrier()
+    t1 = time.perf_counter()
+    nerftex_hip.timer.enabled = False
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    samples = total_samples.clone()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(samples, op=dist.ReduceOp.SUM)
+    elapsed = float(elapsed.item())
+    samples = int(samples.item())
+    op_ms = nerftex_hip.timer.summary()
+
+    # ---- roofline of the dominant kernel (hash-grid gather / scatter), measured live with events on the launch stream
+    M_launch = renderer.mean_count + 128 - renderer.mean_count % 128  # rows per launch (padded like raymarching.py:198-201)
+    s_bytes = 2 if use_amp else 4
+    bytes_fwd = 12 + 8 * 16 * 2 * s_bytes + 16 * 2 * s_bytes  # 588 B (fp16) / 1164 B (fp32) per point
+    bytes_bwd = 12 + 16 * 2 * s_bytes + 8 * 16 * 2 * s_bytes
+    kern = {}
+    for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
+        if name in op_ms and op_ms[name]:
+            ms = float(np.mean(op_ms[name]))
+            kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp}
+    dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
+    roofline = None
+    if dominant:
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
+            "other": {k: v for k, v in kern.items() if k != dominant},
+            "note": "event pairs include the launch gap; table (24-48 MiB) is Infinity-Cache resident, see DESIGN.md",
+        }
+
+    # ---- rendered Mpix/s: one 800x800 frame through the reference's inference loop (nerf/renderer.py:436-487)
+    mpix = None
+    if not args.no_infer and rank == 0:
+        field.eval()
+        rng = np.random.default_rng(7)
+        pose = scene.rand_poses(1, 2.0, rng)[0]
+        o, d = scene.get_rays(pose, scene.intrinsics(800, 800), 800, 800)
+        ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+            renderer.render_infer(ro, rd, dt_gamma=dt_gamma)  # warm-up frame
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            n_frames = 3
+            for _ in range(n_frames):
+                img, _, n_inf = renderer.render_infer(ro, rd, dt_gamma=dt_gamma)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+        mpix = {"mpix_per_s": 0.64 * n_frames / (t3 - t2), "ms_per_frame": (t3 - t2) / n_frames * 1e3, "samples_per_frame": int(n_inf)}
+        field.train()
+    dp.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        layers = lambda net: [l.weight.detach().float().cpu().numpy() for l in net]  # noqa: E731
+        if args.mlp == "torch":
+            sw, cw = layers(field.sigma_net), layers(field.color_net)
+        else:  # same shapes, values irrelevant for timing
+            sw = [np.zeros((64, 32), np.float32), np.zeros((16, 64), np.float32)]
+            cw = [np.zeros((64, 31), np.float32), np.zeros((64, 64), np.float32), np.zeros((3, 64), np.float32)]
+        state = dict(emb=field.encoder.embeddings.detach().float().cpu().numpy(), offsets=field.encoder.offsets.cpu().numpy(),
+                     S=float(np.log2(field.encoder.per_level_scale)), sigma_w=sw, color_w=cw)
+        cpu = cpu_baseline(args, sc, bits, state, args.cpu_rays)
+
+    if rank == 0:
+        out = {
+            "metric": "ray-samples/s (train)",
+            "value": samples / elapsed,
+            "unit": "ray-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16" if use_amp else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("configs[1]" if args.mlp == "torch" else "configs[2]") + ": fox-style scene, hashgrid L=16 F=2 T=2^19 + "
+                            + ("nn.Linear 2x64/3x64 MLPs (PyTorch-ROCm)" if args.mlp == "torch" else "FFMLP 2x64/3x64 on MFMA")
+                            + ", HIP gridencoder+raymarching+shencoder, 800x800 random-pose pixels",
+                "rays_per_batch_per_gpu": args.rays, "global_rays": n_global, "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
+                "samples_per_step_per_gpu": samples / args.steps / world, "mean_count": renderer.mean_count, "parallelism": f"dp{world}",
+                "optimizer": "Adam(eps=1e-15)+GradScaler" if use_amp else "Adam(eps=1e-15)",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "rendered": mpix,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

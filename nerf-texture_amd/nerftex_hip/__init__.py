@@ -103,10 +103,11 @@ def require_contiguous(t, name):
 class _Timer:
     def __init__(self):
         self.enabled = False
+        self.only = None  # optional set of op names to time (keeps the event overhead off everything else)
         self.records = {}
 
     def start(self, name):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and name not in self.only):
             return None
         import torch
 

@@ -1,0 +1,98 @@
+"""Data parallelism for the hot path: rays are sharded across one-process-per-GPU ranks, every rank keeps a
+full replica of the hash table + MLP weights, and ONE all-reduce per optimizer step sums the flat gradient.
+
+The reference only wraps its model in torch DDP and never enables it (nerf/utils.py:439-441, world_size=1); DDP
+would bucket the 48 MiB table gradient into many NCCL ring all-reduces.  Here the gradient of every parameter is
+a VIEW into one contiguous fp32 buffer, so the exchange is a single RCCL all-reduce with no pack / unpack copies
+(xGMI is point-to-point: one large collective per step is the cheap shape).  State that must stay identical on
+all ranks besides the weights: the occupancy bitfield (same seed / same analytic scene on every rank here) and
+`mean_count` (all-reduce MAX so every rank sizes its sample buffers alike).
+
+backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard(n_global, rank, world):
+    """Contiguous shard [lo, hi) of a global ray batch (rank r gets rays [r*n/w, (r+1)*n/w))."""
+    per = n_global // world
+    lo = rank * per
+    hi = n_global if rank == world - 1 else lo + per
+    return lo, hi
+
+
+class FlatGradAllReduce:
+    """Owns one flat fp32 gradient buffer; parameters' .grad are views into it."""
+
+    def __init__(self, params, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.average = average
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero_grad(self):
+        self.flat.zero_()
+
+    def broadcast_parameters(self, src=0):
+        if world_size() > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src)
+
+    def all_reduce(self, extra=None):
+        """Sum (then average) the whole gradient in one collective. `extra`: optional 1-D float tensor (e.g. loss,
+        found-inf flag) reduced in the same call by riding at the end of the buffer is not needed here: it is a
+        second, tiny all-reduce."""
+        w = world_size()
+        if w == 1:
+            return extra
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self.average:
+            self.flat.div_(w)
+        if extra is not None:
+            dist.all_reduce(extra, op=dist.ReduceOp.SUM)
+        return extra
+
+
+def all_reduce_max_int(value, device):
+    if world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

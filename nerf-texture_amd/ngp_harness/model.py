@@ -1,0 +1,184 @@
+"""The reference's ngp field + `run_cuda` control flow, restated compactly as the bench / test harness.
+
+`NGPField` follows nerf/network_ff.py:11-123 (FFMLP variant, BASELINE config 3) and nerf/network.py:10-124
+(`nn.Linear` variant, BASELINE config 2 "MLP still PyTorch"):  hash grid (L=16, F=2, base 16, T=2^19,
+desired 2048*bound, align_corners=True -- tools/encoding.py:45) -> sigma net -> trunc_exp;  SH(4) ++ 15 geo
+features (++ 1 zero pad for FFMLP) -> colour net -> sigmoid.  `Renderer` reproduces the call sequence of
+nerf/renderer.py:338-500 (`run_cuda` train and inference branches) and :566-660 (`update_extra_state`
+bookkeeping: step counter ring, mean_count) against the drop-in packages -- it is the "caller" the hot path
+serves, kept minimal: no GUI, no dataset, no light models.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.amp import custom_bwd, custom_fwd
+
+import raymarching
+from ffmlp import FFMLP
+from gridencoder import GridEncoder
+from shencoder import SHEncoder
+
+
+class _trunc_exp(torch.autograd.Function):  # tools/activation.py:5-17
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _trunc_exp.apply
+
+
+class NGPField(nn.Module):
+    def __init__(self, bound=2.0, mlp="torch", num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64):
+        super().__init__()
+        assert mlp in ("torch", "ffmlp")
+        self.bound = bound
+        self.mlp = mlp
+        self.geo_feat_dim = geo_feat_dim
+        self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                                   desired_resolution=2048 * bound, gridtype="hash", align_corners=True)
+        self.encoder_dir = SHEncoder(input_dim=3, degree=4)
+        in_dim, in_dir = self.encoder.output_dim, self.encoder_dir.output_dim
+        if mlp == "ffmlp":
+            self.sigma_net = FFMLP(input_dim=in_dim, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
+            self.color_net = FFMLP(input_dim=in_dir + geo_feat_dim + 1, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
+        else:
+            dims = [in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]
+            self.sigma_net = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
+            dims = [in_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3]
+            self.color_net = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
+
+    @staticmethod
+    def _chain(layers, h):
+        for i, layer in enumerate(layers):
+            h = layer(h)
+            if i != len(layers) - 1:
+                h = F.relu(h, inplace=True)
+        return h
+
+    def _sigma_feat(self, x):
+        x = self.encoder(x, bound=self.bound)
+        h = self.sigma_net(x) if self.mlp == "ffmlp" else self._chain(self.sigma_net, x)
+        return trunc_exp(h[..., 0]), h[..., 1:]
+
+    def forward(self, x, d, **kwargs):
+        sigma, geo_feat = self._sigma_feat(x)
+        d = self.encoder_dir(d)
+        if self.mlp == "ffmlp":
+            pad = torch.zeros_like(geo_feat[..., :1])  # manual padding to 32 inputs (network_ff.py:94-96)
+            h = self.color_net(torch.cat([d, geo_feat, pad], dim=-1))
+        else:
+            h = self._chain(self.color_net, torch.cat([d.to(geo_feat.dtype), geo_feat], dim=-1))
+        return sigma, torch.sigmoid(h), {}
+
+    def density(self, x):
+        sigma, geo_feat = self._sigma_feat(x)
+        return {"sigma": sigma, "geo_feat": geo_feat}
+
+    def get_params(self, lr):
+        return [{"params": self.parameters(), "lr": lr}]
+
+
+class Renderer(nn.Module):
+    """State + control flow of NeRFRenderer with cuda_ray=True (nerf/renderer.py:65-124, :338-500, :566-660)."""
+
+    def __init__(self, field, bound=2.0, min_near=0.2, density_thresh=10.0, density_scale=1.0):
+        super().__init__()
+        self.field = field
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.grid_size = 128
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.density_scale = density_scale
+        aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+        self.register_buffer("aabb_train", aabb)
+        self.register_buffer("aabb_infer", aabb.clone())
+        self.register_buffer("density_grid", torch.zeros(self.cascade, self.grid_size ** 3))
+        self.register_buffer("density_bitfield", torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+        self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+        self.mean_density = 0.0
+        self.iter_density = 0
+        self.mean_count = 0
+        self.local_step = 0
+
+    def set_occupancy(self, density_grid):
+        """Install an analytic density grid (the synthetic scene) and pack it, as update_extra_state :648-654 would."""
+        self.density_grid.copy_(density_grid)
+        self.mean_density = float(self.density_grid.clamp(min=0).mean().item())
+        thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
+
+    def update_mean_count(self):
+        """The step-counter half of update_extra_state (:656-660): one D2H read every 16 steps."""
+        total = min(16, self.local_step)
+        if total > 0:
+            self.mean_count = int(self.step_counter[:total, 0].sum().item() / total)
+        self.local_step = 0
+
+    def render_train(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=True, force_all_rays=False, max_steps=1024):
+        """Training branch of run_cuda (:361-425). Returns image [N,3], depth [N], and the sample count tensor."""
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                                nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
+                                                                max_steps)
+        sigmas, rgbs, _ = self.field(xyzs, dirs)
+        sigmas = self.density_scale * sigmas
+        weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return image, depth, counter
+
+    @torch.no_grad()
+    def render_infer(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024):
+        """Inference branch of run_cuda (:436-487), including its per-iteration alive-count read-back."""
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, dev = rays_o.shape[0], rays_o.device
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+        weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        n_alive = N
+        alive_counter = torch.zeros([1], dtype=torch.int32, device=dev)
+        rays_alive = torch.zeros(2, n_alive, dtype=torch.int32, device=dev)
+        rays_t = torch.zeros(2, n_alive, dtype=torch.float32, device=dev)
+        step = i = 0
+        n_samples = 0
+        while step < max_steps:
+            if step == 0:
+                torch.arange(n_alive, out=rays_alive[0])
+                rays_t[0] = nears
+            else:
+                alive_counter.zero_()
+                raymarching.compact_rays(n_alive, rays_alive[i % 2], rays_alive[(i + 1) % 2], rays_t[i % 2], rays_t[(i + 1) % 2], alive_counter)
+                n_alive = alive_counter.item()
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], rays_o, rays_d, self.bound,
+                                                        self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128, perturb, dt_gamma,
+                                                        max_steps)
+            sigmas, rgbs, _ = self.field(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            raymarching.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], sigmas, rgbs, deltas, weights_sum, depth, image)
+            n_samples += xyzs.shape[0]
+            step += n_step
+            i += 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return image, depth, n_samples

@@ -1,0 +1,88 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the ray sharding + the single flat-gradient all-reduce."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ngp_harness import dp
+
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(rank)  # different init per rank: broadcast must fix it
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
+    red = dp.FlatGradAllReduce(model.parameters())
+    red.broadcast_parameters()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
+
+    torch.manual_seed(123)
+    x_global = torch.randn(64, 8)
+    y_global = torch.randn(64, 3)
+    lo, hi = dp.shard(64, rank, world)
+    assert hi - lo == 32
+    for _ in range(3):
+        red.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x_global[lo:hi]), y_global[lo:hi])
+        loss.backward()
+        assert model[0].weight.grad.data_ptr() == red.flat.data_ptr(), ".grad must stay a view of the flat buffer"
+        red.all_reduce()
+        opt.step()
+    mc = dp.all_reduce_max_int(100 + rank, torch.device("cpu"))
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    q.put((rank, flat, mc))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process_reference():
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
+    torch.manual_seed(123)
+    x = torch.randn(64, 8)
+    y = torch.randn(64, 3)
+    for _ in range(3):
+        opt.zero_grad()
+        # mean over the global batch == average of the two equal-size shard means
+        torch.nn.functional.mse_loss(model(x), y).backward()
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_matches_single_process():
+    world = 2
+    port = 29600 + os.getpid() % 300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort(key=lambda t: t[0])
+    w0, w1 = results[0][1], results[1][1]
+    assert torch.equal(w0, w1), "replicas must stay bit-identical"
+    assert results[0][2] == results[1][2] == 101
+    ref = _single_process_reference()
+    assert torch.allclose(w0, ref, atol=1e-6), "2-rank DP == single-process training on the global batch"
+
+
+def test_shard_covers_batch():
+    sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
+    from ngp_harness import dp
+
+    for n, w in ((65536, 8), (4096, 2), (1000, 3)):
+        spans = [dp.shard(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))

@@ -136,8 +136,9 @@ def test_grid_input_backward_fp32_bit_exact(oracle, dev):
     want = oracle.grid_input_backward(grad, dyd, D)
     ge = torch.zeros(s["rows"], C, device=dev)
     gi = torch.zeros(B, D, device=dev)
-    check(lib.nerftex_grid_encode_backward(ptr(t(grad, dev)), ptr(t(s["x"], dev)), None, ptr(t(s["offsets"], dev)), ptr(ge), B, D, C, L,
-                                           s["S"], s["base"], 1, ptr(t(dyd, dev)), ptr(gi), s["gridtype"], int(s["align"]), F32, 0, stream()))
+    gt, xt, ot, dt_ = t(grad, dev), t(s["x"], dev), t(s["offsets"], dev), t(dyd, dev)  # keep alive across the launch
+    check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(xt), None, ptr(ot), ptr(ge), B, D, C, L,
+                                           s["S"], s["base"], 1, ptr(dt_), ptr(gi), s["gridtype"], int(s["align"]), F32, 0, stream()))
     torch.cuda.synchronize()
     assert np.array_equal(gi.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
@@ -324,8 +325,9 @@ def test_march_rays_train_bit_exact(oracle, dev, cfg, perturb):
 
     x2 = torch.zeros(m + 1, 3, device=dev); d2 = torch.zeros(m + 1, 3, device=dev); l2 = torch.zeros(m + 1, 2, device=dev)
     ts = torch.zeros(m + 1, 1, device=dev); r2 = torch.zeros(N, 3, dtype=torch.int32, device=dev)
-    check(lib.nerftex_march_rays_train_differentiable(ptr(t(o, dev)), ptr(t(d, dev)), ptr(t(bits, dev)), b, cfg["dt_gamma"], 1024, N,
-                                                      sc.cascade, 128, m + 1, ptr(t(wn, dev)), ptr(t(wf, dev)), ptr(x2), ptr(d2), ptr(l2),
+    ot, dt_, bt, nt, ft = t(o, dev), t(d, dev), t(bits, dev), t(wn, dev), t(wf, dev)  # keep alive across the launch
+    check(lib.nerftex_march_rays_train_differentiable(ptr(ot), ptr(dt_), ptr(bt), b, cfg["dt_gamma"], 1024, N,
+                                                      sc.cascade, 128, m + 1, ptr(nt), ptr(ft), ptr(x2), ptr(d2), ptr(l2),
                                                       ptr(ts), ptr(r2), ptr(counter), int(perturb), stream()))
     torch.cuda.synchronize()
     assert np.array_equal(ts.cpu().numpy()[:m].view(np.uint32), wts[:m].view(np.uint32))

@@ -149,4 +149,6 @@ def test_grid_offsets_match_reference(oracle, golden_dir):
         assert off.tolist() == c["offsets"], c["name"]
         assert total == c["rows"]
     fox = [c for c in cases if c["name"] == "fox_bound2"][0]
-    assert fox["rows"] == 6328848  # (res+1)^3 dense levels; SURVEY 8(d) quoted res^3 -- the reference class is authoritative
+    assert fox["rows"] == 6328848  # align_corners=False: (res+1)^3 dense levels
+    fox_a = [c for c in cases if c["name"] == "fox_bound2_align"][0]
+    assert fox_a["rows"] == 6299960  # what get_encoder() (align_corners=True) builds for the fox config

@@ -96,6 +96,9 @@ def module_goldens():
 
     cases = [
         dict(name="fox_bound2", kw=dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096)),
+        # tools/encoding.py:45 get_encoder defaults align_corners=True: what network_ff.py / network.py actually build
+        dict(name="fox_bound2_align", kw=dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096, align_corners=True)),
+        dict(name="bound1_align", kw=dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048, align_corners=True)),
         dict(name="bound1", kw=dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048)),
         dict(name="curved_L8", kw=dict(input_dim=3, num_levels=8, level_dim=2, base_resolution=512, log2_hashmap_size=19, desired_resolution=1024, align_corners=True)),
         dict(name="normal_L4", kw=dict(input_dim=3, num_levels=4, level_dim=2, base_resolution=16, log2_hashmap_size=19, per_level_scale=2 ** (1 / 3))),
