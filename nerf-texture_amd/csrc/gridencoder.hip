@@ -17,7 +17,8 @@
 //             level (<= 4 MiB) -- the property the reference buys with blockIdx.y.
 //  backward : (point, level) threads, level-major so one level's slice of the
 //             gradient table is the atomic working set; hardware float atomics
-//             (global_atomic_add_f32 / global_atomic_pk_add_f16), no CAS loops.
+//             (global_atomic_add_f32 / global_atomic_pk_add_f16), no CAS loops; runs of
+//             lanes in the same grid cell are pre-reduced in the wave (see the kernel).
 //
 // Arithmetic contract (see oracle/src/orc_gridencoder.c): uint32 index math is
 // bit-exact; interpolation weights are products in dimension order; accumulation
@@ -265,25 +266,32 @@ __device__ __forceinline__ void atomic_add_h2(half_t* addr, float a, float b) {
     unsafeAtomicAdd(reinterpret_cast<__half2*>(addr), v);
 }
 
-template <typename T, int D, int C, int N_C, bool BLC>
+// One thread per (point, level); level = blockIdx.y so one level's slice of the gradient table is the
+// atomic working set at a time.
+//
+// Wave64 run compression: samples arrive in ray order, so consecutive lanes of a wave sit in the SAME
+// grid cell on the coarse levels (a run of ~16 lanes at level 0, ~3 at level 4, 1 beyond level ~7).
+// Issued naively, a run of r lanes is r same-address atomics per corner, which the memory-side atomic
+// unit serialises.  Instead the lanes of a run (contiguous, found with one ballot over "same cell as the
+// lane below") add their w*grad contributions with a segmented suffix reduction over lane shuffles, and
+// only the run head issues the atomic: fewer, conflict-free atomics, and for fp16 one rounding per run
+// instead of one per sample.  The reduction is skipped (wave-uniform branch) when every run has length 1.
+template <typename T, int D, int C, bool BLC>
 __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                             const int* __restrict__ offsets, T* __restrict__ grad_grid,
                                                             const uint32_t B, const uint32_t L, const LevelConsts lc,
                                                             const uint32_t gridtype, const bool align_corners) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = t * N_C / C;
-    if (b >= B) return;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t level = blockIdx.y;
-    const uint32_t ch = t * N_C - b * C;
+    const int lane = threadIdx.x & (kWave - 1);
 
+    bool valid = b < B;
     float x[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
+        x[d] = valid ? inputs[(size_t)b * D + d] : 0.0f;
+        if (x[d] < 0 || x[d] > 1) valid = false;  // gridencoder.cu:248-253: out-of-range points add nothing
     }
-#pragma unroll
-    for (int d = 0; d < D; d++)
-        if (x[d] < 0 || x[d] > 1) return;  // gridencoder.cu:248-253
 
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
@@ -300,11 +308,18 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
         pos[d] -= (float)pos_grid[d];
     }
 
-    const T* gp = BLC ? grad + ((size_t)b * L + level) * C + ch : grad + ((size_t)level * B + b) * C + ch;
-    float gc[N_C];
+    float gc[C];
+    if (valid) {
+        const T* gp = BLC ? grad + ((size_t)b * L + level) * C : grad + ((size_t)level * B + b) * C;
+        load_row<T, C>(gp, gc);
+    } else {
 #pragma unroll
-    for (int c = 0; c < N_C; c++) gc[c] = (float)gp[c];
+        for (int c = 0; c < C; c++) gc[c] = 0.0f;
+    }
 
+    // per-corner contributions w * grad (fp32)
+    float v[1 << D][C];
+    uint32_t row[1 << D];
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float w = 1;
@@ -319,12 +334,49 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
                 p[d] = pos_grid[d] + 1;
             }
         }
-        T* dst = table + (size_t)index_of(p) * C + ch;
-        if constexpr (sizeof(T) == 2 && N_C == 2) {
-            atomic_add_h2(reinterpret_cast<half_t*>(dst), w * gc[0], w * gc[1]);  // :299-305
+        row[idx] = index_of(p);
+#pragma unroll
+        for (int c = 0; c < C; c++) v[idx][c] = w * gc[c];
+    }
+
+    bool head = true;
+    if constexpr (C <= 2) {
+        // same cell as the lane below?
+        bool same = valid && lane > 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) same = same && (__shfl_up(pos_grid[d], 1, kWave) == pos_grid[d]);
+        same = same && (__shfl_up((int)valid, 1, kWave) != 0);
+        head = !same;
+        const uint64_t heads = __ballot(head);
+        if (heads != ~0ull) {  // at least one run longer than 1 in this wave
+            const uint64_t above = lane == kWave - 1 ? 0ull : (heads & ~((2ull << lane) - 1ull));
+            const int run_end = above ? __builtin_ctzll(above) : kWave;  // exclusive end of this lane's run
+#pragma unroll
+            for (int step = 1; step < kWave; step <<= 1) {
+                const bool take = lane + step < run_end;
+                if (__ballot(take) == 0ull) break;
+#pragma unroll
+                for (int idx = 0; idx < (1 << D); idx++) {
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float o = __shfl_down(v[idx][c], step, kWave);
+                        if (take) v[idx][c] += o;
+                    }
+                }
+            }
+        }
+    }
+    if (!valid || !head) return;
+
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        T* dst = table + (size_t)row[idx] * C;
+        if constexpr (sizeof(T) == 2 && C % 2 == 0) {
+#pragma unroll
+            for (int c = 0; c < C; c += 2) atomic_add_h2(reinterpret_cast<half_t*>(dst) + c, v[idx][c], v[idx][c + 1]);  // :299-305
         } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
-            for (int c = 0; c < N_C; c++) atomic_add_f32(reinterpret_cast<float*>(dst) + c, w * gc[c]);
+            for (int c = 0; c < C; c++) atomic_add_f32(reinterpret_cast<float*>(dst) + c, v[idx][c]);
         } else {
             // fp16, C == 1: the reference's at::Half atomicAdd is an empty stub (gridencoder.cu:22-26),
             // i.e. it silently adds nothing.  Emulate a scalar half add with a 32-bit CAS instead.
@@ -335,7 +387,7 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
                 assumed = old;
                 unsigned short hs = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
                 half_t hv = __builtin_bit_cast(half_t, hs);
-                hv = (half_t)((float)hv + w * gc[0]);
+                hv = (half_t)((float)hv + v[idx][0]);
                 unsigned short ns = __builtin_bit_cast(unsigned short, hv);
                 unsigned int repl = hi ? ((assumed & 0xffffu) | ((unsigned int)ns << 16)) : ((assumed & 0xffff0000u) | ns);
                 old = atomicCAS(base, assumed, repl);
@@ -386,15 +438,14 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
                     const LevelConsts& lc, bool calc_grad, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool align,
                     int layout, hipStream_t st) {
     if (B == 0) return NERFTEX_OK;
-    constexpr int N_C = C < 2 ? C : 2;
-    const dim3 grid(div_up(B * (uint32_t)C / (uint32_t)N_C, 256u), L), block(256);
+    const dim3 grid(div_up(B, 256u), L), block(256);
     const bool blc = layout == NERFTEX_LAYOUT_BLC;
     if (blc)
-        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, N_C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L,
-                           lc, gridtype, align);
+        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
+                           gridtype, align);
     else
-        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, N_C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B,
-                           L, lc, gridtype, align);
+        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
+                           gridtype, align);
     int rc = check_launch("grid_encode_backward");
     if (rc != NERFTEX_OK) return rc;
     if (calc_grad) {
