@@ -1,0 +1,641 @@
+// Fully-fused tiny MLP on the gfx950 matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulation).
+//
+// Replaces the reference's ffmlp/src/ffmlp.cu (kernel_mlp_fused :331-407, kernel_mlp_fused_backward
+// :410-518, ffmlp_backward :749-895 with its CUTLASS split-K weight-gradient GEMMs on side streams)
+// behind include/nerftex_hip.h.  Same data contract (fp16 tensors, flat [out,in] row-major weights,
+// forward_buffer / backward_buffer [num_layers, B, hidden]), different machine mapping:
+//
+//  * Orientation.  A wave computes H^T = W . X^T, i.e. the WEIGHTS are the MFMA A operand and a 16-row
+//    batch tile is the B operand.  The 16x16 result tile then has the batch index on the lane axis --
+//    which is exactly where the next layer's B operand wants it.  With a fixed permutation of the
+//    contraction index (two result tiles interleave into one 32-deep operand: slot j<4 <- tile 2s,
+//    j>=4 <- tile 2s+1), activations go register -> register through the whole network; the weight
+//    fragments are staged ONCE per workgroup into LDS already in that permuted, lane-ordered form
+//    (one conflict-free ds_read_b128 per fragment).  No activation ever touches LDS; the reference
+//    round-trips every layer through padded shared memory because warp-32 WMMA cannot do this.
+//  * Weight gradients  dW[o,i] = sum_n dPre[n,o] In[n,i]  contract over the BATCH, so both operands
+//    need the batch index in registers.  They are read from global in the natural row-major form and
+//    transposed by the matrix core itself (one MFMA against a 0/1 selection matrix per 16x16 tile,
+//    exact in fp32) instead of through shared memory.  Partial sums stay in fp32 registers, are
+//    combined per workgroup in LDS, written once per workgroup and reduced by a tiny second kernel:
+//    one stream, no split-K side streams / events (ffmlp.cu:711-740), fp32 instead of fp16 accumulation.
+//
+// Supported: hidden_dim in {16,32,64,128,256}, input_dim % 16 == 0, output_dim == 16 (padded),
+// num_layers >= 2, B % 128 == 0, every activation of ffmlp.py:89-96.  The weights of all layers must
+// fit the 160 KB LDS of a CU (true for every width <= 128 and for 256 with num_layers == 2).
+#include "common.hpp"
+#include "workspace.hpp"
+
+namespace nerftex {
+namespace {
+
+constexpr int kBlockThreads = 256;  // 4 waves, one per SIMD
+constexpr int kTilesPerWave = 2;    // 2 x 16 batch rows per wave iteration (two independent MFMA chains)
+constexpr int kRowsPerBlock = 4 * 16 * kTilesPerWave;  // 128, the reference's batch granule too
+constexpr float kAct = 10.0f;       // K_ACT of utils.h:41
+
+enum Act : uint32_t { kRelu = 0, kExp = 1, kSine = 2, kSigmoid = 3, kSquareplus = 4, kSoftplus = 5, kNone = 6 };
+
+__device__ __forceinline__ float act_forward(uint32_t a, float x) {
+    switch (a) {
+        case kRelu: return x > 0.0f ? x : 0.0f;
+        case kExp: return expf(x);
+        case kSine: return sinf(x);
+        case kSigmoid: return 1.0f / (1.0f + expf(-x));
+        case kSquareplus: { const float s = x * kAct; return 0.5f * (s + sqrtf(s * s + 4.0f)) / kAct; }
+        case kSoftplus: return logf(expf(x * kAct) + 1.0f) / kAct;
+        default: return x;
+    }
+}
+// gradient through the activation, expressed with the stored POST-activation value y (utils.h:537-582)
+__device__ __forceinline__ float act_backward(uint32_t a, float g, float y) {
+    switch (a) {
+        case kRelu: return y > 0.0f ? g : 0.0f;
+        case kExp: return g * y;
+        case kSigmoid: return g * (float)(half_t)(y * (1.0f - y));
+        case kSquareplus: { const float s = y * kAct; return g * (float)(half_t)(s * s / (s * s + 1.0f)); }
+        case kSoftplus: return g * (float)(half_t)(1.0f - expf(-y * kAct));
+        default: return g;  // none, and sine (the reference leaves the gradient untouched, utils.h:552-556)
+    }
+}
+
+__device__ __forceinline__ float4_t mfma16(const half8_t& a, const half8_t& b, const float4_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// contraction-index map of a 32-deep operand slot (lane group g = lane>>4, element j<8)
+//   natural : operand comes from row-major memory, 8 consecutive k per lane
+//   permuted: operand is rebuilt from two 16x16 result tiles held in registers (see file header)
+__device__ __forceinline__ int kmap(bool permuted, int ks, int g, int j) {
+    return permuted ? 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3) : 32 * ks + 8 * g + j;
+}
+
+// Stage the A-operand fragments of a matrix view A[m][k] (M x K, M % 16 == 0) into LDS.
+//   element (m,k) = transposed ? W[k*ldw + m] : W[m*ldw + k];  k >= K pads with zero.
+// Layout: fragment (mt, ks) at ((mt*KS + ks)*64 + lane) * 16 bytes -> one ds_read_b128 per lane, no conflicts.
+__device__ void stage_fragments(half8_t* __restrict__ dst, const half_t* __restrict__ W, int ldw, bool transposed, int M, int K,
+                                bool permuted) {
+    const int KS = (K + 31) / 32;
+    const int total = (M / 16) * KS * 64;
+    for (int s = threadIdx.x; s < total; s += kBlockThreads) {
+        const int frag = s >> 6, lane = s & 63;
+        const int mt = frag / KS, ks = frag - mt * KS;
+        const int m = 16 * mt + (lane & 15), g = lane >> 4;
+        half8_t v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = kmap(permuted, ks, g, j);
+            v[j] = k < K ? (transposed ? W[(size_t)k * ldw + m] : W[(size_t)m * ldw + k]) : (half_t)0.0f;
+        }
+        dst[s] = v;
+    }
+}
+
+__host__ __device__ constexpr int frag_count(int M, int K) { return (M / 16) * ((K + 31) / 32); }
+
+// two fp32 result tiles (rows 4g+j of tiles 2s, 2s+1) -> the permuted 32-deep B operand of the next layer
+__device__ __forceinline__ half8_t pack_operand(const float4_t& lo, const float4_t& hi) {
+    half8_t b;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        b[j] = (half_t)lo[j];
+        b[4 + j] = (half_t)hi[j];
+    }
+    return b;
+}
+
+__device__ __forceinline__ void store4(half_t* p, const float4_t& v) {
+    half4_t h;
+#pragma unroll
+    for (int j = 0; j < 4; j++) h[j] = (half_t)v[j];
+    *reinterpret_cast<half4_t*>(p) = h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / inference
+// ------------------------------------------------------------------------------------------------
+template <int HIDDEN, bool INFERENCE>
+__global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half_t* __restrict__ X, const half_t* __restrict__ W,
+                                                                      half_t* __restrict__ fwd, half_t* __restrict__ out, uint32_t B,
+                                                                      uint32_t IN, uint32_t NL, uint32_t act, uint32_t out_act) {
+    constexpr int OT = HIDDEN / 16;         // result tiles per hidden layer
+    constexpr int KSH = (HIDDEN + 31) / 32;  // 32-deep steps over a hidden layer
+    constexpr int NT = kTilesPerWave;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8_t* frags = reinterpret_cast<half8_t*>(smem);
+
+    const int KS0 = (IN + 31) / 32;
+    const int base_hidden = OT * KS0;             // first fragment of matrix 1
+    const int per_hidden = OT * KSH;
+    const int base_out = base_hidden + (NL - 1) * per_hidden;
+    stage_fragments(frags, W, IN, false, HIDDEN, IN, false);
+    for (uint32_t l = 1; l < NL; l++)
+        stage_fragments(frags + (size_t)(base_hidden + (l - 1) * per_hidden) * 64, W + (size_t)HIDDEN * IN + (size_t)(l - 1) * HIDDEN * HIDDEN,
+                        HIDDEN, false, HIDDEN, HIDDEN, true);
+    stage_fragments(frags + (size_t)base_out * 64, W + (size_t)HIDDEN * IN + (size_t)(NL - 1) * HIDDEN * HIDDEN, HIDDEN, false, 16, HIDDEN,
+                    true);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const size_t layer_stride = (size_t)B * HIDDEN;
+
+    for (uint32_t row0 = blockIdx.x * kRowsPerBlock + wave * 16 * NT; row0 < B; row0 += gridDim.x * kRowsPerBlock) {
+        float4_t acc[NT][OT];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) acc[t][ot] = float4_t{0, 0, 0, 0};
+
+        // ---- layer 0: B operand straight from the row-major input (16 B per lane, 1 KiB per wave load)
+        for (int ks = 0; ks < KS0; ks++) {
+            half8_t b[NT];
+            const uint32_t k0 = 32 * ks + 8 * g;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (k0 < IN) b[t] = *reinterpret_cast<const half8_t*>(X + (size_t)(row0 + 16 * t + r) * IN + k0);
+                else b[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) {
+                const half8_t a = frags[(size_t)(ot * KS0 + ks) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t][ot] = mfma16(a, b[t], acc[t][ot]);
+            }
+        }
+
+        half8_t bop[NT][KSH];
+        for (uint32_t l = 0;; l++) {
+            // activation, optional write-out of the post-activation values, repack as next B operand
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[t][ot][j] = act_forward(act, acc[t][ot][j]);
+                    if constexpr (!INFERENCE)
+                        store4(fwd + l * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g, acc[t][ot]);
+                }
+#pragma unroll
+                for (int s = 0; s < KSH; s++) {
+                    const float4_t zero{0, 0, 0, 0};
+                    bop[t][s] = pack_operand(acc[t][2 * s], (2 * s + 1 < OT) ? acc[t][(2 * s + 1 < OT) ? 2 * s + 1 : 0] : zero);
+                }
+            }
+            if (l + 1 >= NL) break;
+            // ---- hidden matrix l+1
+            const half8_t* fl = frags + (size_t)(base_hidden + l * per_hidden) * 64;
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) {
+                float4_t c[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) c[t] = float4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSH; ks++) {
+                    const half8_t a = fl[(size_t)(ot * KSH + ks) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t][ot] = c[t];
+            }
+        }
+
+        // ---- output layer: 16 (padded) outputs = one result tile
+        {
+            const half8_t* fo = frags + (size_t)base_out * 64;
+            float4_t c[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) c[t] = float4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSH; ks++) {
+                const half8_t a = fo[(size_t)ks * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) c[t][j] = act_forward(out_act, c[t][j]);
+                store4(out + (size_t)(row0 + 16 * t + r) * 16 + 4 * g, c[t]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: activation gradients (dL/d pre-activation of every hidden layer) + dL/d input
+//   bb[j] holds the gradient at hidden activation NL-1-j (the reference's backward_buffer order)
+// ------------------------------------------------------------------------------------------------
+template <int HIDDEN>
+__global__ __launch_bounds__(kBlockThreads) void ffmlp_dgrad_kernel(const half_t* __restrict__ grad, const half_t* __restrict__ W,
+                                                                    const half_t* __restrict__ fwd, half_t* __restrict__ bb,
+                                                                    half_t* __restrict__ grad_inputs, uint32_t B, uint32_t IN, uint32_t NL,
+                                                                    uint32_t act) {
+    constexpr int OT = HIDDEN / 16;
+    constexpr int KSH = (HIDDEN + 31) / 32;
+    constexpr int NT = kTilesPerWave;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8_t* frags = reinterpret_cast<half8_t*>(smem);
+
+    const half_t* W_hidden = W + (size_t)HIDDEN * IN;
+    const half_t* W_out = W_hidden + (size_t)(NL - 1) * HIDDEN * HIDDEN;
+    // fragment table: [W_out^T (HIDDEN x 16)] [W_l^T for l = NL-1 .. 1] [W_0^T (IN x HIDDEN), optional]
+    const int per_hidden = OT * KSH;
+    const int base_hidden = OT;  // W_out^T has K = 16 -> one 32-deep step per tile
+    const int base_in = base_hidden + (NL - 1) * per_hidden;
+    stage_fragments(frags, W_out, HIDDEN, true, HIDDEN, 16, false);
+    for (uint32_t j = 1; j < NL; j++)
+        stage_fragments(frags + (size_t)(base_hidden + (j - 1) * per_hidden) * 64, W_hidden + (size_t)(NL - 1 - j) * HIDDEN * HIDDEN, HIDDEN, true,
+                        HIDDEN, HIDDEN, true);
+    if (grad_inputs) stage_fragments(frags + (size_t)base_in * 64, W, IN, true, IN, HIDDEN, true);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const size_t layer_stride = (size_t)B * HIDDEN;
+
+    for (uint32_t row0 = blockIdx.x * kRowsPerBlock + wave * 16 * NT; row0 < B; row0 += gridDim.x * kRowsPerBlock) {
+        // B operand of the first product: grad^T (16 outputs = lane groups 0,1; groups 2,3 are zero padding)
+        half8_t bg[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (g < 2) bg[t] = *reinterpret_cast<const half8_t*>(grad + (size_t)(row0 + 16 * t + r) * 16 + 8 * g);
+            else bg[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        float4_t acc[NT][OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) {
+            const half8_t a = frags[(size_t)ot * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t][ot] = mfma16(a, bg[t], float4_t{0, 0, 0, 0});
+        }
+
+        half8_t bop[NT][KSH];
+        for (uint32_t j = 0;; j++) {
+            const half_t* f = fwd + (size_t)(NL - 1 - j) * layer_stride;  // post-activations of the layer being crossed
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) {
+                    const size_t off = (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g;
+                    const half4_t y = *reinterpret_cast<const half4_t*>(f + off);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[t][ot][q] = act_backward(act, (float)(half_t)acc[t][ot][q], (float)y[q]);
+                    store4(bb + j * layer_stride + off, acc[t][ot]);
+                }
+#pragma unroll
+                for (int s = 0; s < KSH; s++) {
+                    const float4_t zero{0, 0, 0, 0};
+                    bop[t][s] = pack_operand(acc[t][2 * s], (2 * s + 1 < OT) ? acc[t][(2 * s + 1 < OT) ? 2 * s + 1 : 0] : zero);
+                }
+            }
+            if (j + 1 >= NL) break;
+            const half8_t* fl = frags + (size_t)(base_hidden + j * per_hidden) * 64;  // W_{NL-1-j}^T
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) {
+                float4_t c[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) c[t] = float4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSH; ks++) {
+                    const half8_t a = fl[(size_t)(ot * KSH + ks) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t][ot] = c[t];
+            }
+        }
+
+        if (grad_inputs) {  // dL/dX = W_0^T . dPre_0, no activation (ffmlp.cu:880-887)
+            const half8_t* fi = frags + (size_t)base_in * 64;
+            for (uint32_t it = 0; it < IN / 16; it++) {
+                float4_t c[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) c[t] = float4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSH; ks++) {
+                    const half8_t a = fi[(size_t)(it * KSH + ks) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) store4(grad_inputs + (size_t)(row0 + 16 * t + r) * IN + 16 * it + 4 * g, c[t]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 2: weight gradients  dW[o,i] = sum_n dPre[n,o] * In[n,i]   (contraction over the batch)
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxLayers = 12;
+struct WgradLayer {
+    const half_t* dpre;  // [B, ld_d] rows, O valid columns
+    const half_t* in;    // [B, ld_i] rows, K valid columns
+    uint32_t ld_d, ld_i, O, K;
+    uint32_t w_off;      // offset of this matrix in the flat weight vector
+};
+struct WgradArgs {
+    WgradLayer layer[kMaxLayers];
+};
+
+// 16 batch rows x 32 features, natural A-operand form (lane r = batch row, 8 consecutive features)
+__device__ __forceinline__ half8_t load_rows(const half_t* p, uint32_t ld, uint32_t row, uint32_t col0, uint32_t ncols, int g) {
+    const uint32_t c = col0 + 8 * g;
+    if (c < ncols) return *reinterpret_cast<const half8_t*>(p + (size_t)row * ld + c);
+    return half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+__global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_kernel(const WgradArgs args, uint32_t B, float* __restrict__ partials,
+                                                                    uint32_t n_params) {
+    constexpr int G = 4;  // tiles per group in each direction -> 16 accumulator tiles (64 VGPRs)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][G*G tiles][256] fp32, per-workgroup combine
+
+    const WgradLayer L = args.layer[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const uint32_t OT = L.O / 16, IT = L.K / 16;
+
+    // selection matrices: B operand with B[k][col] = (k == col) / (k == 16 + col); A x Sel = transpose into "batch in registers"
+    half8_t sel0, sel1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        sel0[j] = (8 * g + j == r) ? (half_t)1.0f : (half_t)0.0f;
+        sel1[j] = (8 * g + j == 16 + r) ? (half_t)1.0f : (half_t)0.0f;
+    }
+    const float4_t zero{0, 0, 0, 0};
+    float* out = partials + (size_t)blockIdx.x * n_params + L.w_off;
+
+    for (uint32_t og = 0; og < OT; og += G) {
+        for (uint32_t ig = 0; ig < IT; ig += G) {
+            float4_t acc[G][G];
+#pragma unroll
+            for (int a = 0; a < G; a++)
+#pragma unroll
+                for (int b = 0; b < G; b++) acc[a][b] = zero;
+
+            // each wave walks 32-row steps of the batch
+            for (uint32_t row0 = (blockIdx.x * 4 + wave) * 32; row0 < B; row0 += gridDim.x * 4 * 32) {
+                half8_t A[G], Bm[G];
+                // transposed dPre tiles -> A operands (lane = output neuron, slots = 2 x 4 batch rows)
+#pragma unroll
+                for (int a = 0; a < G; a += 2) {
+                    const uint32_t col0 = 16 * (og + a);  // 32 features feed tiles a, a+1
+                    const half8_t x0 = load_rows(L.dpre, L.ld_d, row0 + r, col0, L.O, g);
+                    const half8_t x1 = load_rows(L.dpre, L.ld_d, row0 + 16 + r, col0, L.O, g);
+                    A[a] = pack_operand(mfma16(x0, sel0, zero), mfma16(x1, sel0, zero));
+                    A[a + 1] = pack_operand(mfma16(x0, sel1, zero), mfma16(x1, sel1, zero));
+                }
+#pragma unroll
+                for (int b = 0; b < G; b += 2) {
+                    const uint32_t col0 = 16 * (ig + b);
+                    const half8_t x0 = load_rows(L.in, L.ld_i, row0 + r, col0, L.K, g);
+                    const half8_t x1 = load_rows(L.in, L.ld_i, row0 + 16 + r, col0, L.K, g);
+                    Bm[b] = pack_operand(mfma16(x0, sel0, zero), mfma16(x1, sel0, zero));
+                    Bm[b + 1] = pack_operand(mfma16(x0, sel1, zero), mfma16(x1, sel1, zero));
+                }
+#pragma unroll
+                for (int a = 0; a < G; a++)
+#pragma unroll
+                    for (int b = 0; b < G; b++) acc[a][b] = mfma16(A[a], Bm[b], acc[a][b]);
+            }
+
+            // combine the 4 waves in LDS, then one fp32 write per element per workgroup
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < G; a++)
+#pragma unroll
+                for (int b = 0; b < G; b++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) red[((wave * G * G + a * G + b) * 4 + j) * 64 + lane] = acc[a][b][j];
+            __syncthreads();
+            for (int e = threadIdx.x; e < G * G * 256; e += kBlockThreads) {
+                const int tile = e >> 8, j = (e >> 6) & 3, ln = e & 63;
+                const int a = tile / G, b = tile % G;
+                const uint32_t o = 16 * (og + a) + 4 * (ln >> 4) + j, i = 16 * (ig + b) + (ln & 15);
+                if (o < L.O && i < L.K) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) s += red[((w * G * G + tile) * 4 + j) * 64 + ln];
+                    out[(size_t)o * L.K + i] = s;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_parts,
+                                                                           uint32_t n_params, half_t* __restrict__ grad_weights) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_params) return;
+    float s = 0.0f;
+    for (uint32_t k = 0; k < n_parts; k++) s += partials[(size_t)k * n_params + p];
+    grad_weights[p] = (half_t)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int g_num_cus = 0;
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+int validate(uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+             uint32_t output_activation) {
+    if (hidden_dim != 16 && hidden_dim != 32 && hidden_dim != 64 && hidden_dim != 128 && hidden_dim != 256) {
+        set_error("hidden_dim should in [16, 32, 64, 128, 256]");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (input_dim == 0 || input_dim % 16 != 0) {
+        set_error("FFMLP input_dim should be 16 * m (m  > 0), but got %u", input_dim);
+        return NERFTEX_ERR_INVALID;
+    }
+    if (output_dim != 16) {
+        set_error("FFMLP current only supports output dim <= 16 (padded to 16), but got %u", output_dim);
+        return NERFTEX_ERR_INVALID;
+    }
+    if (num_layers < 2 || num_layers + 1 > (uint32_t)kMaxLayers) {
+        set_error("FFMLP num_layers should be in [2, %d], but got %u", kMaxLayers - 1, num_layers);
+        return NERFTEX_ERR_INVALID;
+    }
+    if (B % kRowsPerBlock != 0) {
+        set_error("ffmlp batch size must be 128 * m (m > 0), but got %u.", B);
+        return NERFTEX_ERR_INVALID;
+    }
+    if (activation > kNone || output_activation > kNone) {
+        set_error("FFMLP: unknown activation id");
+        return NERFTEX_ERR_INVALID;
+    }
+    return NERFTEX_OK;
+}
+
+size_t lds_bytes_forward(uint32_t H, uint32_t IN, uint32_t NL) {
+    return (size_t)(frag_count(H, IN) + (NL - 1) * frag_count(H, H) + frag_count(16, H)) * 1024;
+}
+size_t lds_bytes_dgrad(uint32_t H, uint32_t IN, uint32_t NL, bool with_inputs) {
+    return (size_t)(frag_count(H, 16) + (NL - 1) * frag_count(H, H) + (with_inputs ? frag_count(IN, H) : 0)) * 1024;
+}
+constexpr size_t kLdsLimit = 160 * 1024;
+
+int lds_check(size_t bytes) {
+    if (bytes > kLdsLimit) {
+        set_error("FFMLP: the weights of this network (%zu KB as MFMA fragments) exceed the 160 KB LDS of a gfx950 CU", bytes / 1024);
+        return NERFTEX_ERR_INVALID;
+    }
+    return NERFTEX_OK;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "hipFuncSetAttribute");
+    return NERFTEX_OK;
+}
+
+uint32_t persistent_grid(uint32_t B, size_t lds) {
+    const uint32_t blocks_needed = B / kRowsPerBlock;
+    uint32_t per_cu = lds > 0 ? (uint32_t)(kLdsLimit / lds) : 8;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const uint32_t cap = (uint32_t)num_cus() * per_cu;
+    return blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap;
+}
+
+template <int H, bool INF>
+int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t IN, uint32_t NL, uint32_t act, uint32_t out_act,
+                   void* fwd, void* outputs, hipStream_t st) {
+    const size_t lds = lds_bytes_forward(H, IN, NL);
+    int rc = lds_check(lds);
+    if (rc != NERFTEX_OK) return rc;
+    auto kernel = ffmlp_forward_kernel<H, INF>;
+    rc = set_lds(kernel, lds);
+    if (rc != NERFTEX_OK) return rc;
+    hipLaunchKernelGGL(kernel, dim3(persistent_grid(B, lds)), dim3(kBlockThreads), lds, st, (const half_t*)inputs, (const half_t*)weights,
+                       (half_t*)fwd, (half_t*)outputs, B, IN, NL, act, out_act);
+    return check_launch(INF ? "ffmlp_inference" : "ffmlp_forward");
+}
+
+template <bool INF>
+int dispatch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t IN, uint32_t H, uint32_t NL, uint32_t act,
+                     uint32_t out_act, void* fwd, void* outputs, hipStream_t st) {
+    switch (H) {
+        case 16: return launch_forward<16, INF>(inputs, weights, B, IN, NL, act, out_act, fwd, outputs, st);
+        case 32: return launch_forward<32, INF>(inputs, weights, B, IN, NL, act, out_act, fwd, outputs, st);
+        case 64: return launch_forward<64, INF>(inputs, weights, B, IN, NL, act, out_act, fwd, outputs, st);
+        case 128: return launch_forward<128, INF>(inputs, weights, B, IN, NL, act, out_act, fwd, outputs, st);
+        default: return launch_forward<256, INF>(inputs, weights, B, IN, NL, act, out_act, fwd, outputs, st);
+    }
+}
+
+template <int H>
+int launch_dgrad(const void* grad, const void* weights, const void* fwd, void* bb, void* grad_inputs, uint32_t B, uint32_t IN, uint32_t NL,
+                 uint32_t act, hipStream_t st) {
+    const size_t lds = lds_bytes_dgrad(H, IN, NL, grad_inputs != nullptr);
+    int rc = lds_check(lds);
+    if (rc != NERFTEX_OK) return rc;
+    auto kernel = ffmlp_dgrad_kernel<H>;
+    rc = set_lds(kernel, lds);
+    if (rc != NERFTEX_OK) return rc;
+    hipLaunchKernelGGL(kernel, dim3(persistent_grid(B, lds)), dim3(kBlockThreads), lds, st, (const half_t*)grad, (const half_t*)weights,
+                       (const half_t*)fwd, (half_t*)bb, (half_t*)grad_inputs, B, IN, NL, act);
+    return check_launch("ffmlp_backward(dgrad)");
+}
+
+}  // namespace
+}  // namespace nerftex
+
+using namespace nerftex;
+
+extern "C" int nerftex_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                     uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                     void* forward_buffer, void* outputs, void* stream) {
+    clear_error();
+    int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+    if (rc != NERFTEX_OK || B == 0) return rc;
+    if (!forward_buffer) {
+        set_error("ffmlp_forward: forward_buffer must not be NULL (use ffmlp_inference)");
+        return NERFTEX_ERR_INVALID;
+    }
+    return dispatch_forward<false>(inputs, weights, B, input_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs,
+                                   as_stream(stream));
+}
+
+extern "C" int nerftex_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                       uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                       void* inference_buffer, void* outputs, void* stream) {
+    (void)inference_buffer;  // the reference needs a [B, hidden] scratch; activations stay in registers here
+    clear_error();
+    int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+    if (rc != NERFTEX_OK || B == 0) return rc;
+    return dispatch_forward<true>(inputs, weights, B, input_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs,
+                                  as_stream(stream));
+}
+
+extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                                      uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                                      uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
+                                      void* grad_weights, void* stream) {
+    clear_error();
+    int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+    if (rc != NERFTEX_OK || B == 0) return rc;
+    if (!backward_buffer || !forward_buffer) {
+        set_error("ffmlp_backward: forward_buffer and backward_buffer must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    hipStream_t st = as_stream(stream);
+    const uint32_t H = hidden_dim, IN = input_dim, NL = num_layers;
+    void* gi = calc_grad_inputs ? grad_inputs : nullptr;
+
+    switch (H) {
+        case 16: rc = launch_dgrad<16>(grad, weights, forward_buffer, backward_buffer, gi, B, IN, NL, activation, st); break;
+        case 32: rc = launch_dgrad<32>(grad, weights, forward_buffer, backward_buffer, gi, B, IN, NL, activation, st); break;
+        case 64: rc = launch_dgrad<64>(grad, weights, forward_buffer, backward_buffer, gi, B, IN, NL, activation, st); break;
+        case 128: rc = launch_dgrad<128>(grad, weights, forward_buffer, backward_buffer, gi, B, IN, NL, activation, st); break;
+        default: rc = launch_dgrad<256>(grad, weights, forward_buffer, backward_buffer, gi, B, IN, NL, activation, st); break;
+    }
+    if (rc != NERFTEX_OK) return rc;
+
+    // weight gradients: one launch over (batch chunks, matrices), then the cross-workgroup reduction
+    const uint32_t n_params = H * (IN + H * (NL - 1) + 16);
+    const size_t LS = (size_t)B * H;
+    const half_t* fb = static_cast<const half_t*>(forward_buffer);
+    const half_t* bb = static_cast<const half_t*>(backward_buffer);
+    WgradArgs args{};
+    // matrix 0: dPre = bb[NL-1], In = X
+    args.layer[0] = WgradLayer{bb + (size_t)(NL - 1) * LS, static_cast<const half_t*>(inputs), H, IN, H, IN, 0};
+    for (uint32_t l = 1; l < NL; l++)  // hidden matrix l: dPre = bb[NL-1-l], In = fwd[l-1]
+        args.layer[l] = WgradLayer{bb + (size_t)(NL - 1 - l) * LS, fb + (size_t)(l - 1) * LS, H, H, H, H, H * IN + (l - 1) * H * H};
+    args.layer[NL] = WgradLayer{static_cast<const half_t*>(grad), fb + (size_t)(NL - 1) * LS, 16, H, 16, H, H * IN + (NL - 1) * H * H};
+
+    uint32_t n_parts = B / 128;  // every wave gets at least one 32-row step
+    const uint32_t cap = (uint32_t)num_cus() / 2;
+    if (n_parts > cap) n_parts = cap;
+    if (n_parts == 0) n_parts = 1;
+    float* partials = static_cast<float*>(workspace(kWsMlp, sizeof(float) * (size_t)n_parts * n_params));
+    if (!partials) return NERFTEX_ERR_HIP;
+    const size_t red_bytes = sizeof(float) * 4 * 16 * 256;  // 64 KiB
+    hipLaunchKernelGGL(ffmlp_wgrad_kernel, dim3(n_parts, NL + 1), dim3(kBlockThreads), red_bytes, st, args, B, partials, n_params);
+    rc = check_launch("ffmlp_backward(wgrad)");
+    if (rc != NERFTEX_OK) return rc;
+    hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, (uint32_t)kBlockThreads)), dim3(kBlockThreads), 0, st, partials, n_parts,
+                       n_params, static_cast<half_t*>(grad_weights));
+    return check_launch("ffmlp_backward(reduce)");
+}
+
+// ffmlp.cu:711-740 creates num_layers+1 side streams + events for the split-K GEMMs.  Nothing to create here:
+// the weight-gradient partials live in the library workspace, sized on demand.
+extern "C" int nerftex_ffmlp_allocate_splitk(size_t size) {
+    (void)size;
+    clear_error();
+    return NERFTEX_OK;
+}
+
+extern "C" int nerftex_ffmlp_free_splitk(void) {
+    clear_error();
+    return NERFTEX_OK;
+}

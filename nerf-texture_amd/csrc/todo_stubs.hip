@@ -4,11 +4,6 @@
 using namespace nerftex;
 #define NOT_YET(name) do { set_error(name ": not implemented yet"); return NERFTEX_ERR_INVALID; } while (0)
 extern "C" {
-int nerftex_ffmlp_forward(const void*, const void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void*, void*, void*) { NOT_YET("ffmlp_forward"); }
-int nerftex_ffmlp_inference(const void*, const void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void*, void*, void*) { NOT_YET("ffmlp_inference"); }
-int nerftex_ffmlp_backward(const void*, const void*, const void*, const void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, void*, void*, void*, void*) { NOT_YET("ffmlp_backward"); }
-int nerftex_ffmlp_allocate_splitk(size_t) { return NERFTEX_OK; }
-int nerftex_ffmlp_free_splitk(void) { return NERFTEX_OK; }
 int nerftex_create_raytracer(const float*, uint32_t, const uint32_t*, uint32_t, nerftex_raytracer**) { NOT_YET("create_raytracer"); }
 int nerftex_destroy_raytracer(nerftex_raytracer*) { return NERFTEX_OK; }
 int nerftex_raytracer_trace(const nerftex_raytracer*, const float*, const float*, float*, float*, float*, int64_t*, uint32_t, void*) { NOT_YET("raytracer_trace"); }
