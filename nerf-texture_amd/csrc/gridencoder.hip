@@ -25,6 +25,7 @@
 // is fmaf(w, g, acc) over corners 0..2^D-1 in fp32.  For fp16 tables the sum is
 // kept in fp32 and rounded once (the reference rounds to half after every corner).
 #include "common.hpp"
+#include "workspace.hpp"
 
 #include <cmath>
 
@@ -34,6 +35,7 @@ namespace nerftex {
 namespace {
 
 constexpr int kMaxLevels = 32;
+constexpr uint32_t kXcds = 8;  // accelerator complex dies of an MI355X, each with a private 4 MiB L2
 
 struct LevelConsts {
     float scale[kMaxLevels];
@@ -266,8 +268,7 @@ __device__ __forceinline__ void atomic_add_h2(half_t* addr, float a, float b) {
     unsafeAtomicAdd(reinterpret_cast<__half2*>(addr), v);
 }
 
-// One thread per (point, level); level = blockIdx.y so one level's slice of the gradient table is the
-// atomic working set at a time.
+// One thread per (point, level).
 //
 // Wave64 run compression: samples arrive in ray order, so consecutive lanes of a wave sit in the SAME
 // grid cell on the coarse levels (a run of ~16 lanes at level 0, ~3 at level 4, 1 beyond level ~7).
@@ -280,9 +281,19 @@ template <typename T, int D, int C, bool BLC>
 __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                             const int* __restrict__ offsets, T* __restrict__ grad_grid,
                                                             const uint32_t B, const uint32_t L, const LevelConsts lc,
-                                                            const uint32_t gridtype, const bool align_corners) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t level = blockIdx.y;
+                                                            const uint32_t gridtype, const bool align_corners,
+                                                            const uint32_t nchunks) {
+    // XCD-aware level schedule.  The 8 XCDs of an MI355X have private L2s; a float atomic executes in the L2
+    // that owns the line, and a line touched from two XCDs ping-pongs across the fabric.  Workgroups are
+    // dispatched round-robin over the XCDs (workgroup id % 8, observed, a speed assumption only -- the atomics
+    // are device-scope and stay correct under any placement), so workgroup id % 8 picks the level: XCD x owns
+    // levels x, x+8, ... and walks them one after the other, keeping that level's slice of the gradient table
+    // (<= 2-4 MiB) resident in its own L2 for the whole pass.
+    const uint32_t xcd = blockIdx.x % kXcds;
+    const uint32_t q = blockIdx.x / kXcds;
+    const uint32_t level = (q / nchunks) * kXcds + xcd;
+    if (level >= L) return;
+    const uint32_t b = (q % nchunks) * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
 
     bool valid = b < B;
@@ -396,6 +407,117 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, large batches: owner-computes accumulation in LDS (no global atomics)
+// ------------------------------------------------------------------------------------------------
+// Measured on MI355X (tools/probes/atomic_probe.hip): global float atomics top out at ~20 G lane-ops/s no
+// matter how small the footprint or which XCD issues them, ~10x below plain stores.  A training batch is
+// ~29 M corner contributions, i.e. >= 1.4 ms of atomics.  So for large batches the scatter is turned
+// around: the gradient table is cut into tiles of kTileFloats fp32 accumulators that fit the 160 KB LDS,
+// each workgroup OWNS tiles, scans every sample of the tile's level (sample + its level gradient are 16 B,
+// L2-resident after the first pass), adds the contributions that fall into its tile with LDS atomics
+// (ds_add_f32, ~3 orders of magnitude more throughput) and finally adds the tile to the table with plain
+// coalesced read-modify-writes.  Accumulation is fp32 (the reference rounds every single add to fp16).
+constexpr uint32_t kOwnerThreads = 1024;
+constexpr uint32_t kOwnerMinBatch = 16384;  // below this the per-sample atomics are cheaper than sweeping the whole table
+inline uint32_t owner_grid() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return (uint32_t)cus;  // one 1024-thread workgroup (128 KiB LDS) per CU, persistent over tiles
+}
+constexpr uint32_t kTileFloats = 32 * 1024;  // 128 KiB of fp32 accumulators per workgroup
+
+// [B, L*C] -> [L, B, C] so a (level, tile) owner streams contiguous gradients (what grid.py:72 does with a permute)
+template <typename T, int C>
+__global__ __launch_bounds__(256) void grad_to_level_major_kernel(const T* __restrict__ grad, T* __restrict__ out, uint32_t B, uint32_t L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * L) return;
+    const uint32_t b = t / L, l = t - b * L;
+    float v[C];
+    load_row<T, C>(grad + (size_t)t * C, v);
+    store_row<T, C>(out + ((size_t)l * B + b) * C, v);
+}
+
+template <typename T, int D, int C>
+__global__ __launch_bounds__(kOwnerThreads) void grid_backward_owner_kernel(const T* __restrict__ grad_lbc, const float* __restrict__ inputs,
+                                                                            const int* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                                            const uint32_t B, const uint32_t L, const LevelConsts lc,
+                                                                            const uint32_t gridtype, const bool align_corners) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    constexpr uint32_t kRowsPerTile = kTileFloats / C;
+
+    uint32_t total_tiles = 0;
+    for (uint32_t l = 0; l < L; l++) total_tiles += div_up((uint32_t)(offsets[l + 1] - offsets[l]), kRowsPerTile);
+
+    for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        // decode tile -> (level, first row); uniform across the workgroup
+        uint32_t level = 0, t = tile;
+        for (;; level++) {
+            const uint32_t n = div_up((uint32_t)(offsets[level + 1] - offsets[level]), kRowsPerTile);
+            if (t < n) break;
+            t -= n;
+        }
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+        const uint32_t row0 = t * kRowsPerTile;
+        const uint32_t nrows = min(kRowsPerTile, hashmap_size - row0);
+        const float scale = lc.scale[level];
+        const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
+
+        for (uint32_t i = threadIdx.x; i < nrows * C; i += kOwnerThreads) acc[i] = 0.0f;
+        __syncthreads();
+
+        const T* __restrict__ g_level = grad_lbc + (size_t)level * B * C;
+        for (uint32_t b = threadIdx.x; b < B; b += kOwnerThreads) {
+            float x[D];
+            bool valid = true;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                x[d] = inputs[(size_t)b * D + d];
+                if (x[d] < 0 || x[d] > 1) valid = false;
+            }
+            if (!valid) continue;
+            float pos[D];
+            uint32_t pos_grid[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+            }
+            float gc[C];
+            load_row<T, C>(g_level + (size_t)b * C, gc);
+#pragma unroll
+            for (int idx = 0; idx < (1 << D); idx++) {
+                uint32_t p[D];
+#pragma unroll
+                for (int d = 0; d < D; d++) p[d] = pos_grid[d] + ((idx >> d) & 1);
+                const uint32_t rel = index_of(p) - row0;
+                if (rel < nrows) {
+                    float w = 1;
+#pragma unroll
+                    for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+#pragma unroll
+                    for (int c = 0; c < C; c++) atomicAdd(&acc[rel * C + c], w * gc[c]);  // ds_add_f32
+                }
+            }
+        }
+        __syncthreads();
+
+        T* __restrict__ dst = grad_grid + ((size_t)off + row0) * C;
+        for (uint32_t i = threadIdx.x; i < nrows * C; i += kOwnerThreads) {
+            const float a = acc[i];
+            if (a != 0.0f) dst[i] = (T)((float)dst[i] + a);  // the table is pre-zeroed by the caller; "+=" keeps the accumulate contract
+        }
+        __syncthreads();
+    }
+}
+
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]    (gridencoder.cu:317-343)
 template <typename T, int D, int C, bool BLC>
 __global__ __launch_bounds__(256) void grid_input_backward_kernel(const T* __restrict__ grad, const T* __restrict__ dy_dx,
@@ -438,14 +560,39 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
                     const LevelConsts& lc, bool calc_grad, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool align,
                     int layout, hipStream_t st) {
     if (B == 0) return NERFTEX_OK;
-    const dim3 grid(div_up(B, 256u), L), block(256);
+    if (B >= kOwnerMinBatch) {
+        const T* g = grad;
+        if (layout == NERFTEX_LAYOUT_BLC) {
+            T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
+            if (!tmp) return NERFTEX_ERR_HIP;
+            hipLaunchKernelGGL((grad_to_level_major_kernel<T, C>), dim3(div_up(B * L, 256u)), dim3(256), 0, st, grad, tmp, B, L);
+            int rc0 = check_launch("grid_encode_backward(transpose)");
+            if (rc0 != NERFTEX_OK) return rc0;
+            g = tmp;
+        }
+        auto kernel = grid_backward_owner_kernel<T, D, C>;
+        const size_t lds = sizeof(float) * kTileFloats;
+        NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        "hipFuncSetAttribute");
+        hipLaunchKernelGGL(kernel, dim3(owner_grid()), dim3(kOwnerThreads), lds, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align);
+        int rc1 = check_launch("grid_encode_backward(owner)");
+        if (rc1 != NERFTEX_OK || !calc_grad) return rc1;
+        const dim3 g2(div_up(B * (uint32_t)D, 256u)), blk(256);
+        if (layout == NERFTEX_LAYOUT_BLC)
+            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, true>), g2, blk, 0, st, grad, dy_dx, grad_inputs, B, L);
+        else
+            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, false>), g2, blk, 0, st, grad, dy_dx, grad_inputs, B, L);
+        return check_launch("grid_encode_backward(inputs)");
+    }
+    const uint32_t nchunks = div_up(B, 256u);
+    const dim3 grid(kXcds * nchunks * div_up(L, kXcds)), block(256);
     const bool blc = layout == NERFTEX_LAYOUT_BLC;
     if (blc)
         hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
-                           gridtype, align);
+                           gridtype, align, nchunks);
     else
         hipLaunchKernelGGL((grid_backward_kernel<T, D, C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
-                           gridtype, align);
+                           gridtype, align, nchunks);
     int rc = check_launch("grid_encode_backward");
     if (rc != NERFTEX_OK) return rc;
     if (calc_grad) {

@@ -126,6 +126,39 @@ def test_grid_backward(oracle, dev, case, dtype):
         assert np.count_nonzero(got) > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", [GRID_CASES[0], GRID_CASES[1], GRID_CASES[2], GRID_CASES[3], GRID_CASES[4]], ids=lambda c: c[0])
+def test_grid_backward_large_batch_owner_path(oracle, dev, case, dtype):
+    """B >= 16384 switches to the LDS owner-computes accumulation (no global atomics, fp32 sums)."""
+    from nerftex_hip import F16, F32, check, lib, ptr, stream
+
+    s = _grid_setup(oracle, case, 20011, 17, dtype)
+    rng = np.random.default_rng(18)
+    B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
+    # spatially coherent samples (runs along rays) on top of the random ones: heavy same-row traffic on coarse levels
+    s["x"][5000:15000] = np.clip(np.repeat(s["x"][5000:5100], 100, axis=0) + np.tile(np.linspace(0, 0.02, 100, dtype=np.float32)[:, None], (100, D)), 0, 1)
+    grad_lbc = (rng.standard_normal((L, B, C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)
+    want = oracle.grid_encode_backward(grad_lbc, s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
+    x, off = t(s["x"], dev), t(s["offsets"], dev)
+    tag = F16 if dtype == np.float16 else F32
+    tdt = torch.float16 if dtype == np.float16 else torch.float32
+    for layout, g in ((0, grad_lbc), (1, np.ascontiguousarray(grad_lbc.transpose(1, 0, 2).reshape(B, L * C)))):
+        ge = torch.zeros(s["rows"], C, dtype=tdt, device=dev)
+        gt = t(g, dev)
+        dummy = torch.zeros(1, dtype=tdt, device=dev)
+        check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), B, D, C, L, s["S"], s["base"], 0, ptr(dummy),
+                                               ptr(dummy), s["gridtype"], int(s["align"]), tag, layout, stream()))
+        torch.cuda.synchronize()
+        got = ge.cpu().numpy().astype(np.float64)
+        scale = np.abs(want).max()
+        if dtype == np.float32:
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
+        else:
+            # fp32 accumulation, ONE rounding to half at the end; the oracle rounds each contribution to half first
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-3 * scale)
+        assert np.count_nonzero(got) > 0
+
+
 def test_grid_input_backward_fp32_bit_exact(oracle, dev):
     from nerftex_hip import F32, check, lib, ptr, stream
 
