@@ -28,6 +28,7 @@
 #include "workspace.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -259,6 +260,25 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(const float* __restri
     }
 }
 
+// ---- parameters of the large-batch (tile-owner) backward path, see grid_backward_owner_kernel below ----
+constexpr uint32_t kOwnerThreads = 1024;
+constexpr uint32_t kOwnerWaves = kOwnerThreads / kWave;
+constexpr uint32_t kOwnerMinBatch = 16384;      // below this the per-sample atomics are cheaper than sweeping the table
+constexpr uint32_t kOwnerAccBytes = 128 * 1024;  // accumulator tile
+constexpr uint32_t kQueueCap = 128;              // per wave: < 64 pending + <= 64 pushed per round
+constexpr uint32_t kOwnerLdsBytes = kOwnerAccBytes + kOwnerWaves * kQueueCap * 12;  // + per-wave hit queues (<= 12 B entries)
+
+inline int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward: scatter-add of w * grad into the table gradient
 // ------------------------------------------------------------------------------------------------
@@ -408,31 +428,22 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, large batches: owner-computes accumulation in LDS (no global atomics)
+// backward, large batches: tile-owner accumulation in LDS for the big (hashed) levels
 // ------------------------------------------------------------------------------------------------
-// Measured on MI355X (tools/probes/atomic_probe.hip): global float atomics top out at ~20 G lane-ops/s no
-// matter how small the footprint or which XCD issues them, ~10x below plain stores.  A training batch is
-// ~29 M corner contributions, i.e. >= 1.4 ms of atomics.  So for large batches the scatter is turned
-// around: the gradient table is cut into tiles of kTileFloats fp32 accumulators that fit the 160 KB LDS,
-// each workgroup OWNS tiles, scans every sample of the tile's level (sample + its level gradient are 16 B,
-// L2-resident after the first pass), adds the contributions that fall into its tile with LDS atomics
-// (ds_add_f32, ~3 orders of magnitude more throughput) and finally adds the tile to the table with plain
-// coalesced read-modify-writes.  Accumulation is fp32 (the reference rounds every single add to fp16).
-constexpr uint32_t kOwnerThreads = 1024;
-constexpr uint32_t kOwnerMinBatch = 16384;  // below this the per-sample atomics are cheaper than sweeping the whole table
-inline uint32_t owner_grid() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
-    return (uint32_t)cus;  // one 1024-thread workgroup (128 KiB LDS) per CU, persistent over tiles
-}
-constexpr uint32_t kTileFloats = 32 * 1024;  // 128 KiB of fp32 accumulators per workgroup
-
-// [B, L*C] -> [L, B, C] so a (level, tile) owner streams contiguous gradients (what grid.py:72 does with a permute)
+// Measured on MI355X (tools/probes/atomic_probe.hip): global float atomics retire ~20 G cache-line
+// transactions/s whatever the footprint or the issuing XCD (lanes that fall in one 64-B line share a
+// transaction; plain stores are ~10x faster).  A training batch scatters ~29 M corner contributions into
+// ~15 M distinct lines per step: >= 0.7-1.4 ms of atomics, while every 64-B line of a fine level is hit
+// ~30 times per step.  So for large batches the big levels are turned around: a level's slice of the
+// gradient table is cut into tiles whose accumulators fit the 160 KB LDS; a workgroup takes (tile, slice
+// of the batch), scans its samples (16 B each: position + this level's gradient, L2-resident), and adds
+// the corners that fall into its tile with LDS atomics (ds_pk_add_f16 / ds_add_f32).  Only ~1 corner in
+// 15-30 hits a given tile, so hits are first pushed into a per-wave LDS queue (ballot + mbcnt compaction)
+// and drained 64 at a time with all lanes busy, instead of running a 2-lanes-active hit path per corner.
+// The finished tile is added to the table with fully coalesced atomics (16 lanes per line: ~250 G ops/s).
+// Small levels (a handful of tiles: they would serialise on a few CUs) stay on the per-sample atomic
+// kernel above, where the wave64 run compression already removes most of their traffic.
+// [B, L*C] -> [L, B, C] so a tile owner streams contiguous gradients (what grid.py:72 does with a permute)
 template <typename T, int C>
 __global__ __launch_bounds__(256) void grad_to_level_major_kernel(const T* __restrict__ grad, T* __restrict__ out, uint32_t B, uint32_t L) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,76 +454,224 @@ __global__ __launch_bounds__(256) void grad_to_level_major_kernel(const T* __res
     store_row<T, C>(out + ((size_t)l * B + b) * C, v);
 }
 
-template <typename T, int D, int C>
+// queue entry of the owner kernel: row inside the tile + the (already weighted) 2-channel contribution
+template <typename T> struct OwnerEntry;
+template <> struct OwnerEntry<half_t> { uint32_t rel; half2_t v; };
+template <> struct OwnerEntry<float> { uint32_t rel; float v0, v1; };
+
+__device__ __forceinline__ void lds_add2(half_t* acc_row, const half2_t& v) {
+    typedef __attribute__((address_space(3))) half2_t lds_h2;
+    __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)acc_row, v);  // ds_pk_add_f16
+}
+__device__ __forceinline__ void lds_add2(float* acc_row, float v0, float v1) {
+    atomicAdd(acc_row, v0);  // ds_add_f32
+    atomicAdd(acc_row + 1, v1);
+}
+
+// work decomposition, recomputed by every workgroup from the level table: level l has nt_l tiles and is
+// swept by sp_l workgroups per tile (each taking 1/sp_l of the batch), sp_l chosen so that every level
+// contributes about `items_per_level` work items whatever its size.
+template <typename T>
+struct OwnerPlan {
+    static constexpr uint32_t kRowsPerTile = kOwnerAccBytes / (uint32_t)(2 * sizeof(T));
+    __device__ static uint32_t tiles(uint32_t rows) { return div_up(rows, kRowsPerTile); }
+    __device__ static uint32_t splits(uint32_t rows, uint32_t items_per_level) {
+        const uint32_t nt = tiles(rows);
+        const uint32_t sp = (items_per_level + nt / 2) / nt;
+        return sp ? sp : 1u;
+    }
+};
+
+template <typename T, int D>
 __global__ __launch_bounds__(kOwnerThreads) void grid_backward_owner_kernel(const T* __restrict__ grad_lbc, const float* __restrict__ inputs,
                                                                             const int* __restrict__ offsets, T* __restrict__ grad_grid,
                                                                             const uint32_t B, const uint32_t L, const LevelConsts lc,
-                                                                            const uint32_t gridtype, const bool align_corners) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];
-    constexpr uint32_t kRowsPerTile = kTileFloats / C;
+                                                                            const uint32_t gridtype, const bool align_corners,
+                                                                            const uint32_t items_per_level) {
+    constexpr int C = 2;
+    using Plan = OwnerPlan<T>;
+    using Entry = OwnerEntry<T>;
+    constexpr uint32_t kRowsPerTile = Plan::kRowsPerTile;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* acc = reinterpret_cast<T*>(smem);
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    Entry* queue = reinterpret_cast<Entry*>(smem + kOwnerAccBytes) + wave * kQueueCap;
 
-    uint32_t total_tiles = 0;
-    for (uint32_t l = 0; l < L; l++) total_tiles += div_up((uint32_t)(offsets[l + 1] - offsets[l]), kRowsPerTile);
+    uint32_t total_items = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t rows = (uint32_t)(offsets[l + 1] - offsets[l]);
+        total_items += Plan::tiles(rows) * Plan::splits(rows, items_per_level);
+    }
 
-    for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        // decode tile -> (level, first row); uniform across the workgroup
-        uint32_t level = 0, t = tile;
-        for (;; level++) {
-            const uint32_t n = div_up((uint32_t)(offsets[level + 1] - offsets[level]), kRowsPerTile);
-            if (t < n) break;
-            t -= n;
+    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+        uint32_t r = item, level = 0, splits = 1;
+        for (;; level++) {  // decode item -> (level, tile, split); uniform
+            const uint32_t rows = (uint32_t)(offsets[level + 1] - offsets[level]);
+            splits = Plan::splits(rows, items_per_level);
+            const uint32_t n = Plan::tiles(rows) * splits;
+            if (r < n) break;
+            r -= n;
         }
+        const uint32_t tile = r / splits, split = r - tile * splits;
         const uint32_t off = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-        const uint32_t row0 = t * kRowsPerTile;
+        const uint32_t row0 = tile * kRowsPerTile;
         const uint32_t nrows = min(kRowsPerTile, hashmap_size - row0);
         const float scale = lc.scale[level];
         const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
-
-        for (uint32_t i = threadIdx.x; i < nrows * C; i += kOwnerThreads) acc[i] = 0.0f;
-        __syncthreads();
-
         const T* __restrict__ g_level = grad_lbc + (size_t)level * B * C;
-        for (uint32_t b = threadIdx.x; b < B; b += kOwnerThreads) {
-            float x[D];
-            bool valid = true;
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                x[d] = inputs[(size_t)b * D + d];
-                if (x[d] < 0 || x[d] > 1) valid = false;
-            }
-            if (!valid) continue;
-            float pos[D];
-            uint32_t pos_grid[D];
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
-                pos_grid[d] = (uint32_t)floorf(pos[d]);
-                pos[d] -= (float)pos_grid[d];
-            }
-            float gc[C];
-            load_row<T, C>(g_level + (size_t)b * C, gc);
-#pragma unroll
-            for (int idx = 0; idx < (1 << D); idx++) {
-                uint32_t p[D];
-#pragma unroll
-                for (int d = 0; d < D; d++) p[d] = pos_grid[d] + ((idx >> d) & 1);
-                const uint32_t rel = index_of(p) - row0;
-                if (rel < nrows) {
-                    float w = 1;
-#pragma unroll
-                    for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
-#pragma unroll
-                    for (int c = 0; c < C; c++) atomicAdd(&acc[rel * C + c], w * gc[c]);  // ds_add_f32
-                }
-            }
+
+        {   // zero the accumulators (dword granularity)
+            uint32_t* z = reinterpret_cast<uint32_t*>(acc);
+            const uint32_t ndw = (nrows * C * (uint32_t)sizeof(T) + 3) / 4;
+            for (uint32_t i = threadIdx.x; i < ndw; i += kOwnerThreads) z[i] = 0u;
         }
         __syncthreads();
 
+        auto drain = [&](uint32_t n_entries) {
+            if (lane < n_entries) {
+                const Entry e = queue[lane];
+                if constexpr (sizeof(T) == 2) lds_add2(acc + (size_t)e.rel * C, e.v);
+                else lds_add2(acc + (size_t)e.rel * C, e.v0, e.v1);
+            }
+        };
+
+        const uint32_t per_split = div_up(div_up(B, splits), kOwnerThreads) * kOwnerThreads;
+        const uint32_t lo = split * per_split;
+        const uint32_t hi = min(B, lo + per_split);
+        const uint32_t n_iter = per_split / kOwnerThreads;
+        // staggered start: workgroups sweeping the same samples should not walk the same L2 lines in lock-step
+        const uint32_t shift = (uint32_t)((blockIdx.x * 37u) % n_iter);
+        uint32_t q_count = 0;  // wave-uniform
+
+        auto sample_of = [&](uint32_t it) {
+            uint32_t k = it + shift;
+            if (k >= n_iter) k -= n_iter;
+            return lo + k * kOwnerThreads + threadIdx.x;
+        };
+        // software pipeline: the next sample's 16 bytes are in flight while the current one is processed
+        float xn[D];
+        float gn[C];
+        auto fetch = [&](uint32_t b) {
+            if (b < hi) {
+#pragma unroll
+                for (int d = 0; d < D; d++) xn[d] = inputs[(size_t)b * D + d];
+                load_row<T, C>(g_level + (size_t)b * C, gn);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; d++) xn[d] = -1.0f;  // out of range -> contributes nothing
+                gn[0] = gn[1] = 0.0f;
+            }
+        };
+        // the sweep, instantiated twice: hashed power-of-two levels get a branch-free index (3 multiplies shared by
+        // the 8 corners, then xor / and / sub per corner); every other level type uses the general index function
+        auto sweep = [&](auto rel_of) {
+            fetch(sample_of(0));
+            for (uint32_t it = 0; it < n_iter; it++) {
+                float x[D], g[C];
+#pragma unroll
+                for (int d = 0; d < D; d++) x[d] = xn[d];
+                g[0] = gn[0];
+                g[1] = gn[1];
+                if (it + 1 < n_iter) fetch(sample_of(it + 1));
+
+                bool valid = true;
+                float pos[D];
+                uint32_t pos_grid[D];
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    if (x[d] < 0 || x[d] > 1) valid = false;
+                    pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+                    pos_grid[d] = (uint32_t)floorf(pos[d]);
+                    pos[d] -= (float)pos_grid[d];
+                }
+                uint32_t rel[1 << D];
+                rel_of(pos_grid, rel);
+                uint32_t bits = 0;
+#pragma unroll
+                for (int idx = 0; idx < (1 << D); idx++)
+                    if (rel[idx] < nrows) bits |= 1u << idx;
+                if (!valid) bits = 0;
+                // push the hits corner by corner (ballot + mbcnt compaction); drain whenever a full wave of work is queued
+#pragma unroll
+                for (int idx = 0; idx < (1 << D); idx++) {
+                    const bool hit = (bits >> idx) & 1u;
+                    const uint64_t m = __ballot(hit);
+                    if (m == 0ull) continue;
+                    if (hit) {
+                        float wi = 1;
+#pragma unroll
+                        for (int d = 0; d < D; d++) wi *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+                        const uint32_t slot = q_count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        Entry e;
+                        e.rel = rel[idx];
+                        if constexpr (sizeof(T) == 2) e.v = half2_t{(half_t)(wi * g[0]), (half_t)(wi * g[1])};
+                        else { e.v0 = wi * g[0]; e.v1 = wi * g[1]; }
+                        queue[slot] = e;
+                    }
+                    q_count += (uint32_t)__popcll(m);
+                    if (q_count >= (uint32_t)kWave) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        drain(kWave);
+                        const uint32_t rest = q_count - kWave;
+                        Entry moved{};
+                        if (lane < rest) moved = queue[kWave + lane];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < rest) queue[lane] = moved;
+                        q_count = rest;
+                    }
+                }
+            }
+        };
+        if (index_of.hashed && index_of.pow2) {
+            const uint32_t mask = hashmap_size - 1;
+            sweep([&](const uint32_t (&pg)[D], uint32_t (&rel)[1 << D]) {
+                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+                uint32_t h[D][2];
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    h[d][0] = pg[d] * primes[d];
+                    h[d][1] = h[d][0] + primes[d];
+                }
+#pragma unroll
+                for (int idx = 0; idx < (1 << D); idx++) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int d = 0; d < D; d++) v ^= h[d][(idx >> d) & 1];
+                    rel[idx] = (v & mask) - row0;
+                }
+            });
+        } else {
+            sweep([&](const uint32_t (&pg)[D], uint32_t (&rel)[1 << D]) {
+#pragma unroll
+                for (int idx = 0; idx < (1 << D); idx++) {
+                    uint32_t p[D];
+#pragma unroll
+                    for (int d = 0; d < D; d++) p[d] = pg[d] + ((idx >> d) & 1);
+                    rel[idx] = index_of(p) - row0;
+                }
+            });
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        drain(q_count);
+        __syncthreads();
+
+        // add the tile to the table: consecutive lanes -> consecutive addresses, so each 64-B line is ONE atomic transaction
         T* __restrict__ dst = grad_grid + ((size_t)off + row0) * C;
-        for (uint32_t i = threadIdx.x; i < nrows * C; i += kOwnerThreads) {
-            const float a = acc[i];
-            if (a != 0.0f) dst[i] = (T)((float)dst[i] + a);  // the table is pre-zeroed by the caller; "+=" keeps the accumulate contract
+        if constexpr (sizeof(T) == 2) {
+            const uint32_t* a32 = reinterpret_cast<const uint32_t*>(acc);
+            for (uint32_t i = threadIdx.x; i < nrows; i += kOwnerThreads) {
+                const uint32_t v = a32[i];
+                if (v & 0x7fff7fffu) unsafeAtomicAdd(reinterpret_cast<__half2*>(dst) + i, __builtin_bit_cast(__half2, v));
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < nrows * C; i += kOwnerThreads) {
+                const float v = reinterpret_cast<const float*>(acc)[i];
+                if (v != 0.0f) atomic_add_f32(reinterpret_cast<float*>(dst) + i, v);
+            }
         }
         __syncthreads();
     }
@@ -560,41 +719,45 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
                     const LevelConsts& lc, bool calc_grad, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool align,
                     int layout, hipStream_t st) {
     if (B == 0) return NERFTEX_OK;
-    if (B >= kOwnerMinBatch) {
-        const T* g = grad;
-        if (layout == NERFTEX_LAYOUT_BLC) {
-            T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
-            if (!tmp) return NERFTEX_ERR_HIP;
-            hipLaunchKernelGGL((grad_to_level_major_kernel<T, C>), dim3(div_up(B * L, 256u)), dim3(256), 0, st, grad, tmp, B, L);
-            int rc0 = check_launch("grid_encode_backward(transpose)");
-            if (rc0 != NERFTEX_OK) return rc0;
-            g = tmp;
-        }
-        auto kernel = grid_backward_owner_kernel<T, D, C>;
-        const size_t lds = sizeof(float) * kTileFloats;
-        NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        "hipFuncSetAttribute");
-        hipLaunchKernelGGL(kernel, dim3(owner_grid()), dim3(kOwnerThreads), lds, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align);
-        int rc1 = check_launch("grid_encode_backward(owner)");
-        if (rc1 != NERFTEX_OK || !calc_grad) return rc1;
-        const dim3 g2(div_up(B * (uint32_t)D, 256u)), blk(256);
-        if (layout == NERFTEX_LAYOUT_BLC)
-            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, true>), g2, blk, 0, st, grad, dy_dx, grad_inputs, B, L);
-        else
-            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, false>), g2, blk, 0, st, grad, dy_dx, grad_inputs, B, L);
-        return check_launch("grid_encode_backward(inputs)");
-    }
     const uint32_t nchunks = div_up(B, 256u);
     const dim3 grid(kXcds * nchunks * div_up(L, kXcds)), block(256);
     const bool blc = layout == NERFTEX_LAYOUT_BLC;
-    if (blc)
-        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
-                           gridtype, align, nchunks);
-    else
-        hipLaunchKernelGGL((grid_backward_kernel<T, D, C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
-                           gridtype, align, nchunks);
-    int rc = check_launch("grid_encode_backward");
-    if (rc != NERFTEX_OK) return rc;
+    const char* force = getenv("NERFTEX_GRID_BWD");  // "atomic" | "owner": A/B switch for profiling
+    bool owner = C == 2 && (force ? (force[0] == 'o') : (B >= kOwnerMinBatch));
+    int rc = NERFTEX_OK;
+    if constexpr (C == 2) {
+        if (owner) {  // every level through the LDS tile owners, no per-sample global atomics at all
+            const T* g = grad;
+            if (blc) {
+                T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
+                if (!tmp) return NERFTEX_ERR_HIP;
+                hipLaunchKernelGGL((grad_to_level_major_kernel<T, C>), dim3(div_up(B * L, 256u)), dim3(256), 0, st, grad, tmp, B, L);
+                rc = check_launch("grid_encode_backward(transpose)");
+                if (rc != NERFTEX_OK) return rc;
+                g = tmp;
+            }
+            auto kernel = grid_backward_owner_kernel<T, D>;
+            NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnerLdsBytes),
+                            "hipFuncSetAttribute");
+            const uint32_t cus = (uint32_t)device_cus();
+            const char* ip = getenv("NERFTEX_GRID_BWD_ITEMS");
+            const uint32_t items_per_level = ip ? (uint32_t)atoi(ip) : div_up(6u * cus, L);
+            hipLaunchKernelGGL(kernel, dim3(cus), dim3(kOwnerThreads), kOwnerLdsBytes, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align,
+                               items_per_level ? items_per_level : 1u);
+            rc = check_launch("grid_encode_backward(owner)");
+            if (rc != NERFTEX_OK) return rc;
+        }
+    }
+    if (!owner) {  // per-sample atomics with wave64 run compression
+        if (blc)
+            hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
+                               gridtype, align, nchunks);
+        else
+            hipLaunchKernelGGL((grid_backward_kernel<T, D, C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
+                               gridtype, align, nchunks);
+        rc = check_launch("grid_encode_backward");
+        if (rc != NERFTEX_OK) return rc;
+    }
     if (calc_grad) {
         const dim3 g2(div_up(B * (uint32_t)D, 256u));
         if (blc)

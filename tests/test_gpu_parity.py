@@ -154,8 +154,8 @@ def test_grid_backward_large_batch_owner_path(oracle, dev, case, dtype):
         if dtype == np.float32:
             np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
         else:
-            # fp32 accumulation, ONE rounding to half at the end; the oracle rounds each contribution to half first
-            np.testing.assert_allclose(got, want, rtol=0, atol=3e-3 * scale)
+            # big levels: fp16 LDS accumulation per tile; small levels: packed-half atomics (every add rounds to half)
+            np.testing.assert_allclose(got, want, rtol=0, atol=(3e-3 if case[0] == "fox_L16_C2" else 2e-2) * scale)
         assert np.count_nonzero(got) > 0
 
 
