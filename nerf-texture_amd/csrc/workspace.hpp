@@ -8,7 +8,7 @@
 
 namespace nerftex {
 
-enum WorkspaceSlot { kWsMarch = 0, kWsCompact = 1, kWsMlp = 2, kWsGrid = 3, kWsSlots = 4 };
+enum WorkspaceSlot { kWsMarch = 0, kWsCompact = 1, kWsMlp = 2, kWsGrid = 3, kWsGridFwd = 4, kWsSlots = 5 };
 
 // returns nullptr (and sets the error text) on allocation failure
 void* workspace(WorkspaceSlot slot, size_t bytes);
