@@ -282,3 +282,18 @@ def ffmlp_backward(grad, inputs, weights, forward_buffer, input_dim, output_dim,
     lib().orc_ffmlp_backward(_p(grad), _p(inputs), _p(weights), _p(forward_buffer), u32(B), u32(input_dim),
                              u32(output_dim), u32(hidden_dim), u32(num_layers), u32(activation), _p(bb), _p(gi), _p(gw))
     return gw, gi, bb
+
+
+# ------------------------------------------------------------------ RayTracer (brute force)
+def raytrace(vertices, triangles, rays_o, rays_d):
+    v = _f32(vertices)
+    f = np.ascontiguousarray(triangles, dtype=np.uint32)
+    o, d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    N = o.shape[0]
+    pos = np.zeros((N, 3), np.float32)
+    nrm = np.zeros((N, 3), np.float32)
+    depth = np.zeros(N, np.float32)
+    face = np.zeros(N, np.int64)
+    second = np.zeros(N, np.float32)
+    lib().orc_raytrace(_p(v), _p(f), u32(f.shape[0]), _p(o), _p(d), u32(N), _p(pos), _p(nrm), _p(depth), _p(face), _p(second))
+    return pos, nrm, depth, face, second

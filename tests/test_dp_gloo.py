@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
         opt.step()
     mc = dp.all_reduce_max_int(100 + rank, torch.device("cpu"))
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-    q.put((rank, flat, mc))
+    q.put((rank, flat.numpy().copy(), mc))  # by value: torch tensors travel as shared-memory fds that die with the worker
     dp.barrier()
     dist.destroy_process_group()
 
@@ -71,7 +71,7 @@ def test_two_rank_gloo_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     results.sort(key=lambda t: t[0])
-    w0, w1 = results[0][1], results[1][1]
+    w0, w1 = torch.from_numpy(results[0][1]), torch.from_numpy(results[1][1])
     assert torch.equal(w0, w1), "replicas must stay bit-identical"
     assert results[0][2] == results[1][2] == 101
     ref = _single_process_reference()
