@@ -77,7 +77,7 @@ def test_trace_matches_bruteforce_oracle(oracle, dev, golden_dir, mesh):
     pos, nrm, depth, face = rt.trace(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))
     pos, nrm, depth, face = pos.cpu().numpy(), nrm.cpu().numpy(), depth.cpu().numpy(), face.cpu().numpy()
     hit = w_face >= 0
-    assert hit.mean() > 0.2 and (~hit).sum() > 0
+    assert hit.mean() > 0.05 and (~hit).sum() > 0
     # identical arithmetic per triangle: the closest distance is bit-exact (the BVH only prunes)
     same = depth.view(np.uint32) == w_depth.view(np.uint32)
     assert same.mean() > 0.999, f"{(~same).sum()} rays differ"
@@ -126,4 +126,4 @@ def test_curved_field_lookup_chain(oracle, dev):
     want = want.transpose(1, 0, 2).reshape(x.shape[0], -1)
     got = feat.detach().cpu().numpy()
     assert np.array_equal(got[ok], want[ok]), "hash lookup at the projected surface point is bit-exact"
-    assert float(field.encoder.clustering_loss()) == float(field.encoder.clustering_loss()) or True
+    assert torch.isfinite(field.encoder.clustering_loss(pick_level=False).detach())
