@@ -424,13 +424,19 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_kernel(const WgradA
     }
 }
 
+// sum the per-workgroup partials: 64 consecutive parameters x 4 slices of the partial list per workgroup
+// (256-B coalesced reads), LDS combine of the 4 slices, one fp16 store per parameter
 __global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_parts,
                                                                            uint32_t n_params, half_t* __restrict__ grad_weights) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_params) return;
+    __shared__ float red[4][64];
+    const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * 64 + lane;
     float s = 0.0f;
-    for (uint32_t k = 0; k < n_parts; k++) s += partials[(size_t)k * n_params + p];
-    grad_weights[p] = (half_t)s;
+    if (p < n_params)
+        for (uint32_t k = slice; k < n_parts; k += 4) s += partials[(size_t)k * n_params + p];
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && p < n_params) grad_weights[p] = (half_t)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,7 +628,7 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     hipLaunchKernelGGL(ffmlp_wgrad_kernel, dim3(n_parts, NL + 1), dim3(kBlockThreads), red_bytes, st, args, B, partials, n_params);
     rc = check_launch("ffmlp_backward(wgrad)");
     if (rc != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, (uint32_t)kBlockThreads)), dim3(kBlockThreads), 0, st, partials, n_parts,
+    hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, 64u)), dim3(kBlockThreads), 0, st, partials, n_parts,
                        n_params, static_cast<half_t*>(grad_weights));
     return check_launch("ffmlp_backward(reduce)");
 }

@@ -1,0 +1,133 @@
+// Pieces shared by the hash-grid kernels (gridencoder.hip, gridencoder_binned.hip): level constants folded on the
+// host, the index function of the reference (gridencoder.cu:35-72) in uniform-per-level form, vector row access.
+#pragma once
+#include "common.hpp"
+
+#include <cmath>
+
+#pragma clang fp contract(off)  // only explicit fmaf() may fuse: the hash-grid float path is bit-exact vs the oracle
+
+namespace nerftex {
+namespace gridenc {
+
+constexpr int kMaxLevels = 32;
+constexpr uint32_t kXcds = 8;  // accelerator complex dies of an MI355X, each with a private 4 MiB L2
+constexpr uint32_t kLevelFwdMinBatch = 8192;  // from here on the XCD-pinned (point, level) forward wins
+
+struct LevelConsts {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+// host: gridencoder.cu:125-127, evaluated once per call instead of per thread
+inline LevelConsts make_level_consts(uint32_t L, float S, uint32_t H) {
+    LevelConsts lc{};
+    for (uint32_t l = 0; l < L && l < (uint32_t)kMaxLevels; l++) {
+        const float p = exp2f((float)l * S) * (float)H;
+        const float scale = p - 1.0f;
+        lc.scale[l] = scale;
+        lc.resolution[l] = (uint32_t)ceil((double)scale) + 1u;
+    }
+    return lc;
+}
+
+// uniform (per level) description of the index function, gridencoder.cu:54-72
+template <int D>
+struct IndexFn {
+    uint32_t stride[D];  // stride[d] used while the reference loop is still running
+    uint32_t ndense;     // number of dimensions the dense loop covers
+    bool hashed;
+    bool pow2;
+    uint32_t size;
+
+    __device__ IndexFn(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
+        uint32_t s = 1;
+        ndense = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            stride[d] = s;
+            if (s <= hashmap_size) {
+                ndense = d + 1;
+                s *= align_corners ? resolution : (resolution + 1);
+            }
+        }
+        hashed = (gridtype == 0) && (s > hashmap_size);
+        size = hashmap_size;
+        pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
+    }
+
+    __device__ __forceinline__ uint32_t operator()(const uint32_t (&p)[D]) const {
+        uint32_t index;
+        if (hashed) {
+            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+            index = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) index ^= p[d] * primes[d];
+        } else {
+            index = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if ((uint32_t)d < ndense) index += p[d] * stride[d];
+        }
+        if (pow2) return index & (size - 1);
+        return index >= size ? index % size : index;
+    }
+};
+
+template <typename T, int C>
+struct Vec;
+template <> struct Vec<float, 1> { using type = float; };
+template <> struct Vec<float, 2> { using type = float2_t; };
+template <> struct Vec<float, 4> { using type = float4_t; };
+template <> struct Vec<half_t, 1> { using type = half_t; };
+template <> struct Vec<half_t, 2> { using type = half2_t; };
+template <> struct Vec<half_t, 4> { using type = half4_t; };
+template <> struct Vec<half_t, 8> { using type = half8_t; };
+
+// load C consecutive features of one table row as floats (one vector load where a type exists)
+template <typename T, int C>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, float (&v)[C]) {
+    if constexpr (C == 8 && sizeof(T) == 4) {
+        const float4_t a = *reinterpret_cast<const float4_t*>(p);
+        const float4_t b = *reinterpret_cast<const float4_t*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = a[i]; v[4 + i] = b[i]; }
+    } else if constexpr (C == 1) {
+        v[0] = (float)p[0];
+    } else {
+        using V = typename Vec<T, C>::type;
+        const V a = *reinterpret_cast<const V*>(p);
+#pragma unroll
+        for (int i = 0; i < C; i++) v[i] = (float)a[i];
+    }
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]) {
+    if constexpr (C == 8 && sizeof(T) == 4) {
+        float4_t a, b;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = v[i]; b[i] = v[4 + i]; }
+        *reinterpret_cast<float4_t*>(p) = a;
+        *reinterpret_cast<float4_t*>(p + 4) = b;
+    } else if constexpr (C == 1) {
+        p[0] = (T)v[0];
+    } else {
+        using V = typename Vec<T, C>::type;
+        V a;
+#pragma unroll
+        for (int i = 0; i < C; i++) a[i] = (T)v[i];
+        *reinterpret_cast<V*>(p) = a;
+    }
+}
+
+
+
+// large-batch table-gradient path (gridencoder_binned.hip): bins the corner contributions by table tile, then
+// accumulates every tile in LDS.  C == 2 only.  Returns NERFTEX_OK or an error; grad is level-major [L,B,2].
+template <typename T, int D>
+int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
+                         const LevelConsts& lc, uint32_t gridtype, bool align_corners, hipStream_t st);
+
+}  // namespace gridenc
+}  // namespace nerftex

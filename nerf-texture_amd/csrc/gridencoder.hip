@@ -25,6 +25,7 @@
 // is fmaf(w, g, acc) over corners 0..2^D-1 in fp32.  For fp16 tables the sum is
 // kept in fp32 and rounded once (the reference rounds to half after every corner).
 #include "common.hpp"
+#include "grid_common.hpp"
 #include "workspace.hpp"
 
 #include <cmath>
@@ -35,116 +36,7 @@
 namespace nerftex {
 namespace {
 
-constexpr int kMaxLevels = 32;
-constexpr uint32_t kXcds = 8;  // accelerator complex dies of an MI355X, each with a private 4 MiB L2
-constexpr uint32_t kLevelFwdMinBatch = 8192;  // from here on the XCD-pinned (point, level) forward wins
-
-struct LevelConsts {
-    float scale[kMaxLevels];
-    uint32_t resolution[kMaxLevels];
-};
-
-// host: gridencoder.cu:125-127, evaluated once per call instead of per thread
-LevelConsts make_level_consts(uint32_t L, float S, uint32_t H) {
-    LevelConsts lc{};
-    for (uint32_t l = 0; l < L && l < (uint32_t)kMaxLevels; l++) {
-        const float p = exp2f((float)l * S) * (float)H;
-        const float scale = p - 1.0f;
-        lc.scale[l] = scale;
-        lc.resolution[l] = (uint32_t)ceil((double)scale) + 1u;
-    }
-    return lc;
-}
-
-// uniform (per level) description of the index function, gridencoder.cu:54-72
-template <int D>
-struct IndexFn {
-    uint32_t stride[D];  // stride[d] used while the reference loop is still running
-    uint32_t ndense;     // number of dimensions the dense loop covers
-    bool hashed;
-    bool pow2;
-    uint32_t size;
-
-    __device__ IndexFn(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
-        uint32_t s = 1;
-        ndense = 0;
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            stride[d] = s;
-            if (s <= hashmap_size) {
-                ndense = d + 1;
-                s *= align_corners ? resolution : (resolution + 1);
-            }
-        }
-        hashed = (gridtype == 0) && (s > hashmap_size);
-        size = hashmap_size;
-        pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
-    }
-
-    __device__ __forceinline__ uint32_t operator()(const uint32_t (&p)[D]) const {
-        uint32_t index;
-        if (hashed) {
-            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-            index = 0;
-#pragma unroll
-            for (int d = 0; d < D; d++) index ^= p[d] * primes[d];
-        } else {
-            index = 0;
-#pragma unroll
-            for (int d = 0; d < D; d++)
-                if ((uint32_t)d < ndense) index += p[d] * stride[d];
-        }
-        if (pow2) return index & (size - 1);
-        return index >= size ? index % size : index;
-    }
-};
-
-template <typename T, int C>
-struct Vec;
-template <> struct Vec<float, 1> { using type = float; };
-template <> struct Vec<float, 2> { using type = float2_t; };
-template <> struct Vec<float, 4> { using type = float4_t; };
-template <> struct Vec<half_t, 1> { using type = half_t; };
-template <> struct Vec<half_t, 2> { using type = half2_t; };
-template <> struct Vec<half_t, 4> { using type = half4_t; };
-template <> struct Vec<half_t, 8> { using type = half8_t; };
-
-// load C consecutive features of one table row as floats (one vector load where a type exists)
-template <typename T, int C>
-__device__ __forceinline__ void load_row(const T* __restrict__ p, float (&v)[C]) {
-    if constexpr (C == 8 && sizeof(T) == 4) {
-        const float4_t a = *reinterpret_cast<const float4_t*>(p);
-        const float4_t b = *reinterpret_cast<const float4_t*>(p + 4);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { v[i] = a[i]; v[4 + i] = b[i]; }
-    } else if constexpr (C == 1) {
-        v[0] = (float)p[0];
-    } else {
-        using V = typename Vec<T, C>::type;
-        const V a = *reinterpret_cast<const V*>(p);
-#pragma unroll
-        for (int i = 0; i < C; i++) v[i] = (float)a[i];
-    }
-}
-
-template <typename T, int C>
-__device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]) {
-    if constexpr (C == 8 && sizeof(T) == 4) {
-        float4_t a, b;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { a[i] = v[i]; b[i] = v[4 + i]; }
-        *reinterpret_cast<float4_t*>(p) = a;
-        *reinterpret_cast<float4_t*>(p + 4) = b;
-    } else if constexpr (C == 1) {
-        p[0] = (T)v[0];
-    } else {
-        using V = typename Vec<T, C>::type;
-        V a;
-#pragma unroll
-        for (int i = 0; i < C; i++) a[i] = (T)v[i];
-        *reinterpret_cast<V*>(p) = a;
-    }
-}
+using namespace gridenc;
 
 // ------------------------------------------------------------------------------------------------
 // forward: thread = point, loop over levels
@@ -527,10 +419,18 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
     bool head = true;
     if constexpr (C <= 2) {
         // same cell as the lane below?
+        // every lane must execute every shuffle (no short-circuit): the lane above reads this lane's registers
         bool same = valid && lane > 0;
+        {
+            const int prev_valid = __shfl_up((int)valid, 1, kWave);
+            bool eq = prev_valid != 0;
 #pragma unroll
-        for (int d = 0; d < D; d++) same = same && (__shfl_up(pos_grid[d], 1, kWave) == pos_grid[d]);
-        same = same && (__shfl_up((int)valid, 1, kWave) != 0);
+            for (int d = 0; d < D; d++) {
+                const uint32_t prev = __shfl_up(pos_grid[d], 1, kWave);
+                eq = eq & (prev == pos_grid[d]);
+            }
+            same = same & eq;
+        }
         head = !same;
         const uint64_t heads = __ballot(head);
         if (heads != ~0ull) {  // at least one run longer than 1 in this wave
@@ -906,6 +806,12 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
                 if (rc != NERFTEX_OK) return rc;
                 g = tmp;
             }
+            const char* algo = getenv("NERFTEX_GRID_BWD_ALGO");  // "sweep" keeps the tile-owner sweep; default = binning
+            if (!(algo && algo[0] == 's')) {
+                rc = grid_backward_binned<T, D>(g, inputs, offsets, grad_emb, B, L, lc, gridtype, align, st);
+                if (rc == NERFTEX_OK) goto table_done;
+                if (rc > 0) return rc;  // rc < 0: shape outside the binned path's limits -> sweep below
+            }
             auto kernel = grid_backward_owner_kernel<T, D>;
             NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnerLdsBytes),
                             "hipFuncSetAttribute");
@@ -918,6 +824,7 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
             if (rc != NERFTEX_OK) return rc;
         }
     }
+table_done:
     if (!owner) {  // per-sample atomics with wave64 run compression
         if (blc)
             hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,

@@ -18,6 +18,8 @@
 #include "common.hpp"
 #include "workspace.hpp"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace nerftex {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kRayBlock) void march_count_kernel(const float* __r
                                                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                              const float* __restrict__ nears, const float* __restrict__ fars,
                                                              int* __restrict__ rays, const int* __restrict__ counter,
-                                                             uint32_t* __restrict__ ws, uint32_t perturb) {
+                                                             uint32_t* __restrict__ ws, uint32_t perturb, float* __restrict__ tlog) {
     __shared__ uint32_t wave_tot[kRayBlock / kWave];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t num_steps = 0;
@@ -283,8 +285,10 @@ __global__ __launch_bounds__(kRayBlock) void march_count_kernel(const float* __r
         const Dda s(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid, fars[n]);
         float t = ray_t0(s, nears[n], perturb, n, 42);
         float x, y, z, dt;
+        float* log_row = tlog ? tlog + (size_t)n * max_steps : nullptr;
         while (t < s.far && num_steps < max_steps) {
             if (s.step(t, x, y, z, dt)) {
+                if (log_row) log_row[num_steps] = t;  // parameter of the accepted sample: all the expand pass needs
                 num_steps++;
                 t += dt;
             }
@@ -367,6 +371,83 @@ __global__ __launch_bounds__(kRayBlock) void march_write_kernel(const float* __r
             last_t = t;
             px += 3; pd += 3; pl += 2;
             step++;
+        }
+    }
+}
+
+// Sample-parallel second pass (used when the count pass logged the accepted t's): a 256-thread workgroup owns 64 rays,
+// rebuilds their offsets (workgroup sums + wave64 scan, as above), then its 4 waves expand the rays one after the
+// other with 64 lanes over the samples of a ray -- coalesced log reads and coalesced xyz / dir / delta stores instead
+// of a second serial DDA per ray.  x = clamp(o + t d), dt = clamp(t dt_gamma, ..) and t_next = t + dt are recomputed
+// with the very expressions of the DDA, so the samples are bit-identical to the replay.
+template <bool WITH_TS>
+__global__ __launch_bounds__(256) void march_expand_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
+                                                           float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                           const float* __restrict__ nears, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                           float* __restrict__ deltas, float* __restrict__ rays_ts, int* __restrict__ rays,
+                                                           int* __restrict__ counter, const uint32_t* __restrict__ ws, uint32_t perturb,
+                                                           const float* __restrict__ tlog) {
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t s_off[kRayBlock], s_cnt[kRayBlock];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += ws[1 + j];
+    part = wave_sum(part);
+    if (lane == 0) red[wid] = part;
+    __syncthreads();
+    const uint32_t before = ws[0] + red[0] + red[1] + red[2] + red[3];
+    if (wid == 0) {  // one wave = the 64 rays of this workgroup
+        const uint32_t n = blockIdx.x * kRayBlock + lane;
+        const uint32_t num_steps = n < N ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
+        const uint32_t incl = wave_inclusive_scan(num_steps);
+        const uint32_t point_index = before + incl - num_steps;
+        s_off[lane] = point_index;
+        s_cnt[lane] = (num_steps == 0 || point_index + num_steps >= M) ? 0u : num_steps;  // raymarching.cu:418-419
+        if (n < N) {
+            rays[3 * (size_t)n] = (int)n;
+            rays[3 * (size_t)n + 1] = (int)point_index;
+        }
+        if (blockIdx.x == gridDim.x - 1 && lane == kWave - 1) {
+            counter[0] = (int)(point_index + num_steps);
+            counter[1] = counter[1] + (int)N;
+        }
+    }
+    __syncthreads();
+
+    const float dt_min = 2 * kSqrt3 / (float)max_steps;
+    const float dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
+    for (uint32_t r = wid; r < kRayBlock; r += 4) {
+        const uint32_t cnt = s_cnt[r];
+        if (cnt == 0) continue;
+        const uint32_t n = blockIdx.x * kRayBlock + r;
+        const uint32_t off = s_off[r];
+        const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
+        const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
+        float t0 = nears[n];
+        if (perturb) {
+            Pcg32 rng(42);
+            rng.advance((uint64_t)n);
+            t0 = fmaf(dt_min, rng.next_float(), t0);
+        }
+        const float* log_row = tlog + (size_t)n * max_steps;
+        for (uint32_t k = lane; k < cnt; k += kWave) {
+            const float t = log_row[k];
+            const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+            float last_t = t0;
+            if (k > 0) {
+                const float tp = log_row[k - 1];
+                last_t = tp + clampf(tp * dt_gamma, dt_min, dt_max);
+            }
+            const float t_next = t + dt;
+            const size_t i = (size_t)off + k;
+            xyzs[3 * i] = clampf(fmaf(t, dx, ox), -bound, bound);
+            xyzs[3 * i + 1] = clampf(fmaf(t, dy, oy), -bound, bound);
+            xyzs[3 * i + 2] = clampf(fmaf(t, dz, oz), -bound, bound);
+            dirs[3 * i] = dx; dirs[3 * i + 1] = dy; dirs[3 * i + 2] = dz;
+            deltas[2 * i] = dt;
+            deltas[2 * i + 1] = t_next - last_t;
+            if constexpr (WITH_TS) rays_ts[i] = t_next;
         }
     }
 }
@@ -593,13 +674,25 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
         return NERFTEX_ERR_INVALID;
     }
     const uint32_t nblocks = div_up(N, kRayBlock);
-    uint32_t* ws = static_cast<uint32_t*>(workspace(kWsMarch, sizeof(uint32_t) * (1 + (size_t)nblocks)));
-    if (!ws) return NERFTEX_ERR_HIP;
+    // scratch: [0] base, [1..nblocks] workgroup totals, then (optionally) the per-ray log of accepted t's [N, max_steps]
+    const size_t head = (sizeof(uint32_t) * (1 + (size_t)nblocks) + 255) / 256 * 256;
+    const size_t log_bytes = sizeof(float) * (size_t)N * max_steps;
+    const char* force = getenv("NERFTEX_MARCH");  // "replay" | "log": A/B switch for profiling
+    const bool use_log = force ? (force[0] == 'l') : (log_bytes <= ((size_t)1 << 30));
+    char* base = static_cast<char*>(workspace(kWsMarch, head + (use_log ? log_bytes : 0)));
+    if (!base) return NERFTEX_ERR_HIP;
+    uint32_t* ws = reinterpret_cast<uint32_t*>(base);
+    float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
-                       C, H, nears, fars, rays, counter, ws, perturb);
+                       C, H, nears, fars, rays, counter, ws, perturb, tlog);
     int rc = check_launch("march_rays_train(count)");
     if (rc != NERFTEX_OK) return rc;
+    if (use_log) {
+        hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+                           nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog);
+        return check_launch("march_rays_train(expand)");
+    }
     hipLaunchKernelGGL((march_write_kernel<WITH_TS>), dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                        max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb);
     return check_launch("march_rays_train(write)");
