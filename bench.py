@@ -154,7 +154,9 @@ def main():
         pool.append((torch.from_numpy(o[lo:hi]).to(dev), torch.from_numpy(d[lo:hi]).to(dev)))
     gt = torch.rand(n_pool, args.rays, 3, device=dev)
 
-    opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    # same optimizer as main_nerf.py:128 (Adam, betas (0.9, 0.99), eps 1e-15); fused=True keeps GradScaler.step free of its
+    # per-step found_inf .item() read-back (the unscale / skip-on-inf logic runs inside the fused kernel instead)
+    opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
     reducer = dp.FlatGradAllReduce(field.parameters())
     reducer.broadcast_parameters()
     use_amp = args.dtype == "fp16"
