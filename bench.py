@@ -8,10 +8,12 @@ nerf/utils.py:1011-1022 + nerf/renderer.py:338-425 of the reference:
     near_far_from_aabb -> march_rays_train -> hash-grid encode -> sigma MLP -> SH encode -> colour MLP ->
     composite_rays_train -> MSE loss -> backward through the same chain -> (N>1: one RCCL all-reduce of the flat
     gradient) -> GradScaler.step(Adam) -> every 16 steps the `mean_count` read-back of update_extra_state.
-Workload = BASELINE.json configs[1]: fox-style scene, L=16 F=2 hash grid (T=2^19, desired 2048*bound, bound 2),
-HIP gridencoder + raymarching + shencoder, MLPs (2x64 / 3x64, nn.Linear) on PyTorch-ROCm, 800x800 random-pose
-pixels, 4096 rays per batch per GPU, fp16 autocast like the reference's `-O`.  `--mlp ffmlp --rays 8192` is
-configs[2].  Inputs are resident in HBM before the timed region; data = synthetic, weights = seeded random init.
+Default workload = BASELINE.json configs[2] at N=1 and configs[4] at N=8 (8192 rays per GPU -> 65536 rays/step): fox-style
+scene, L=16 F=2 hash grid (T=2^19, desired 2048*bound, bound 2), all four native components on the HIP path
+(gridencoder, raymarching, shencoder, ffmlp 2x64 + 3x64 on MFMA), 800x800 random-pose pixels, fp16 autocast like the
+reference's `-O`.  `--mlp torch --rays 4096` is configs[1] ("MLP still PyTorch-ROCm"); at N=1 the other configuration
+is also run briefly and reported under "other_config".  Inputs are resident in HBM before the timed region; data =
+synthetic, weights = seeded random init.
 
 Prints ONE JSON line (rank 0).  `value` = ray samples actually marched (sum over steps and ranks of the
 march_rays_train counter) / max-over-ranks wall time of the K timed steps.
@@ -31,6 +33,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes), see profiles/: filled in per round
+# for the default workload; None = not collected for this kernel version.
+TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": None, "grid_encode_backward": None}
 
 
 def parse():
@@ -38,8 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per batch PER GPU (weak scaling)")
-    ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="torch")
+    ap.add_argument("--rays", type=int, default=8192, help="rays per batch PER GPU (weak scaling; 8 GPUs x 8192 = configs[4]'s 65536)")
+    ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
+    ap.add_argument("--no-other", action="store_true", help="skip the short run of the other single-GPU configuration")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
     ap.add_argument("--bound", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,39 +126,30 @@ def cpu_baseline(args, sc, bits, field_state, n_rays):
     }
 
 
-# ----------------------------------------------------------------------------------------------------- main
-def main():
-    args = parse()
-    from ngp_harness import dp, scene
-
-    rank, world, local = dp.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
+# ----------------------------------------------------------------------------------------------------- training leg
+def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid, bits, time_grid_kernels):
+    """K timed training steps of one configuration. Returns (result dict, field, renderer)."""
     import nerftex_hip
+    from ngp_harness import dp, scene
     from ngp_harness.model import NGPField, Renderer
 
-    # ---- scene + inputs, resident in HBM before anything is timed
-    sc = scene.Scene(bound=args.bound, seed=0)
-    grid, thresh, bits = sc.bitfield()
     torch.manual_seed(0)
-    field = NGPField(bound=args.bound, mlp=args.mlp).to(dev)
+    field = NGPField(bound=args.bound, mlp=mlp).to(dev)
     torch.manual_seed(1)  # FFMLP.reset_parameters reseeds with 42; give the table its own stream
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
     renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
     renderer.set_occupancy(torch.from_numpy(grid).to(dev))
     assert np.array_equal(renderer.density_bitfield.cpu().numpy(), bits), "packbits parity (HIP vs numpy)"
 
+    # inputs resident in HBM before anything is timed: a pool of ray batches (this rank's shard) + target colours
     n_pool = 8
-    n_global = args.rays * world
+    n_global = rays * world
     pool = []
     for k in range(n_pool):
         o, d = scene.train_batch(n_global, seed=100 + k, n_views=4)
         lo, hi = dp.shard(n_global, rank, world)
         pool.append((torch.from_numpy(o[lo:hi]).to(dev), torch.from_numpy(d[lo:hi]).to(dev)))
-    gt = torch.rand(n_pool, args.rays, 3, device=dev)
+    gt = torch.rand(n_pool, rays, 3, device=dev)
 
     # same optimizer as main_nerf.py:128 (Adam, betas (0.9, 0.99), eps 1e-15); fused=True keeps GradScaler.step free of its
     # per-step found_inf .item() read-back (the unscale / skip-on-inf logic runs inside the fused kernel instead)
@@ -163,7 +160,6 @@ def main():
     scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
     total_samples = torch.zeros((), dtype=torch.int64, device=dev)
     dt_gamma = 1 / 128
-
     field.train()
 
     def train_step(k, count=True):
@@ -182,20 +178,20 @@ def main():
             renderer.update_mean_count()
             renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
 
-    # ---- priming = the reference's first 16 "epoch-0" steps: full-size buffers until a mean sample count exists
+    # priming = the reference's first "epoch-0" steps: full-size buffers until a mean sample count exists
     for k in range(2):
         train_step(k, count=False)
     renderer.update_mean_count()
     renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
-    for k in range(args.warmup):
+    for k in range(warmup):
         train_step(k, count=False)
 
-    nerftex_hip.timer.enabled = True
+    nerftex_hip.timer.enabled = time_grid_kernels
     nerftex_hip.timer.only = {"grid_encode_forward", "grid_encode_backward"}
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         train_step(k)
     torch.cuda.synchronize()
     dp.barrier()
@@ -210,27 +206,56 @@ def main():
         dist.all_reduce(samples, op=dist.ReduceOp.SUM)
     elapsed = float(elapsed.item())
     samples = int(samples.item())
-    op_ms = nerftex_hip.timer.summary()
+    op_ms = nerftex_hip.timer.summary() if time_grid_kernels else {}
+    res = dict(value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
+               mean_count=renderer.mean_count, op_ms=op_ms, use_amp=use_amp, dt_gamma=dt_gamma, n_global=n_global)
+    return res, field, renderer
 
-    # ---- roofline of the dominant kernel (hash-grid gather / scatter), measured live with events on the launch stream
+
+WORKLOADS = {
+    "ffmlp": "configs[2] (1 GPU) / configs[4] (8 GPUs, 65536 rays/step): fox-style scene, hashgrid L=16 F=2 T=2^19, FFMLP 2x64 + 3x64 on MFMA, "
+             "HIP gridencoder+raymarching+shencoder+ffmlp, 800x800 random-pose pixels",
+    "torch": "configs[1]: fox-style scene, hashgrid L=16 F=2 T=2^19, nn.Linear 2x64 + 3x64 MLPs on PyTorch-ROCm, "
+             "HIP gridencoder+raymarching+shencoder, 800x800 random-pose pixels",
+}
+
+
+# ----------------------------------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    from ngp_harness import dp, scene
+
+    rank, world, local = dp.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    sc = scene.Scene(bound=args.bound, seed=0)
+    grid, thresh, bits = sc.bitfield()
+    res, field, renderer = measure_training(args, args.mlp, args.rays, args.steps, args.warmup, dev, rank, world, sc, grid, bits, True)
+    use_amp, dt_gamma = res["use_amp"], res["dt_gamma"]
+
+    # ---- roofline of the dominant hash-grid kernel, measured live with event pairs on the launch stream
     M_launch = renderer.mean_count + 128 - renderer.mean_count % 128  # rows per launch (padded like raymarching.py:198-201)
     s_bytes = 2 if use_amp else 4
     bytes_fwd = 12 + 8 * 16 * 2 * s_bytes + 16 * 2 * s_bytes  # 588 B (fp16) / 1164 B (fp32) per point
     bytes_bwd = 12 + 16 * 2 * s_bytes + 8 * 16 * 2 * s_bytes
     kern = {}
     for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
-        if name in op_ms and op_ms[name]:
-            ms = float(np.mean(op_ms[name]))
+        if res["op_ms"].get(name):
+            ms = float(np.mean(res["op_ms"][name]))
             kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp}
     dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
     roofline = None
     if dominant:
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dominant),
             "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
             "other": {k: v for k, v in kern.items() if k != dominant},
-            "note": "event pairs include the launch gap; table (24-48 MiB) is Infinity-Cache resident, see DESIGN.md",
+            "note": "op = all launches of the C-ABI call (backward: transpose+count+scan+fill+sum); event pairs include launch gaps; the 24 MiB "
+                    "table is Infinity-Cache resident, gathers are bounded by the divergent-request rate, see DESIGN.md 4/6",
         }
 
     # ---- rendered Mpix/s: one 800x800 frame through the reference's inference loop (nerf/renderer.py:436-487)
@@ -254,12 +279,20 @@ def main():
         field.train()
     dp.barrier()
 
+    # ---- the other single-GPU configuration of BASELINE.json, short run, for the record (rank 0, N = 1 only)
+    other = None
+    if rank == 0 and world == 1 and not args.no_other:
+        o_mlp, o_rays = ("torch", 4096) if args.mlp == "ffmlp" else ("ffmlp", 8192)
+        r2, _, _ = measure_training(args, o_mlp, o_rays, 16, 16, dev, rank, world, sc, grid, bits, False)
+        other = {"workload": WORKLOADS[o_mlp], "rays_per_batch": o_rays, "value": r2["value"], "unit": "ray-samples/s", "ms_per_step": r2["ms_per_step"],
+                 "steps": 16}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        layers = lambda net: [l.weight.detach().float().cpu().numpy() for l in net]  # noqa: E731
         if args.mlp == "torch":
+            layers = lambda net: [l.weight.detach().float().cpu().numpy() for l in net]  # noqa: E731
             sw, cw = layers(field.sigma_net), layers(field.color_net)
-        else:  # same shapes, values irrelevant for timing
+        else:  # same layer shapes as the nn.Linear variant; values are irrelevant for timing
             sw = [np.zeros((64, 32), np.float32), np.zeros((16, 64), np.float32)]
             cw = [np.zeros((64, 31), np.float32), np.zeros((64, 64), np.float32), np.zeros((3, 64), np.float32)]
         state = dict(emb=field.encoder.embeddings.detach().float().cpu().numpy(), offsets=field.encoder.offsets.cpu().numpy(),
@@ -269,28 +302,28 @@ def main():
     if rank == 0:
         out = {
             "metric": "ray-samples/s (train)",
-            "value": samples / elapsed,
+            "value": res["value"],
             "unit": "ray-samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16" if use_amp else "f32",
             "data": "synthetic",
             "config": {
-                "workload": ("configs[1]" if args.mlp == "torch" else "configs[2]") + ": fox-style scene, hashgrid L=16 F=2 T=2^19 + "
-                            + ("nn.Linear 2x64/3x64 MLPs (PyTorch-ROCm)" if args.mlp == "torch" else "FFMLP 2x64/3x64 on MFMA")
-                            + ", HIP gridencoder+raymarching+shencoder, 800x800 random-pose pixels",
-                "rays_per_batch_per_gpu": args.rays, "global_rays": n_global, "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
-                "samples_per_step_per_gpu": samples / args.steps / world, "mean_count": renderer.mean_count, "parallelism": f"dp{world}",
-                "optimizer": "Adam(eps=1e-15)+GradScaler" if use_amp else "Adam(eps=1e-15)",
+                "workload": WORKLOADS[args.mlp],
+                "rays_per_batch_per_gpu": args.rays, "global_rays": res["n_global"], "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
+                "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
+                "optimizer": "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)",
+                "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
             "rendered": mpix,
+            "other_config": other,
         }
         print(json.dumps(out))
 

@@ -457,49 +457,95 @@ __global__ __launch_bounds__(256) void march_expand_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }  // v_exp_f32 path, as the reference's __expf
 
-__global__ __launch_bounds__(kRayBlock) void composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                                                                     const float* __restrict__ deltas, const int* __restrict__ rays,
-                                                                     uint32_t M, uint32_t N, float* __restrict__ weights_sum,
-                                                                     float* __restrict__ depth, float* __restrict__ image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+// wave64 inclusive scans over lanes (sum / product)
+__device__ __forceinline__ float wave_scan_add(float v) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float o = __shfl_up(v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float o = __shfl_up(v, off, kWave);
+        if (lane >= off) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// The reference walks each ray's samples serially in one thread (raymarching.cu:739-767 / :843-880): 4096 threads, each
+// striding through its own segment.  Here ONE WAVE takes a ray, its 64 lanes take 64 consecutive samples (coalesced
+// loads), transmittance T_i = prod_{j<i}(1 - alpha_j) comes from a multiplicative wave scan carried across chunks, the
+// running sums the backward needs from additive scans.  Same quantities, tree instead of serial summation order.
+constexpr uint32_t kCompBlock = 256;
+
+__global__ __launch_bounds__(kCompBlock) void composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                        const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                        uint32_t M, uint32_t N, float* __restrict__ weights_sum,
+                                                                        float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * (kCompBlock / kWave) + threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
                    num_steps = (uint32_t)rays[3 * (size_t)n + 2];
     if (num_steps == 0 || offset + num_steps >= M) {
-        weights_sum[index] = 0;
-        depth[index] = 0;
-        image[3 * (size_t)index] = 0; image[3 * (size_t)index + 1] = 0; image[3 * (size_t)index + 2] = 0;
+        if (lane == 0) {
+            weights_sum[index] = 0;
+            depth[index] = 0;
+            image[3 * (size_t)index] = 0; image[3 * (size_t)index + 1] = 0; image[3 * (size_t)index + 2] = 0;
+        }
         return;
     }
-    const float* sg = sigmas + offset;
-    const float* c = rgbs + (size_t)offset * 3;
-    const float* dl = deltas + (size_t)offset * 2;
-    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const float alpha = 1.0f - fast_exp(-sg[0] * dl[0]);
-        const float weight = alpha * T;
-        r = fmaf(weight, c[0], r);
-        g = fmaf(weight, c[1], g);
-        b = fmaf(weight, c[2], b);
-        t += dl[1];
-        d = fmaf(weight, t, d);
-        ws += weight;
-        T *= 1.0f - alpha;
-        sg++; c += 3; dl += 2;
+    float T_carry = 1.0f, t_carry = 0.0f;
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    for (uint32_t c0 = 0; c0 < num_steps; c0 += kWave) {
+        const uint32_t k = c0 + lane;
+        const bool on = k < num_steps;
+        const size_t i = (size_t)offset + k;
+        const float sg = on ? sigmas[i] : 0.0f;
+        const float d0 = on ? deltas[2 * i] : 0.0f, d1 = on ? deltas[2 * i + 1] : 0.0f;
+        const float alpha = 1.0f - fast_exp(-sg * d0);  // 0 for idle lanes
+        const float incl = wave_scan_mul(1.0f - alpha);
+        float excl = __shfl_up(incl, 1, kWave);
+        if (lane == 0) excl = 1.0f;
+        const float weight = alpha * (T_carry * excl);
+        const float t = t_carry + wave_scan_add(d1);
+        if (on) {
+            r = fmaf(weight, rgbs[3 * i], r);
+            g = fmaf(weight, rgbs[3 * i + 1], g);
+            b = fmaf(weight, rgbs[3 * i + 2], b);
+            d = fmaf(weight, t, d);
+            ws += weight;
+        }
+        T_carry *= __shfl(incl, kWave - 1, kWave);
+        t_carry = __shfl(t, kWave - 1, kWave);
     }
-    weights_sum[index] = ws;
-    depth[index] = d;
-    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    r = wave_sum_f(r); g = wave_sum_f(g); b = wave_sum_f(b); ws = wave_sum_f(ws); d = wave_sum_f(d);
+    if (lane == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+        image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    }
 }
 
-__global__ __launch_bounds__(kRayBlock) void composite_train_bwd_kernel(const float* __restrict__ grad_weights_sum,
-                                                                     const float* __restrict__ grad_image,
-                                                                     const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                                                                     const float* __restrict__ deltas, const int* __restrict__ rays,
-                                                                     const float* __restrict__ weights_sum, const float* __restrict__ image,
-                                                                     uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
-                                                                     float* __restrict__ grad_rgbs) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kCompBlock) void composite_train_bwd_kernel(const float* __restrict__ grad_weights_sum,
+                                                                        const float* __restrict__ grad_image,
+                                                                        const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                        const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                        const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                        uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
+                                                                        float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * (kCompBlock / kWave) + threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
                    num_steps = (uint32_t)rays[3 * (size_t)n + 2];
@@ -508,27 +554,37 @@ __global__ __launch_bounds__(kRayBlock) void composite_train_bwd_kernel(const fl
     const float gi0 = grad_image[3 * (size_t)index], gi1 = grad_image[3 * (size_t)index + 1], gi2 = grad_image[3 * (size_t)index + 2];
     const float r_final = image[3 * (size_t)index], g_final = image[3 * (size_t)index + 1], b_final = image[3 * (size_t)index + 2];
     const float ws_final = weights_sum[index];
-    const float* sg = sigmas + offset;
-    const float* c = rgbs + (size_t)offset * 3;
-    const float* dl = deltas + (size_t)offset * 2;
-    float* gs = grad_sigmas + offset;
-    float* gc = grad_rgbs + (size_t)offset * 3;
-    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const float alpha = 1.0f - fast_exp(-sg[0] * dl[0]);
-        const float weight = alpha * T;
-        r = fmaf(weight, c[0], r);
-        g = fmaf(weight, c[1], g);
-        b = fmaf(weight, c[2], b);
-        ws += weight;
-        T *= 1.0f - alpha;
-        gc[0] = gi0 * weight; gc[1] = gi1 * weight; gc[2] = gi2 * weight;
-        float acc = gi0 * fmaf(T, c[0], -(r_final - r));
-        acc = fmaf(gi1, fmaf(T, c[1], -(g_final - g)), acc);
-        acc = fmaf(gi2, fmaf(T, c[2], -(b_final - b)), acc);
-        acc = fmaf(gws, T - (ws_final - ws), acc);
-        gs[0] = dl[0] * acc;
-        sg++; c += 3; dl += 2; gs++; gc += 3;
+    float T_carry = 1.0f, r_c = 0, g_c = 0, b_c = 0, ws_c = 0;
+    for (uint32_t c0 = 0; c0 < num_steps; c0 += kWave) {
+        const uint32_t k = c0 + lane;
+        const bool on = k < num_steps;
+        const size_t i = (size_t)offset + k;
+        const float sg = on ? sigmas[i] : 0.0f;
+        const float d0 = on ? deltas[2 * i] : 0.0f;
+        const float c0r = on ? rgbs[3 * i] : 0.0f, c1g = on ? rgbs[3 * i + 1] : 0.0f, c2b = on ? rgbs[3 * i + 2] : 0.0f;
+        const float alpha = 1.0f - fast_exp(-sg * d0);
+        const float incl = wave_scan_mul(1.0f - alpha);
+        float excl = __shfl_up(incl, 1, kWave);
+        if (lane == 0) excl = 1.0f;
+        const float weight = alpha * (T_carry * excl);
+        const float T = T_carry * incl;  // transmittance AFTER this sample, as in the reference's post-update T (:855-868)
+        const float r = r_c + wave_scan_add(weight * c0r);
+        const float g = g_c + wave_scan_add(weight * c1g);
+        const float b = b_c + wave_scan_add(weight * c2b);
+        const float ws = ws_c + wave_scan_add(weight);
+        if (on) {
+            grad_rgbs[3 * i] = gi0 * weight;
+            grad_rgbs[3 * i + 1] = gi1 * weight;
+            grad_rgbs[3 * i + 2] = gi2 * weight;
+            float acc = gi0 * fmaf(T, c0r, -(r_final - r));
+            acc = fmaf(gi1, fmaf(T, c1g, -(g_final - g)), acc);
+            acc = fmaf(gi2, fmaf(T, c2b, -(b_final - b)), acc);
+            acc = fmaf(gws, T - (ws_final - ws), acc);
+            grad_sigmas[i] = d0 * acc;
+        }
+        T_carry *= __shfl(incl, kWave - 1, kWave);
+        r_c = __shfl(r, kWave - 1, kWave); g_c = __shfl(g, kWave - 1, kWave); b_c = __shfl(b, kWave - 1, kWave);
+        ws_c = __shfl(ws, kWave - 1, kWave);
     }
 }
 
@@ -761,7 +817,7 @@ extern "C" int nerftex_composite_rays_train_forward(const float* sigmas, const f
                                                     void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(composite_train_fwd_kernel, ray_grid_for(N), dim3(kRayBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
+    hipLaunchKernelGGL(composite_train_fwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
                        weights_sum, depth, image);
     return check_launch("composite_rays_train_forward");
 }
@@ -772,7 +828,7 @@ extern "C" int nerftex_composite_rays_train_backward(const float* grad_weights_s
                                                      float* grad_sigmas, float* grad_rgbs, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(composite_train_bwd_kernel, ray_grid_for(N), dim3(kRayBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
+    hipLaunchKernelGGL(composite_train_bwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
                        sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
     return check_launch("composite_rays_train_backward");
 }
