@@ -36,6 +36,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes), see profiles/: filled in per round
 # for the default workload; None = not collected for this kernel version.
 TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": None, "grid_encode_backward": None}
+# device kernels behind each hash-grid C-ABI call (whichever of them ran)
+GRID_KERNELS = {
+    "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
+    "grid_encode_backward": ("grad_to_level_major_kernel", "bin_count_kernel", "scan_tiles_kernel", "scan_global_kernel", "bin_fill_kernel",
+                             "sum_tiles_kernel", "grid_backward_owner_kernel", "grid_backward_kernel", "grid_input_backward_kernel"),
+}
 
 
 def parse():
@@ -46,6 +52,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=8192, help="rays per batch PER GPU (weak scaling; 8 GPUs x 8192 = configs[4]'s 65536)")
     ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other single-GPU configuration")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
     ap.add_argument("--bound", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,8 +193,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     for k in range(warmup):
         train_step(k, count=False)
 
-    nerftex_hip.timer.enabled = time_grid_kernels
-    nerftex_hip.timer.only = {"grid_encode_forward", "grid_encode_backward"}
+    if time_grid_kernels:
+        nerftex_hip.kernel_profile(2, reset=True)  # hipEvent pairs around the hash-grid kernels only (8 of ~90 launches per step)
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -196,7 +203,17 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     torch.cuda.synchronize()
     dp.barrier()
     t1 = time.perf_counter()
-    nerftex_hip.timer.enabled = False
+    kernel_us, all_kernel_us = {}, {}
+    if time_grid_kernels:
+        nerftex_hip.kernel_profile(0)
+        kernel_us = nerftex_hip.kernel_profile()
+        # outside the timed region: 8 more steps with every library kernel bracketed, for the per-kernel table
+        nerftex_hip.kernel_profile(1, reset=True)
+        for k in range(8):
+            train_step(k, count=False)
+        nerftex_hip.kernel_profile(0)
+        all_kernel_us = nerftex_hip.kernel_profile()
+        nerftex_hip.kernel_profile(reset=True)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     samples = total_samples.clone()
     if world > 1:
@@ -206,9 +223,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         dist.all_reduce(samples, op=dist.ReduceOp.SUM)
     elapsed = float(elapsed.item())
     samples = int(samples.item())
-    op_ms = nerftex_hip.timer.summary() if time_grid_kernels else {}
     res = dict(value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
-               mean_count=renderer.mean_count, op_ms=op_ms, use_amp=use_amp, dt_gamma=dt_gamma, n_global=n_global)
+               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
 
 
@@ -233,19 +249,24 @@ def main():
 
     sc = scene.Scene(bound=args.bound, seed=0)
     grid, thresh, bits = sc.bitfield()
-    res, field, renderer = measure_training(args, args.mlp, args.rays, args.steps, args.warmup, dev, rank, world, sc, grid, bits, True)
+    res, field, renderer = measure_training(args, args.mlp, args.rays, args.steps, args.warmup, dev, rank, world, sc, grid, bits,
+                                            not args.no_kernel_timing)
     use_amp, dt_gamma = res["use_amp"], res["dt_gamma"]
 
-    # ---- roofline of the dominant hash-grid kernel, measured live with event pairs on the launch stream
+    # ---- roofline of the dominant hash-grid op, from the library's own per-kernel hipEvent pairs over the timed region
     M_launch = renderer.mean_count + 128 - renderer.mean_count % 128  # rows per launch (padded like raymarching.py:198-201)
     s_bytes = 2 if use_amp else 4
     bytes_fwd = 12 + 8 * 16 * 2 * s_bytes + 16 * 2 * s_bytes  # 588 B (fp16) / 1164 B (fp32) per point
     bytes_bwd = 12 + 16 * 2 * s_bytes + 8 * 16 * 2 * s_bytes
+    prof = res["kernel_us"]
     kern = {}
     for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
-        if res["op_ms"].get(name):
-            ms = float(np.mean(res["op_ms"][name]))
-            kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp}
+        parts = {k: prof[k] for k in GRID_KERNELS[name] if k in prof}
+        if parts:
+            calls = max(v["calls"] for v in parts.values())
+            ms = sum(v["total_us"] for v in parts.values()) / calls * 1e-3
+            kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
+                          "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in parts.items()}}
     dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
     roofline = None
     if dominant:
@@ -253,9 +274,12 @@ def main():
             "bound": "hbm", "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dominant),
             "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
+            "kernels_avg_us": kern[dominant]["kernels_avg_us"],
             "other": {k: v for k, v in kern.items() if k != dominant},
-            "note": "op = all launches of the C-ABI call (backward: transpose+count+scan+fill+sum); event pairs include launch gaps; the 24 MiB "
-                    "table is Infinity-Cache resident, gathers are bounded by the divergent-request rate, see DESIGN.md 4/6",
+            "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(res["all_kernel_us"].items(), key=lambda kv: -kv[1]["total_us"])},
+            "note": "avg_launch_ms = sum of the device durations of the kernels one C-ABI call launches (hipEvent pairs recorded by the library on the "
+                    "launch stream, names = rocprofv3 kernel names; bin_count/bin_fill are bin_kernel<..,false/true>); the 24 MiB table is "
+                    "Infinity-Cache resident and the gathers are bounded by the divergent-request rate, see DESIGN.md 4/6",
         }
 
     # ---- rendered Mpix/s: one 800x800 frame through the reference's inference loop (nerf/renderer.py:436-487)

@@ -45,6 +45,14 @@ const char* nerftex_last_error(void);
 /* library / build identification: "nerftex_hip <ver> gfx950" */
 const char* nerftex_version(void);
 
+/* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every kernel the
+ * library launches).  on = 0 off (default), 1 every kernel, 2 hash-grid kernels only; bench.py uses 2 over its timed
+ * region to report the roofline kernel's average launch duration.  report() synchronises the device and writes a JSON object
+ * {"kernel": {"calls": n, "avg_us": x, "total_us": y}, ...} into buf (truncated to n bytes, NUL-terminated).      */
+int nerftex_profile_enable(int on);
+int nerftex_profile_reset(void);
+int nerftex_profile_report(char* buf, size_t n);
+
 /* ------------------------------------------------------------------------- *
  * gridencoder  (reference: gridencoder/src/bindings.cpp:5-8,
  *               gridencoder/src/gridencoder.h:12-13, gridencoder.cu:419-474)

@@ -39,6 +39,20 @@ inline int check_launch(const char* what) {
 template <typename T>
 constexpr T div_up(T a, T b) { return (a + b - 1) / b; }
 
+// ---- optional per-kernel timing (runtime.hip): { KernelTimer t("name", stream); hipLaunchKernelGGL(...); } --------------
+extern int g_profile_mode;                   // 0 off, 1 every kernel, 2 hash-grid kernels only
+constexpr int kTimeAny = 1, kTimeGrid = 2;  // timer groups
+void profile_begin(const char* name, hipStream_t st, int* slot);
+void profile_end(hipStream_t st, int slot);
+struct KernelTimer {
+    hipStream_t st;
+    int slot = -1;
+    KernelTimer(const char* name, hipStream_t s, int group = kTimeAny) : st(s) {
+        if (g_profile_mode == 1 || (g_profile_mode == 2 && group == kTimeGrid)) profile_begin(name, s, &slot);
+    }
+    ~KernelTimer() { if (slot >= 0) profile_end(st, slot); }
+};
+
 // ---- device-side types --------------------------------------------------------------------------
 using half_t = _Float16;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));

@@ -521,8 +521,11 @@ int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t
     auto kernel = ffmlp_forward_kernel<H, INF>;
     rc = set_lds(kernel, lds);
     if (rc != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(kernel, dim3(persistent_grid(B, lds)), dim3(kBlockThreads), lds, st, (const half_t*)inputs, (const half_t*)weights,
-                       (half_t*)fwd, (half_t*)outputs, B, IN, NL, act, out_act);
+    {
+        KernelTimer kt(INF ? "ffmlp_inference_kernel" : "ffmlp_forward_kernel", st);
+        hipLaunchKernelGGL(kernel, dim3(persistent_grid(B, lds)), dim3(kBlockThreads), lds, st, (const half_t*)inputs, (const half_t*)weights,
+                           (half_t*)fwd, (half_t*)outputs, B, IN, NL, act, out_act);
+    }
     return check_launch(INF ? "ffmlp_inference" : "ffmlp_forward");
 }
 
@@ -547,8 +550,11 @@ int launch_dgrad(const void* grad, const void* weights, const void* fwd, void* b
     auto kernel = ffmlp_dgrad_kernel<H>;
     rc = set_lds(kernel, lds);
     if (rc != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(kernel, dim3(persistent_grid(B, lds)), dim3(kBlockThreads), lds, st, (const half_t*)grad, (const half_t*)weights,
-                       (const half_t*)fwd, (half_t*)bb, (half_t*)grad_inputs, B, IN, NL, act);
+    {
+        KernelTimer kt("ffmlp_dgrad_kernel", st);
+        hipLaunchKernelGGL(kernel, dim3(persistent_grid(B, lds)), dim3(kBlockThreads), lds, st, (const half_t*)grad, (const half_t*)weights,
+                           (const half_t*)fwd, (half_t*)bb, (half_t*)grad_inputs, B, IN, NL, act);
+    }
     return check_launch("ffmlp_backward(dgrad)");
 }
 
@@ -625,11 +631,17 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     float* partials = static_cast<float*>(workspace(kWsMlp, sizeof(float) * (size_t)n_parts * n_params));
     if (!partials) return NERFTEX_ERR_HIP;
     const size_t red_bytes = sizeof(float) * 4 * 16 * 256;  // 64 KiB
-    hipLaunchKernelGGL(ffmlp_wgrad_kernel, dim3(n_parts, NL + 1), dim3(kBlockThreads), red_bytes, st, args, B, partials, n_params);
+    {
+        KernelTimer kt("ffmlp_wgrad_kernel", st);
+        hipLaunchKernelGGL(ffmlp_wgrad_kernel, dim3(n_parts, NL + 1), dim3(kBlockThreads), red_bytes, st, args, B, partials, n_params);
+    }
     rc = check_launch("ffmlp_backward(wgrad)");
     if (rc != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, 64u)), dim3(kBlockThreads), 0, st, partials, n_parts,
-                       n_params, static_cast<half_t*>(grad_weights));
+    {
+        KernelTimer kt("ffmlp_wgrad_reduce_kernel", st);
+        hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, 64u)), dim3(kBlockThreads), 0, st, partials, n_parts,
+                           n_params, static_cast<half_t*>(grad_weights));
+    }
     return check_launch("ffmlp_backward(reduce)");
 }
 

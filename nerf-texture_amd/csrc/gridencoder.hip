@@ -767,20 +767,29 @@ int launch_forward(const float* inputs, const T* emb, const int* offsets, T* out
             if (!lbc) return NERFTEX_ERR_HIP;
         }
         const uint32_t nchunks = div_up(B, 256u);
-        hipLaunchKernelGGL((grid_forward_level_kernel<T, D, C>), dim3(kXcds * nchunks * div_up(L, kXcds)), dim3(256), 0, st, inputs, emb, offsets,
-                           lbc, B, L, lc, calc_grad, dy_dx, gridtype, align, nchunks);
+        {
+            KernelTimer kt("grid_forward_level_kernel", st, kTimeGrid);
+            hipLaunchKernelGGL((grid_forward_level_kernel<T, D, C>), dim3(kXcds * nchunks * div_up(L, kXcds)), dim3(256), 0, st, inputs, emb, offsets,
+                               lbc, B, L, lc, calc_grad, dy_dx, gridtype, align, nchunks);
+        }
         int rc = check_launch("grid_encode_forward");
         if (rc != NERFTEX_OK || layout != NERFTEX_LAYOUT_BLC) return rc;
-        hipLaunchKernelGGL((level_major_to_rows_kernel<T, C>), dim3(nchunks), dim3(256), 0, st, lbc, outputs, B, L);
+        {
+            KernelTimer kt("level_major_to_rows_kernel", st, kTimeGrid);
+            hipLaunchKernelGGL((level_major_to_rows_kernel<T, C>), dim3(nchunks), dim3(256), 0, st, lbc, outputs, B, L);
+        }
         return check_launch("grid_encode_forward(rows)");
     }
     const dim3 grid(div_up(B, 256u)), block(256);
-    if (layout == NERFTEX_LAYOUT_BLC)
-        hipLaunchKernelGGL((grid_forward_kernel<T, D, C, true>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, lc,
-                           calc_grad, dy_dx, gridtype, align);
-    else
-        hipLaunchKernelGGL((grid_forward_kernel<T, D, C, false>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, lc,
-                           calc_grad, dy_dx, gridtype, align);
+    {
+        KernelTimer kt("grid_forward_kernel", st, kTimeGrid);
+        if (layout == NERFTEX_LAYOUT_BLC)
+            hipLaunchKernelGGL((grid_forward_kernel<T, D, C, true>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, lc,
+                               calc_grad, dy_dx, gridtype, align);
+        else
+            hipLaunchKernelGGL((grid_forward_kernel<T, D, C, false>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, lc,
+                               calc_grad, dy_dx, gridtype, align);
+    }
     return check_launch("grid_encode_forward");
 }
 
@@ -801,7 +810,10 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
             if (blc) {
                 T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
                 if (!tmp) return NERFTEX_ERR_HIP;
-                hipLaunchKernelGGL((grad_to_level_major_kernel<T, C>), dim3(div_up(B * L, 256u)), dim3(256), 0, st, grad, tmp, B, L);
+                {
+                    KernelTimer kt("grad_to_level_major_kernel", st, kTimeGrid);
+                    hipLaunchKernelGGL((grad_to_level_major_kernel<T, C>), dim3(div_up(B * L, 256u)), dim3(256), 0, st, grad, tmp, B, L);
+                }
                 rc = check_launch("grid_encode_backward(transpose)");
                 if (rc != NERFTEX_OK) return rc;
                 g = tmp;
@@ -818,29 +830,38 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
             const uint32_t cus = (uint32_t)device_cus();
             const char* ip = getenv("NERFTEX_GRID_BWD_ITEMS");
             const uint32_t items_per_level = ip ? (uint32_t)atoi(ip) : div_up(6u * cus, L);
-            hipLaunchKernelGGL(kernel, dim3(cus), dim3(kOwnerThreads), kOwnerLdsBytes, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align,
-                               items_per_level ? items_per_level : 1u);
+            {
+                KernelTimer kt("kernel", st, kTimeGrid);
+                hipLaunchKernelGGL(kernel, dim3(cus), dim3(kOwnerThreads), kOwnerLdsBytes, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align,
+                                   items_per_level ? items_per_level : 1u);
+            }
             rc = check_launch("grid_encode_backward(owner)");
             if (rc != NERFTEX_OK) return rc;
         }
     }
 table_done:
     if (!owner) {  // per-sample atomics with wave64 run compression
-        if (blc)
-            hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
-                               gridtype, align, nchunks);
-        else
-            hipLaunchKernelGGL((grid_backward_kernel<T, D, C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
-                               gridtype, align, nchunks);
+        {
+            KernelTimer kt("grid_backward_kernel", st, kTimeGrid);
+            if (blc)
+                hipLaunchKernelGGL((grid_backward_kernel<T, D, C, true>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
+                                   gridtype, align, nchunks);
+            else
+                hipLaunchKernelGGL((grid_backward_kernel<T, D, C, false>), grid, block, 0, st, grad, inputs, offsets, grad_emb, B, L, lc,
+                                   gridtype, align, nchunks);
+        }
         rc = check_launch("grid_encode_backward");
         if (rc != NERFTEX_OK) return rc;
     }
     if (calc_grad) {
         const dim3 g2(div_up(B * (uint32_t)D, 256u));
-        if (blc)
-            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, true>), g2, block, 0, st, grad, dy_dx, grad_inputs, B, L);
-        else
-            hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, false>), g2, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+        {
+            KernelTimer kt("grid_input_backward_kernel", st, kTimeGrid);
+            if (blc)
+                hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, true>), g2, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+            else
+                hipLaunchKernelGGL((grid_input_backward_kernel<T, D, C, false>), g2, block, 0, st, grad, dy_dx, grad_inputs, B, L);
+        }
         rc = check_launch("grid_encode_backward(inputs)");
     }
     return rc;

@@ -34,6 +34,7 @@ constexpr uint32_t kTileBytes = 128 * 1024;  // LDS accumulator tile of K4
 constexpr uint32_t kMaxTilesPerLevel = 64;
 constexpr uint32_t kSliceRecords = 64 * 1024;  // records per K4 work item
 constexpr uint32_t kSumThreads = 1024;
+constexpr uint32_t kSumUnroll = 8;          // record loads in flight per lane in K4
 
 struct LevelTable {
     int32_t offsets[kMaxLevels + 1];
@@ -234,14 +235,15 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(uint32_t* __restrict__ 
 
 // K2b: one workgroup: tile_start = exclusive prefix of tile_count, and the K4 work list (one entry per (tile, slice))
 __global__ __launch_bounds__(1024) void scan_global_kernel(uint32_t L, const LevelTable tab, const uint32_t* __restrict__ tile_count,
-                                                           uint32_t* __restrict__ tile_start, uint32_t* __restrict__ items) {
+                                                           uint32_t* __restrict__ tile_start, uint32_t* __restrict__ items,
+                                                           const uint32_t slice_records) {
     __shared__ uint32_t s_rec[1024], s_itm[1024];
     const uint32_t T = tab.tile_base[L];
     uint32_t rec_carry = 0, itm_carry = 0;
     for (uint32_t g0 = 0; g0 < T; g0 += 1024) {  // Hillis-Steele scan over blocks of 1024 tiles (T is a few hundred)
         const uint32_t g = g0 + threadIdx.x;
         const uint32_t n = g < T ? tile_count[g] : 0u;
-        const uint32_t slices = div_up(n, kSliceRecords);
+        const uint32_t slices = div_up(n, slice_records);
         s_rec[threadIdx.x] = n;
         s_itm[threadIdx.x] = slices;
         __syncthreads();
@@ -299,24 +301,37 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_kernel(const Rec<T>* __
     const uint32_t per = div_up(n, slices);
     const uint32_t lo = item * per, hi = min(n, lo + per);
     const Rec<T>* __restrict__ rec = records + tile_start[g];
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kSumThreads) {
-        const Rec<T> r = rec[i];
-        const uint32_t ra = r.row_a - row0, rb = r.row_b - row0;
-        if constexpr (sizeof(T) == 2) {
-            typedef __attribute__((address_space(3))) half2_t lds_h2;
-            __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)(acc + (size_t)ra * 2), r.va);
-            if (rb < nrows) __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)(acc + (size_t)rb * 2), r.vb);
-            else unsafeAtomicAdd(reinterpret_cast<__half2*>(level_table) + r.row_b, __builtin_bit_cast(__half2, r.vb));  // partner row in another tile
-        } else {
-            float* a = reinterpret_cast<float*>(acc);
-            atomicAdd(a + (size_t)ra * 2, r.va0);
-            atomicAdd(a + (size_t)ra * 2 + 1, r.va1);
-            if (rb < nrows) {
-                atomicAdd(a + (size_t)rb * 2, r.vb0);
-                atomicAdd(a + (size_t)rb * 2 + 1, r.vb1);
+    // The loop is latency-bound unless several record loads are in flight per lane: issue kSumUnroll independent 16/24-B loads, then
+    // retire them (the LDS / stray global atomics would otherwise fence every load behind the previous record's adds).
+    for (uint32_t base = lo; base < hi; base += kSumThreads * kSumUnroll) {
+        Rec<T> r[kSumUnroll];
+        bool live[kSumUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kSumUnroll; u++) {
+            const uint32_t i = base + u * kSumThreads + threadIdx.x;
+            live[u] = i < hi;
+            r[u] = rec[live[u] ? i : lo];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kSumUnroll; u++) {
+            if (!live[u]) continue;
+            const uint32_t ra = r[u].row_a - row0, rb = r[u].row_b - row0;
+            if constexpr (sizeof(T) == 2) {
+                typedef __attribute__((address_space(3))) half2_t lds_h2;
+                __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)(acc + (size_t)ra * 2), r[u].va);
+                if (rb < nrows) __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)(acc + (size_t)rb * 2), r[u].vb);
+                else unsafeAtomicAdd(reinterpret_cast<__half2*>(level_table) + r[u].row_b, __builtin_bit_cast(__half2, r[u].vb));  // partner row in another tile
             } else {
-                unsafeAtomicAdd(reinterpret_cast<float*>(level_table) + (size_t)r.row_b * 2, r.vb0);
-                unsafeAtomicAdd(reinterpret_cast<float*>(level_table) + (size_t)r.row_b * 2 + 1, r.vb1);
+                float* a = reinterpret_cast<float*>(acc);
+                atomicAdd(a + (size_t)ra * 2, r[u].va0);
+                atomicAdd(a + (size_t)ra * 2 + 1, r[u].va1);
+                if (rb < nrows) {
+                    atomicAdd(a + (size_t)rb * 2, r[u].vb0);
+                    atomicAdd(a + (size_t)rb * 2 + 1, r[u].vb1);
+                } else {
+                    unsafeAtomicAdd(reinterpret_cast<float*>(level_table) + (size_t)r[u].row_b * 2, r[u].vb0);
+                    unsafeAtomicAdd(reinterpret_cast<float*>(level_table) + (size_t)r[u].row_b * 2 + 1, r[u].vb1);
+                }
             }
         }
     }
@@ -389,7 +404,12 @@ int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offs
     const uint32_t nchunks = div_up(B, kBinThreads);
     const size_t n_counts = (size_t)L * nchunks * kMaxTilesPerLevel;
     const size_t max_records = (size_t)B * L * NP;
-    const uint32_t max_items = tiles + (uint32_t)(max_records / kSliceRecords) + 1;
+    static const uint32_t slice_records = [] {  // records per K4 work item (tuning switch; default kSliceRecords)
+        const char* e = getenv("NERFTEX_GRID_BWD_SLICE");
+        const long v = e ? atol(e) : 0;
+        return v >= 1024 ? (uint32_t)v : kSliceRecords;
+    }();
+    const uint32_t max_items = tiles + (uint32_t)(max_records / slice_records) + 1;
     if (tiles >= 4096 || max_items / (tiles ? tiles : 1) >= 1024) return -1;  // item code fields; caller falls back
     const size_t head_bytes = (sizeof(uint32_t) * (n_counts + 2 * (size_t)tiles + 2 + (size_t)max_items + 2) + 255) / 256 * 256;
     char* base = static_cast<char*>(workspace(kWsGridBins, head_bytes + sizeof(Rec<T>) * max_records));
@@ -402,21 +422,36 @@ int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offs
 
     const dim3 bgrid(nchunks, L), bblock(kBinThreads);
     const bool merge_runs = getenv("NERFTEX_GRID_BWD_NOMERGE") == nullptr;
-    hipLaunchKernelGGL((bin_kernel<T, D, false>), bgrid, bblock, 0, st, grad_lbc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts,
-                       tile_start, records, merge_runs);
+    {
+        KernelTimer kt("bin_count_kernel", st, kTimeGrid);
+        hipLaunchKernelGGL((bin_kernel<T, D, false>), bgrid, bblock, 0, st, grad_lbc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts,
+                           tile_start, records, merge_runs);
+    }
     if ((rc = check_launch("grid_encode_backward(count)")) != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(div_up(tiles, 4u)), dim3(256), 0, st, counts, nchunks, L, tab, tile_count);
+    {
+        KernelTimer kt("scan_tiles_kernel", st, kTimeGrid);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(div_up(tiles, 4u)), dim3(256), 0, st, counts, nchunks, L, tab, tile_count);
+    }
     if ((rc = check_launch("grid_encode_backward(scan)")) != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(scan_global_kernel, dim3(1), dim3(1024), 0, st, L, tab, tile_count, tile_start, items);
+    {
+        KernelTimer kt("scan_global_kernel", st, kTimeGrid);
+        hipLaunchKernelGGL(scan_global_kernel, dim3(1), dim3(1024), 0, st, L, tab, tile_count, tile_start, items, slice_records);
+    }
     if ((rc = check_launch("grid_encode_backward(scan2)")) != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL((bin_kernel<T, D, true>), bgrid, bblock, 0, st, grad_lbc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts,
-                       tile_start, records, merge_runs);
+    {
+        KernelTimer kt("bin_fill_kernel", st, kTimeGrid);
+        hipLaunchKernelGGL((bin_kernel<T, D, true>), bgrid, bblock, 0, st, grad_lbc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts,
+                           tile_start, records, merge_runs);
+    }
     if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
 
     auto kernel = sum_tiles_kernel<T>;
     NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileBytes),
                     "hipFuncSetAttribute");
-    hipLaunchKernelGGL(kernel, dim3(max_items), dim3(kSumThreads), kTileBytes, st, records, tile_count, tile_start, items, L, tab, grad_grid);
+    {
+        KernelTimer kt("sum_tiles_kernel", st, kTimeGrid);
+        hipLaunchKernelGGL(kernel, dim3(max_items), dim3(kSumThreads), kTileBytes, st, records, tile_count, tile_start, items, L, tab, grad_grid);
+    }
     return check_launch("grid_encode_backward(sum)");
 }
 

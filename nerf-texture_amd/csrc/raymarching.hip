@@ -740,17 +740,26 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     uint32_t* ws = reinterpret_cast<uint32_t*>(base);
     float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
-                       C, H, nears, fars, rays, counter, ws, perturb, tlog);
+    {
+        KernelTimer kt("march_count_kernel", st);
+        hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                           C, H, nears, fars, rays, counter, ws, perturb, tlog);
+    }
     int rc = check_launch("march_rays_train(count)");
     if (rc != NERFTEX_OK) return rc;
     if (use_log) {
-        hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
-                           nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog);
+        {
+            KernelTimer kt("march_expand_kernel", st);
+            hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+                               nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog);
+        }
         return check_launch("march_rays_train(expand)");
     }
-    hipLaunchKernelGGL((march_write_kernel<WITH_TS>), dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                       max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb);
+    {
+        KernelTimer kt("march_write_kernel", st);
+        hipLaunchKernelGGL((march_write_kernel<WITH_TS>), dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                           max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb);
+    }
     return check_launch("march_rays_train(write)");
 }
 
@@ -763,35 +772,50 @@ extern "C" int nerftex_near_far_from_aabb(const float* rays_o, const float* rays
                                           float* nears, float* fars, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(near_far_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, aabb, N, min_near, nears, fars);
+    {
+        KernelTimer kt("near_far_kernel", as_stream(stream));
+        hipLaunchKernelGGL(near_far_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, aabb, N, min_near, nears, fars);
+    }
     return check_launch("near_far_from_aabb");
 }
 
 extern "C" int nerftex_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(polar_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, radius, N, coords);
+    {
+        KernelTimer kt("polar_kernel", as_stream(stream));
+        hipLaunchKernelGGL(polar_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, radius, N, coords);
+    }
     return check_launch("polar_from_ray");
 }
 
 extern "C" int nerftex_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(morton3D_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), coords, N, indices);
+    {
+        KernelTimer kt("morton3D_kernel", as_stream(stream));
+        hipLaunchKernelGGL(morton3D_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), coords, N, indices);
+    }
     return check_launch("morton3D");
 }
 
 extern "C" int nerftex_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(morton3D_invert_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), indices, N, coords);
+    {
+        KernelTimer kt("morton3D_invert_kernel", as_stream(stream));
+        hipLaunchKernelGGL(morton3D_invert_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), indices, N, coords);
+    }
     return check_launch("morton3D_invert");
 }
 
 extern "C" int nerftex_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(packbits_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), grid, N, density_thresh, bitfield);
+    {
+        KernelTimer kt("packbits_kernel", as_stream(stream));
+        hipLaunchKernelGGL(packbits_kernel, grid_for(N), dim3(kBlock), 0, as_stream(stream), grid, N, density_thresh, bitfield);
+    }
     return check_launch("packbits");
 }
 
@@ -817,8 +841,11 @@ extern "C" int nerftex_composite_rays_train_forward(const float* sigmas, const f
                                                     void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(composite_train_fwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
-                       weights_sum, depth, image);
+    {
+        KernelTimer kt("composite_train_fwd_kernel", as_stream(stream));
+        hipLaunchKernelGGL(composite_train_fwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
+                           weights_sum, depth, image);
+    }
     return check_launch("composite_rays_train_forward");
 }
 
@@ -828,8 +855,11 @@ extern "C" int nerftex_composite_rays_train_backward(const float* grad_weights_s
                                                      float* grad_sigmas, float* grad_rgbs, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(composite_train_bwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
-                       sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    {
+        KernelTimer kt("composite_train_bwd_kernel", as_stream(stream));
+        hipLaunchKernelGGL(composite_train_bwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
+                           sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    }
     return check_launch("composite_rays_train_backward");
 }
 
@@ -840,8 +870,11 @@ extern "C" int nerftex_march_rays(uint32_t n_alive, uint32_t n_step, const int32
     (void)nears;  // read by the reference kernel but unused (raymarching.cu:940)
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(march_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,
-                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    {
+        KernelTimer kt("march_rays_kernel", as_stream(stream));
+        hipLaunchKernelGGL(march_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,
+                           rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    }
     return check_launch("march_rays");
 }
 
@@ -850,8 +883,11 @@ extern "C" int nerftex_composite_rays(uint32_t n_alive, uint32_t n_step, const i
                                       float* image, void* stream) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(composite_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive,
-                       rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    {
+        KernelTimer kt("composite_rays_kernel", as_stream(stream));
+        hipLaunchKernelGGL(composite_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive,
+                           rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    }
     return check_launch("composite_rays");
 }
 
@@ -863,10 +899,16 @@ extern "C" int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const
     uint32_t* ws = static_cast<uint32_t*>(workspace(kWsCompact, sizeof(uint32_t) * (1 + (size_t)nblocks)));
     if (!ws) return NERFTEX_ERR_HIP;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_t_old, alive_counter, ws);
+    {
+        KernelTimer kt("compact_count_kernel", st);
+        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_t_old, alive_counter, ws);
+    }
     int rc = check_launch("compact_rays(count)");
     if (rc != NERFTEX_OK) return rc;
-    hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_alive, rays_alive_old, rays_t,
-                       rays_t_old, alive_counter, ws);
+    {
+        KernelTimer kt("compact_write_kernel", st);
+        hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_alive, rays_alive_old, rays_t,
+                           rays_t_old, alive_counter, ws);
+    }
     return check_launch("compact_rays(write)");
 }

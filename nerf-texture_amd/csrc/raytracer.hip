@@ -277,7 +277,10 @@ extern "C" int nerftex_raytracer_trace(const nerftex_raytracer* rt, const float*
         return NERFTEX_ERR_INVALID;
     }
     if (N == 0) return NERFTEX_OK;
-    hipLaunchKernelGGL(raytrace_kernel, dim3(div_up(N, 64u)), dim3(64), 0, as_stream(stream), N, rays_o, rays_d, positions, normals, depth, face_idx,
-                       static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles));
+    {
+        KernelTimer kt("raytrace_kernel", as_stream(stream));
+        hipLaunchKernelGGL(raytrace_kernel, dim3(div_up(N, 64u)), dim3(64), 0, as_stream(stream), N, rays_o, rays_d, positions, normals, depth, face_idx,
+                           static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles));
+    }
     return check_launch("raytracer_trace");
 }

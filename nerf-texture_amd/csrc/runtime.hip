@@ -3,7 +3,10 @@
 #include "workspace.hpp"
 
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
+#include <vector>
 
 namespace nerftex {
 
@@ -58,9 +61,69 @@ void release_workspaces() {
         }
 }
 
+// ---- per-kernel timing ------------------------------------------------------------------------------
+int g_profile_mode = 0;
+namespace {
+struct Span { const char* name; hipEvent_t a, b; };
+std::vector<Span> g_spans;
+std::vector<hipEvent_t> g_free_events;
+std::mutex g_profile_mutex;
+hipEvent_t take_event() {
+    if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void profile_begin(const char* name, hipStream_t st, int* slot) {
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    Span sp{name, take_event(), take_event()};
+    (void)hipEventRecord(sp.a, st);
+    g_spans.push_back(sp);
+    *slot = (int)g_spans.size() - 1;
+}
+void profile_end(hipStream_t st, int slot) {
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    if (slot >= 0 && slot < (int)g_spans.size()) (void)hipEventRecord(g_spans[slot].b, st);
+}
+
 }  // namespace nerftex
 
 extern "C" {
+
+int nerftex_profile_enable(int on) { nerftex::g_profile_mode = on; return NERFTEX_OK; }
+
+int nerftex_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(nerftex::g_profile_mutex);
+    (void)hipDeviceSynchronize();
+    for (auto& sp : nerftex::g_spans) { nerftex::g_free_events.push_back(sp.a); nerftex::g_free_events.push_back(sp.b); }
+    nerftex::g_spans.clear();
+    return NERFTEX_OK;
+}
+
+int nerftex_profile_report(char* buf, size_t n) {
+    if (!buf || n == 0) return NERFTEX_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(nerftex::g_profile_mutex);
+    (void)hipDeviceSynchronize();
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto& sp : nerftex::g_spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { auto& a = agg[sp.name]; a.first++; a.second += ms * 1e3; }
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\"%s\": {\"calls\": %ld, \"avg_us\": %.3f, \"total_us\": %.3f}", first ? "" : ", ", kv.first.c_str(), kv.second.first,
+                 kv.second.second / (double)kv.second.first, kv.second.second);
+        out += line;
+        first = false;
+    }
+    out += "}";
+    snprintf(buf, n, "%s", out.c_str());
+    return NERFTEX_OK;
+}
 
 const char* nerftex_last_error(void) { return nerftex::g_err; }
 

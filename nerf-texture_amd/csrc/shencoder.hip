@@ -183,8 +183,11 @@ __global__ __launch_bounds__(256) void sh_backward_kernel(const float* __restric
 template <int DEG>
 int launch(const float* in, float* out, uint32_t B, uint32_t D, bool grad, float* dy_dx, hipStream_t st) {
     const dim3 grid(div_up(B, 256u)), block(256);
-    if (grad) hipLaunchKernelGGL((sh_forward_kernel<DEG, true>), grid, block, 0, st, in, out, B, D, dy_dx);
-    else hipLaunchKernelGGL((sh_forward_kernel<DEG, false>), grid, block, 0, st, in, out, B, D, dy_dx);
+    {
+        KernelTimer kt("sh_forward_kernel", st);
+        if (grad) hipLaunchKernelGGL((sh_forward_kernel<DEG, true>), grid, block, 0, st, in, out, B, D, dy_dx);
+        else hipLaunchKernelGGL((sh_forward_kernel<DEG, false>), grid, block, 0, st, in, out, B, D, dy_dx);
+    }
     return check_launch("sh_encode_forward");
 }
 
@@ -228,6 +231,9 @@ extern "C" int nerftex_sh_encode_backward(const float* grad, const float* inputs
     }
     if (B == 0) return NERFTEX_OK;
     const dim3 grid(div_up(B * D, 256u)), block(256);
-    hipLaunchKernelGGL(sh_backward_kernel, grid, block, 0, as_stream(stream), grad, B, D, C * C, dy_dx, grad_inputs);
+    {
+        KernelTimer kt("sh_backward_kernel", as_stream(stream));
+        hipLaunchKernelGGL(sh_backward_kernel, grid, block, 0, as_stream(stream), grad, B, D, C * C, dy_dx, grad_inputs);
+    }
     return check_launch("sh_encode_backward");
 }

@@ -23,6 +23,9 @@ _u32, _f32, _i, _vp, _sz = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_size_
 
 # name -> argument ctypes, in the order of include/nerftex_hip.h
 _SIGNATURES = {
+    "nerftex_profile_enable": [_i],
+    "nerftex_profile_reset": [],
+    "nerftex_profile_report": [C.c_char_p, _sz],
     "nerftex_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _u32, _i, _i, _i, _vp],
     "nerftex_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _vp],
     "nerftex_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _i, _vp, _vp],
@@ -134,3 +137,18 @@ class _Timer:
 
 
 timer = _Timer()
+
+
+def kernel_profile(enable=None, reset=False):
+    """Per-kernel device timing of the library itself (hipEvent pairs on the launch stream).  kernel_profile(True) starts,
+    kernel_profile() returns {"kernel": {"calls", "avg_us", "total_us"}} so far, kernel_profile(False) stops."""
+    import json
+
+    if reset:
+        check(lib.nerftex_profile_reset())
+    if enable is not None:
+        check(lib.nerftex_profile_enable(int(enable)))  # 0 off, 1 / True every kernel, 2 hash-grid kernels only
+        return None
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.nerftex_profile_report(buf, len(buf)))
+    return json.loads(buf.value.decode() or "{}")

@@ -38,9 +38,14 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--ops", default="grid_fwd,grid_bwd,sh,ffmlp,march,composite")
     ap.add_argument("--random-points", action="store_true")
+    ap.add_argument("--kernels", action="store_true", help="also report the library's per-kernel hipEvent averages")
     args = ap.parse_args()
     ops = set(args.ops.split(","))
     dev = torch.device("cuda:0")
+    if args.kernels:
+        import nerftex_hip
+
+        nerftex_hip.kernel_profile(1, reset=True)
 
     import raymarching
     from nerftex_hip import F16, F32, LAYOUT_BLC, check, lib, ptr, stream
@@ -122,6 +127,9 @@ def main():
         img = torch.empty(args.rays, 3, device=dev)
         res["composite_fwd"] = {"ms": timeit(lambda: check(lib.nerftex_composite_rays_train_forward(ptr(sig), ptr(rgb), ptr(deltas), ptr(rays), M, args.rays, ptr(ws),
                                                                                                      ptr(dep), ptr(img), stream())))}
+    if args.kernels:
+        nerftex_hip.kernel_profile(0)
+        res["kernels_avg_us"] = {k: round(v["avg_us"], 2) for k, v in nerftex_hip.kernel_profile().items()}
     print(json.dumps(res, indent=1))
 
 
