@@ -39,6 +39,18 @@ inline int check_launch(const char* what) {
 template <typename T>
 constexpr T div_up(T a, T b) { return (a + b - 1) / b; }
 
+// compute units of the current device (256 on an MI355X)
+inline int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
 // ---- optional per-kernel timing (runtime.hip): { KernelTimer t("name", stream); hipLaunchKernelGGL(...); } --------------
 extern int g_profile_mode;                   // 0 off, 1 every kernel, 2 hash-grid kernels only
 constexpr int kTimeAny = 1, kTimeGrid = 2;  // timer groups

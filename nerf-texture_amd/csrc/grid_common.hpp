@@ -124,9 +124,10 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]
 
 
 // large-batch table-gradient path (gridencoder_binned.hip): bins the corner contributions by table tile, then
-// accumulates every tile in LDS.  C == 2 only.  Returns NERFTEX_OK or an error; grad is level-major [L,B,2].
+// accumulates every tile in LDS.  C == 2 only.  Returns NERFTEX_OK, an error, or -1 (shape outside its limits);
+// grad is [B, L*2] (blc) or level-major [L,B,2].
 template <typename T, int D>
-int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
+int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
                          const LevelConsts& lc, uint32_t gridtype, bool align_corners, hipStream_t st);
 
 }  // namespace gridenc

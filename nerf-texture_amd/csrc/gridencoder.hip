@@ -314,17 +314,6 @@ constexpr uint32_t kOwnerAccBytes = 128 * 1024;  // accumulator tile
 constexpr uint32_t kQueueCap = 128;              // per wave: < 64 pending + <= 64 pushed per round
 constexpr uint32_t kOwnerLdsBytes = kOwnerAccBytes + kOwnerWaves * kQueueCap * 12;  // + per-wave hit queues (<= 12 B entries)
 
-inline int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
-    return cus;
-}
-
 // ------------------------------------------------------------------------------------------------
 // backward: scatter-add of w * grad into the table gradient
 // ------------------------------------------------------------------------------------------------
@@ -806,8 +795,14 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
     int rc = NERFTEX_OK;
     if constexpr (C == 2) {
         if (owner) {  // every level through the LDS tile owners, no per-sample global atomics at all
+            const char* algo = getenv("NERFTEX_GRID_BWD_ALGO");  // "sweep" keeps the tile-owner sweep; default = binning
+            if (!(algo && algo[0] == 's')) {
+                rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, st);
+                if (rc == NERFTEX_OK) goto table_done;
+                if (rc > 0) return rc;  // rc < 0: shape outside the binned path's limits -> sweep below
+            }
             const T* g = grad;
-            if (blc) {
+            if (blc) {  // the sweep reads level-major gradients
                 T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
                 if (!tmp) return NERFTEX_ERR_HIP;
                 {
@@ -818,12 +813,6 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
                 if (rc != NERFTEX_OK) return rc;
                 g = tmp;
             }
-            const char* algo = getenv("NERFTEX_GRID_BWD_ALGO");  // "sweep" keeps the tile-owner sweep; default = binning
-            if (!(algo && algo[0] == 's')) {
-                rc = grid_backward_binned<T, D>(g, inputs, offsets, grad_emb, B, L, lc, gridtype, align, st);
-                if (rc == NERFTEX_OK) goto table_done;
-                if (rc > 0) return rc;  // rc < 0: shape outside the binned path's limits -> sweep below
-            }
             auto kernel = grid_backward_owner_kernel<T, D>;
             NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnerLdsBytes),
                             "hipFuncSetAttribute");
@@ -831,7 +820,7 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
             const char* ip = getenv("NERFTEX_GRID_BWD_ITEMS");
             const uint32_t items_per_level = ip ? (uint32_t)atoi(ip) : div_up(6u * cus, L);
             {
-                KernelTimer kt("kernel", st, kTimeGrid);
+                KernelTimer kt("grid_backward_owner_kernel", st, kTimeGrid);
                 hipLaunchKernelGGL(kernel, dim3(cus), dim3(kOwnerThreads), kOwnerLdsBytes, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align,
                                    items_per_level ? items_per_level : 1u);
             }

@@ -1,17 +1,23 @@
 // Hash-grid backward for large batches: bin the corner contributions by table tile, accumulate tiles in LDS.
 //
-// Why (measured on MI355X, tools/probes/atomic_probe.hip): global float atomics retire ~20 G cache-line
-// transactions/s however small the footprint; a 4096-ray training batch is ~15 M distinct line updates per step
-// (>= 0.7 ms), and an "owner sweeps all samples" LDS scheme pays a 16-32x redundant sweep (0.5 ms).  Binning does each
-// piece of work once:
-//   K1 count   one thread per (sample, level): 2^(D-1) records per thread -- a record is the pair of x-neighbour
-//              corners, whose rows are adjacent for dense levels and within one 64-B line 15 times out of 16 for
-//              hashed levels (prime[0] == 1) -- histogrammed per 128-KiB table tile in LDS; per (workgroup, tile) counts
-//   K2 scan    per tile: exclusive prefix of the workgroup counts (one wave per tile), then a prefix over tiles
-//   K3 fill    same threads as K1, records {row_a, row_b, w_a*grad, w_b*grad} stored at their exact slot (no atomics to
-//              global memory, ~4 KiB contiguous runs per (workgroup, tile))
-//   K4 sum     a workgroup per (tile, <= 48 Ki records): stream the tile's records, ds_pk_add_f16 / ds_add_f32 into the
-//              LDS tile, then add the tile to the table with plain (single owner) or coalesced-atomic (split tile) writes
+// Why (measured on MI355X, tools/probes/{atomic_probe,lds_atomic_probe}.hip):
+//   * global float atomics retire ~20 G cache-line transactions/s however small the footprint; an 8192-ray training batch is
+//     ~30 M distinct line updates per step (>= 1.4 ms);
+//   * LDS FLOAT atomics (ds_add_f32, ds_pk_add_f16) retire one lane every ~3 clocks per CU (0.2 T lane-ops/s chip-wide) with or
+//     without bank conflicts, LDS INTEGER atomics 16-27x faster (ds_add_u64: 3.3 T/s, ds_add_u32: 5.3 T/s).
+// So every contribution is binned once and the fp16 table is accumulated in 64-bit FIXED POINT:
+//   K1 count   a wave per level, a workgroup per 1024 samples: 2^(D-1) records per (sample, level) -- a record is the pair of
+//              x-neighbour corners, whose rows are adjacent for dense levels and inside one aligned 2^k block for hashed
+//              levels (prime[0] == 1) -- histogrammed per table tile in LDS; per (workgroup, level, tile) counts
+//   K2 scan    per tile: exclusive prefix of the workgroup counts (one wave per tile), then a prefix over tiles + the K4 work list
+//   K3 fill    same threads as K1, records {tile-local rows, w_a*grad, w_b*grad} (12 B fp16 / 20 B fp32) stored at their exact
+//              slot: no global atomics; the gradient is read in the caller's layout ([B,L*C] rows are shared by the 16 level
+//              waves of a workgroup through L1), so no transposed copy of it is made
+//   K4 sum     a workgroup per (tile, slice of its records): fp16: every half is an integer multiple of 2^-24 below 2^16, so
+//              value * 2^24 fits 41 bits and ds_add_u64 sums are EXACT and order-independent; the tile is rounded to fp16 once
+//              (round-to-nearest-even of the true sum) -- deterministic, and tighter than the reference's chain of fp16
+//              atomics.  fp32 tables keep float LDS atomics.  Tiles with one slice are added to the table with plain
+//              read-add-write (sole owner), split tiles with coalesced atomics.
 // Coarse dense levels first merge runs of consecutive samples that share a cell (wave64 segmented reduction), which
 // removes their same-row pile-ups before anything is written.
 // The level table lives on the device; its host copy (needed to size grids and buffers) is read back ONCE per
@@ -20,6 +26,7 @@
 #include "grid_common.hpp"
 #include "workspace.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -29,24 +36,57 @@ namespace nerftex {
 namespace gridenc {
 namespace {
 
-constexpr uint32_t kBinThreads = 1024;       // samples per workgroup in K1 / K3
-constexpr uint32_t kTileBytes = 128 * 1024;  // LDS accumulator tile of K4
+constexpr uint32_t kBinWaves = 16;                      // levels per K1 / K3 workgroup (one wave each)
+constexpr uint32_t kBinThreads = kBinWaves * kWave;     // 1024
+constexpr uint32_t kBinSamples = 1024;                  // samples per K1 / K3 workgroup (16 rounds of 64)
+constexpr uint32_t kTileBytes = 128 * 1024;             // LDS accumulator tile of K4
 constexpr uint32_t kMaxTilesPerLevel = 64;
-constexpr uint32_t kSliceRecords = 64 * 1024;  // records per K4 work item
+constexpr uint32_t kSliceRecords = 32 * 1024;           // records per K4 work item
 constexpr uint32_t kSumThreads = 1024;
-constexpr uint32_t kSumUnroll = 8;          // record loads in flight per lane in K4
+constexpr uint32_t kSumUnroll = 8;                      // record loads in flight per lane in K4
+constexpr uint32_t kRowBits = 14, kRowMask = (1u << kRowBits) - 1u, kHasB = 1u << (2 * kRowBits);
 
 struct LevelTable {
     int32_t offsets[kMaxLevels + 1];
     uint32_t tile_base[kMaxLevels + 1];  // global tile index of each level's first tile
 };
 
+// a record: tile-local rows a | b << 14 | has_b << 28, then the two weighted gradients (C = 2)
 template <typename T> struct Rec;
-template <> struct Rec<half_t> { uint32_t row_a, row_b; half2_t va, vb; };  // 16 B
-template <> struct Rec<float> { uint32_t row_a, row_b; float va0, va1, vb0, vb1; };  // 24 B
+template <> struct Rec<half_t> { uint32_t rows; half2_t va, vb; };              // 12 B
+template <> struct Rec<float> { uint32_t rows; float va0, va1, vb0, vb1; };     // 20 B
 
+// accumulator bytes per table row in K4: fp16 -> 2 x int64 fixed point, fp32 -> 2 x float
 template <typename T>
-constexpr uint32_t rows_per_tile() { return kTileBytes / (uint32_t)(2 * sizeof(T)); }
+constexpr uint32_t rows_per_tile() { return sizeof(T) == 2 ? kTileBytes / 16u : kTileBytes / 8u; }
+static_assert(kMaxTilesPerLevel == kWave, "K3 scans one level's tiles with one wave");
+static_assert(rows_per_tile<half_t>() <= (1u << kRowBits) && rows_per_tile<float>() <= (1u << kRowBits), "local row field");
+
+// ---- fp16 <-> 2^-24 fixed point ------------------------------------------------------------------------------------
+// every finite half is m * 2^-24 with |m| < 2^40; inf / nan map to >= 2^40 and come back as inf
+__device__ __forceinline__ long long half_to_fixed(half_t h) {
+    const uint32_t b = __builtin_bit_cast(uint16_t, h);
+    const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
+    const unsigned long long mag = e ? (unsigned long long)(f | 1024u) << (e - 1u) : (unsigned long long)f;
+    return (b & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+// round-to-nearest-even of s * 2^-24 to half, overflow -> inf
+__device__ __forceinline__ half_t fixed_to_half(long long s) {
+    const uint32_t sign = s < 0 ? 0x8000u : 0u;
+    const unsigned long long m = s < 0 ? (unsigned long long)(-s) : (unsigned long long)s;
+    uint32_t bits;
+    if (m < 2048ull) {
+        bits = (uint32_t)m;  // subnormals and the first binade are exact
+    } else {
+        const uint32_t shift = 53u - (uint32_t)__builtin_clzll(m);  // msb - 10
+        unsigned long long q = m >> shift;
+        const unsigned long long rem = m & ((1ull << shift) - 1ull), half_ulp = 1ull << (shift - 1u);
+        if (rem > half_ulp || (rem == half_ulp && (q & 1ull))) q++;
+        const unsigned long long v = ((unsigned long long)shift << 10) + q;
+        bits = v >= 0x7c00ull ? 0x7c00u : (uint32_t)v;
+    }
+    return __builtin_bit_cast(half_t, (uint16_t)(bits | sign));
+}
 
 // ---- per-sample record construction, shared by K1 (count only) and K3 (fill) ---------------------------------------
 template <typename T, int D>
@@ -57,24 +97,24 @@ struct Sample {
     float va[NP][2], vb[NP][2];
 };
 
+// xs: the sample's coordinates, in_batch: b < B, g: this (sample, level)'s two gradient values (FILL only).
+// Must be called by whole waves (shuffles); consecutive lanes = consecutive samples.
 template <typename T, int D, bool FILL>
-__device__ __forceinline__ void make_sample(Sample<T, D>& sm, const T* __restrict__ g_level, const float* __restrict__ inputs, uint32_t b,
-                                            uint32_t B, float scale, bool align_corners, const IndexFn<D>& index_of, uint32_t hashmap_size, bool merge_runs) {
+__device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[D], bool in_batch, const float (&g)[2], float scale,
+                                            bool align_corners, const IndexFn<D>& index_of, uint32_t hashmap_size, bool merge_runs) {
     constexpr int NP = Sample<T, D>::NP;
     const int lane = threadIdx.x & (kWave - 1);
-    bool valid = b < B;
+    bool valid = in_batch;
     float pos[D];
     uint32_t pg[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const float x = valid ? inputs[(size_t)b * D + d] : 0.0f;
-        if (x < 0 || x > 1) valid = false;
-        pos[d] = fmaf(x, scale, align_corners ? 0.0f : 0.5f);
+        const float x = xs[d];
+        if (!(x >= 0 && x <= 1)) valid = false;
+        pos[d] = fmaf(valid ? x : 0.0f, scale, align_corners ? 0.0f : 0.5f);
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
     }
-    float g[2] = {0.0f, 0.0f};
-    if (FILL && valid) load_row<T, 2>(g_level + (size_t)b * 2, g);
 
     const bool fast = index_of.hashed && index_of.pow2;
     uint32_t h[D][2];
@@ -155,54 +195,158 @@ __device__ __forceinline__ void validate_table(const int* __restrict__ offsets, 
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= L && offsets[threadIdx.x] != tab.offsets[threadIdx.x]) __builtin_trap();
 }
 
-// K1 / K3.  grid (nchunks, L).  counts[(level*nchunks + chunk)*kMaxTilesPerLevel + tile]; after K2a the same array holds
-// the start of this (workgroup, tile) run relative to the tile's first record.
-template <typename T, int D, bool FILL>
-__global__ __launch_bounds__(kBinThreads) void bin_kernel(const T* __restrict__ grad_lbc, const float* __restrict__ inputs,
-                                                         const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
-                                                         uint32_t gridtype, bool align_corners, const LevelTable tab,
-                                                         uint32_t* __restrict__ counts, const uint32_t* __restrict__ tile_start, Rec<T>* __restrict__ records,
-                                                         bool merge_runs) {
-    __shared__ uint32_t hist[kMaxTilesPerLevel];
+template <typename T>
+__device__ __forceinline__ void put_record(Rec<T>* __restrict__ dst, uint32_t rows, const float (&va)[2], const float (&vb)[2]) {
+    Rec<T> r;
+    r.rows = rows;
+    if constexpr (sizeof(T) == 2) {
+        r.va = half2_t{(half_t)va[0], (half_t)va[1]};
+        r.vb = half2_t{(half_t)vb[0], (half_t)vb[1]};
+    } else {
+        r.va0 = va[0]; r.va1 = va[1]; r.vb0 = vb[0]; r.vb1 = vb[1];
+    }
+    *dst = r;
+}
+
+// K1 count.  grid (nchunks, ceil(L/16)), wave w of a workgroup = level blockIdx.y*16 + w, 16 rounds of 64 samples.
+// counts[(level*nchunks + chunk)*kMaxTilesPerLevel + tile]; K2a turns the same array into the start of this
+// (workgroup, level, tile) run relative to the tile's first record.
+template <typename T, int D>
+__global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const float* __restrict__ inputs, const int* __restrict__ offsets, uint32_t B,
+                                                               uint32_t L, const LevelConsts lc, uint32_t gridtype, bool align_corners,
+                                                               const LevelTable tab, uint32_t* __restrict__ counts, bool merge_runs) {
+    __shared__ uint32_t hist[kBinWaves][kMaxTilesPerLevel];
     constexpr int NP = Sample<T, D>::NP;
     constexpr uint32_t kRows = rows_per_tile<T>();
-    if (!FILL) validate_table(offsets, tab, L);
-    const uint32_t level = blockIdx.y, chunk = blockIdx.x;
-    const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
-    const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
-    uint32_t* my_counts = counts + ((size_t)level * gridDim.x + chunk) * kMaxTilesPerLevel;
-
-    if (threadIdx.x < kMaxTilesPerLevel) {
-        const uint32_t nt = tab.tile_base[level + 1] - tab.tile_base[level];
-        hist[threadIdx.x] = (FILL && threadIdx.x < nt) ? my_counts[threadIdx.x] + tile_start[tab.tile_base[level] + threadIdx.x] : 0u;
-    }
+    validate_table(offsets, tab, L);
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const uint32_t level = blockIdx.y * kBinWaves + wave, chunk = blockIdx.x, nchunks = gridDim.x;
+    for (uint32_t i = threadIdx.x; i < kBinWaves * kMaxTilesPerLevel; i += kBinThreads) hist[i / kMaxTilesPerLevel][i % kMaxTilesPerLevel] = 0u;
     __syncthreads();
 
-    Sample<T, D> sm;
-    make_sample<T, D, FILL>(sm, grad_lbc + (size_t)level * B * 2, inputs, chunk * kBinThreads + threadIdx.x, B, lc.scale[level], align_corners,
-                            index_of, hashmap_size, merge_runs);
-    if (sm.valid) {
+    if (level < L) {  // wave-uniform
+        const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
+        const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
+        const float scale = lc.scale[level];
+        uint32_t* my_hist = hist[wave];
+        const float g[2] = {0.0f, 0.0f};
+        for (uint32_t round = 0; round < kBinSamples / kWave; round++) {
+            const uint32_t b0 = chunk * kBinSamples + round * kWave;
+            if (b0 >= B) break;
+            const uint32_t b = b0 + lane;
+            float xs[D];
 #pragma unroll
-        for (int q = 0; q < NP; q++) {
-            const uint32_t tile = sm.row_a[q] / kRows;
-            const uint32_t slot = atomicAdd(&hist[tile], 1u);  // LDS; in FILL mode hist starts at the run's global start
-            if (FILL) {
-                Rec<T> r;
-                r.row_a = sm.row_a[q];
-                r.row_b = sm.row_b[q];
-                if constexpr (sizeof(T) == 2) {
-                    r.va = half2_t{(half_t)sm.va[q][0], (half_t)sm.va[q][1]};
-                    r.vb = half2_t{(half_t)sm.vb[q][0], (half_t)sm.vb[q][1]};
-                } else {
-                    r.va0 = sm.va[q][0]; r.va1 = sm.va[q][1]; r.vb0 = sm.vb[q][0]; r.vb1 = sm.vb[q][1];
+            for (int d = 0; d < D; d++) xs[d] = b < B ? inputs[(size_t)b * D + d] : 0.0f;
+            Sample<T, D> sm;
+            make_sample<T, D, false>(sm, xs, b < B, g, scale, align_corners, index_of, hashmap_size, merge_runs);
+            if (sm.valid) {
+#pragma unroll
+                for (int q = 0; q < NP; q++) {
+                    const uint32_t ta = sm.row_a[q] / kRows, tb = sm.row_b[q] / kRows;
+                    atomicAdd(&my_hist[ta], 1u);
+                    if (ta != tb) atomicAdd(&my_hist[tb], 1u);  // partner row in another tile: its own single-row record
                 }
-                records[slot] = r;
             }
         }
     }
-    if (!FILL) {
-        __syncthreads();
-        if (threadIdx.x < kMaxTilesPerLevel) my_counts[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kBinWaves * kMaxTilesPerLevel; i += kBinThreads) {
+        const uint32_t w = i / kMaxTilesPerLevel, t = i % kMaxTilesPerLevel, lv = blockIdx.y * kBinWaves + w;
+        if (lv < L) counts[((size_t)lv * nchunks + chunk) * kMaxTilesPerLevel + t] = hist[w][t];
+    }
+}
+
+// K3 fill.  One workgroup per (1024 samples, level), thread = sample.  The workgroup's records are first laid out in LDS grouped
+// by tile, then copied out so that consecutive lanes write consecutive records: every (workgroup, tile) run is written with
+// full-width stores instead of 12-B pieces scattered over up to 64 tiles.  Workgroup ids are arranged so that the L levels of
+// one 1024-sample chunk run on ONE XCD (id % 8), close in time: with the caller's [B, L*C] layout each 64-B gradient row is
+// then fetched into that XCD's L2 once and its 16 level slices are served from there -- no transposed copy of the gradient.
+constexpr uint32_t kStageRecords = 4096 + 256;  // LDS slots per workgroup; rarer overflow goes straight to memory
+template <typename T>
+constexpr size_t fill_lds_bytes() { return (sizeof(Rec<T>) + 1) * (size_t)kStageRecords; }
+
+template <typename T, int D, bool BLC>
+__global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(const T* __restrict__ grad, const float* __restrict__ inputs, uint32_t B, uint32_t L,
+                                                              const LevelConsts lc, uint32_t gridtype, bool align_corners, const LevelTable tab,
+                                                              const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_count,
+                                                              const uint32_t* __restrict__ tile_start, Rec<T>* __restrict__ records, bool merge_runs,
+                                                              uint32_t nchunks) {
+    // (a persistent, software-pipelined variant of this kernel measured 1.5x SLOWER: the straight-line form below leaves the
+    //  overlap to the two resident workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel], gbase[kMaxTilesPerLevel];
+    constexpr int NP = Sample<T, D>::NP;
+    constexpr uint32_t kRows = rows_per_tile<T>();
+    Rec<T>* stage = reinterpret_cast<Rec<T>*>(smem);
+    uint8_t* stile = reinterpret_cast<uint8_t*>(smem + sizeof(Rec<T>) * kStageRecords);
+    const uint32_t group = blockIdx.x / (kXcds * L), rem = blockIdx.x % (kXcds * L);
+    const uint32_t level = rem / kXcds, chunk = group * kXcds + rem % kXcds;  // id % 8 = chunk % 8 = the XCD that runs it
+    if (chunk >= nchunks) return;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t b = chunk * kBinSamples + threadIdx.x;
+    const bool in_batch = b < B;
+    const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
+
+    if (threadIdx.x < kWave) {  // wave 0: this workgroup's run lengths -> LDS offsets, and the runs' global starts
+        const uint32_t t = threadIdx.x;  // kMaxTilesPerLevel == kWave
+        const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
+        uint32_t cnt = 0;
+        if (t < ntiles) {
+            const uint32_t g = tab.tile_base[level] + t;
+            const uint32_t here = starts[((size_t)level * nchunks + chunk) * kMaxTilesPerLevel + t];
+            const uint32_t next = chunk + 1 < nchunks ? starts[((size_t)level * nchunks + chunk + 1) * kMaxTilesPerLevel + t] : tile_count[g];
+            cnt = next - here;
+            gbase[t] = tile_start[g] + here;
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave);
+            if ((int)lane >= off) incl += o;
+        }
+        lbase[t] = incl - cnt;
+        lcount[t] = 0;
+        if (t == kWave - 1) lbase[kMaxTilesPerLevel] = incl;
+    }
+
+    float xs[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
+    float g[2] = {0.0f, 0.0f};
+    if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
+    const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
+    Sample<T, D> sm;
+    make_sample<T, D, true>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, hashmap_size, merge_runs);
+    __syncthreads();
+
+    if (sm.valid) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const uint32_t ta = sm.row_a[q] / kRows, tb = sm.row_b[q] / kRows;
+            const uint32_t la = sm.row_a[q] - ta * kRows, lb = sm.row_b[q] - tb * kRows;
+            const uint32_t ka = atomicAdd(&lcount[ta], 1u);
+            const uint32_t sa = lbase[ta] + ka;
+            const bool in_a = sa < kStageRecords;
+            if (in_a) stile[sa] = (uint8_t)ta;
+            Rec<T>* da = in_a ? stage + sa : records + gbase[ta] + ka;
+            if (ta == tb) {
+                put_record<T>(da, la | (lb << kRowBits) | kHasB, sm.va[q], sm.vb[q]);
+            } else {  // partner row lives in another tile (tile edge of a dense level): two single-row records
+                const uint32_t kb = atomicAdd(&lcount[tb], 1u);
+                const uint32_t sb = lbase[tb] + kb;
+                const bool in_b = sb < kStageRecords;
+                if (in_b) stile[sb] = (uint8_t)tb;
+                put_record<T>(da, la, sm.va[q], sm.vb[q]);
+                put_record<T>(in_b ? stage + sb : records + gbase[tb] + kb, lb, sm.vb[q], sm.va[q]);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = min(lbase[kMaxTilesPerLevel], kStageRecords);
+#pragma unroll 5
+    for (uint32_t i = threadIdx.x; i < total; i += kBinThreads) {
+        const uint32_t t = stile[i];
+        records[gbase[t] + (i - lbase[t])] = stage[i];
     }
 }
 
@@ -272,13 +416,14 @@ __global__ __launch_bounds__(1024) void scan_global_kernel(uint32_t L, const Lev
 }
 
 // K4: work item = (tile, slice of its records).  Items are enumerated on the device from tile_count.
+// K4: one workgroup per work item (tile, slice).
 template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ tile_count,
                                                                const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ items,
                                                                uint32_t L, const LevelTable tab, T* __restrict__ grad_grid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* acc = reinterpret_cast<T*>(smem);
     constexpr uint32_t kRows = rows_per_tile<T>();
+    constexpr bool kFixed = sizeof(T) == 2;
     if (blockIdx.x >= items[0]) return;
     const uint32_t code = items[1 + blockIdx.x];
     const uint32_t g = code & 0xfffu, item = (code >> 12) & 0x3ffu, slices = code >> 22;
@@ -289,11 +434,11 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_kernel(const Rec<T>* __
     const uint32_t rows_level = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
     const uint32_t row0 = t * kRows;
     const uint32_t nrows = min(kRows, rows_level - row0);
-    T* __restrict__ level_table = grad_grid + (size_t)(uint32_t)tab.offsets[level] * 2;
+    T* __restrict__ dst = grad_grid + ((size_t)(uint32_t)tab.offsets[level] + row0) * 2;
 
-    {   // zero the tile, 16 B per lane per store
-        float4_t* z = reinterpret_cast<float4_t*>(acc);
-        const uint32_t nq = (nrows * 2 * (uint32_t)sizeof(T) + 15) / 16;
+    {   // zero the accumulators (16 B per table row for fp16, 8 B for fp32), 16 B per lane per store
+        float4_t* z = reinterpret_cast<float4_t*>(smem);
+        const uint32_t nq = kFixed ? nrows : (nrows + 1) / 2;
         for (uint32_t i = threadIdx.x; i < nq; i += kSumThreads) z[i] = float4_t{0, 0, 0, 0};
     }
     __syncthreads();
@@ -301,8 +446,9 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_kernel(const Rec<T>* __
     const uint32_t per = div_up(n, slices);
     const uint32_t lo = item * per, hi = min(n, lo + per);
     const Rec<T>* __restrict__ rec = records + tile_start[g];
-    // The loop is latency-bound unless several record loads are in flight per lane: issue kSumUnroll independent 16/24-B loads, then
-    // retire them (the LDS / stray global atomics would otherwise fence every load behind the previous record's adds).
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
+    float* acc32 = reinterpret_cast<float*>(smem);
+    // several record loads in flight per lane, then retire them
     for (uint32_t base = lo; base < hi; base += kSumThreads * kSumUnroll) {
         Rec<T> r[kSumUnroll];
         bool live[kSumUnroll];
@@ -315,42 +461,46 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_kernel(const Rec<T>* __
 #pragma unroll
         for (uint32_t u = 0; u < kSumUnroll; u++) {
             if (!live[u]) continue;
-            const uint32_t ra = r[u].row_a - row0, rb = r[u].row_b - row0;
-            if constexpr (sizeof(T) == 2) {
-                typedef __attribute__((address_space(3))) half2_t lds_h2;
-                __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)(acc + (size_t)ra * 2), r[u].va);
-                if (rb < nrows) __builtin_amdgcn_ds_atomic_fadd_v2f16((lds_h2*)(acc + (size_t)rb * 2), r[u].vb);
-                else unsafeAtomicAdd(reinterpret_cast<__half2*>(level_table) + r[u].row_b, __builtin_bit_cast(__half2, r[u].vb));  // partner row in another tile
+            const uint32_t ra = r[u].rows & kRowMask, rb = (r[u].rows >> kRowBits) & kRowMask;
+            const bool has_b = (r[u].rows & kHasB) != 0;
+            if constexpr (kFixed) {
+                atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)half_to_fixed(r[u].va[0]));
+                atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)half_to_fixed(r[u].va[1]));
+                if (has_b) {
+                    atomicAdd(acc64 + (size_t)rb * 2, (unsigned long long)half_to_fixed(r[u].vb[0]));
+                    atomicAdd(acc64 + (size_t)rb * 2 + 1, (unsigned long long)half_to_fixed(r[u].vb[1]));
+                }
             } else {
-                float* a = reinterpret_cast<float*>(acc);
-                atomicAdd(a + (size_t)ra * 2, r[u].va0);
-                atomicAdd(a + (size_t)ra * 2 + 1, r[u].va1);
-                if (rb < nrows) {
-                    atomicAdd(a + (size_t)rb * 2, r[u].vb0);
-                    atomicAdd(a + (size_t)rb * 2 + 1, r[u].vb1);
-                } else {
-                    unsafeAtomicAdd(reinterpret_cast<float*>(level_table) + (size_t)r[u].row_b * 2, r[u].vb0);
-                    unsafeAtomicAdd(reinterpret_cast<float*>(level_table) + (size_t)r[u].row_b * 2 + 1, r[u].vb1);
+                atomicAdd(acc32 + (size_t)ra * 2, r[u].va0);
+                atomicAdd(acc32 + (size_t)ra * 2 + 1, r[u].va1);
+                if (has_b) {
+                    atomicAdd(acc32 + (size_t)rb * 2, r[u].vb0);
+                    atomicAdd(acc32 + (size_t)rb * 2 + 1, r[u].vb1);
                 }
             }
         }
     }
     __syncthreads();
 
-    // tile -> table.  Always atomic (another tile's workgroup may be adding a stray partner row), but consecutive lanes hit
-    // consecutive addresses: one transaction per 64-B line.
-    T* __restrict__ dst = level_table + (size_t)row0 * 2;
-    if constexpr (sizeof(T) == 2) {  // one dword per lane: 16 consecutive lanes share a 64-B line = one atomic transaction
-        const uint32_t* a32 = reinterpret_cast<const uint32_t*>(acc);
+    // tile -> table.  A tile with a single work item has a single writer in this launch: plain read-add-write, deterministic.
+    // Split tiles add their partial sums with atomics; consecutive lanes hit consecutive addresses (one transaction per line).
+    const bool sole = slices == 1;
+    if constexpr (kFixed) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kSumThreads) {
-            const uint32_t v = a32[i];
-            if (v & 0x7fff7fffu) unsafeAtomicAdd(reinterpret_cast<__half2*>(dst) + i, __builtin_bit_cast(__half2, v));
+            const long long s0 = (long long)acc64[(size_t)i * 2], s1 = (long long)acc64[(size_t)i * 2 + 1];
+            if ((s0 | s1) == 0) continue;
+            const half2_t v = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
+            half2_t* p = reinterpret_cast<half2_t*>(dst) + i;
+            if (sole) *p = *p + v;
+            else unsafeAtomicAdd(reinterpret_cast<__half2*>(p), __builtin_bit_cast(__half2, v));
         }
     } else {
-        const float* a = reinterpret_cast<const float*>(acc);
         for (uint32_t i = threadIdx.x; i < nrows * 2; i += kSumThreads) {
-            const float v = a[i];
-            if (v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst) + i, v);
+            const float v = acc32[i];
+            if (v == 0.0f) continue;
+            float* p = reinterpret_cast<float*>(dst) + i;
+            if (sole) *p = *p + v;
+            else unsafeAtomicAdd(p, v);
         }
     }
 }
@@ -382,7 +532,7 @@ int host_offsets(const int* offsets_dev, uint32_t L, hipStream_t st, std::vector
 }  // namespace
 
 template <typename T, int D>
-int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
+int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
                          const LevelConsts& lc, uint32_t gridtype, bool align_corners, hipStream_t st) {
     std::vector<int32_t> off;
     int rc = host_offsets(offsets_dev, L, st, off);
@@ -401,9 +551,9 @@ int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offs
     tab.tile_base[L] = tiles;
 
     constexpr uint32_t NP = 1u << (D - 1);
-    const uint32_t nchunks = div_up(B, kBinThreads);
+    const uint32_t nchunks = div_up(B, kBinSamples);
     const size_t n_counts = (size_t)L * nchunks * kMaxTilesPerLevel;
-    const size_t max_records = (size_t)B * L * NP;
+    const size_t max_records = (size_t)B * L * NP * 2;  // worst case: every pair straddles a tile edge
     static const uint32_t slice_records = [] {  // records per K4 work item (tuning switch; default kSliceRecords)
         const char* e = getenv("NERFTEX_GRID_BWD_SLICE");
         const long v = e ? atol(e) : 0;
@@ -420,12 +570,11 @@ int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offs
     uint32_t* items = tile_start + tiles + 1;
     Rec<T>* records = reinterpret_cast<Rec<T>*>(base + head_bytes);
 
-    const dim3 bgrid(nchunks, L), bblock(kBinThreads);
+    const dim3 bgrid(nchunks, div_up(L, kBinWaves)), bblock(kBinThreads);
     const bool merge_runs = getenv("NERFTEX_GRID_BWD_NOMERGE") == nullptr;
     {
         KernelTimer kt("bin_count_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL((bin_kernel<T, D, false>), bgrid, bblock, 0, st, grad_lbc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts,
-                           tile_start, records, merge_runs);
+        hipLaunchKernelGGL((bin_count_kernel<T, D>), bgrid, bblock, 0, st, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts, merge_runs);
     }
     if ((rc = check_launch("grid_encode_backward(count)")) != NERFTEX_OK) return rc;
     {
@@ -439,9 +588,12 @@ int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offs
     }
     if ((rc = check_launch("grid_encode_backward(scan2)")) != NERFTEX_OK) return rc;
     {
+        auto fill = blc ? bin_fill_kernel<T, D, true> : bin_fill_kernel<T, D, false>;
+        const size_t lds = fill_lds_bytes<T>();
+        NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         KernelTimer kt("bin_fill_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL((bin_kernel<T, D, true>), bgrid, bblock, 0, st, grad_lbc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, tab, counts,
-                           tile_start, records, merge_runs);
+        hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), bblock, lds, st, grad, inputs, B, L, lc, gridtype, align_corners, tab, counts,
+                           tile_count, tile_start, records, merge_runs, nchunks);
     }
     if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
 
@@ -455,10 +607,10 @@ int grid_backward_binned(const T* grad_lbc, const float* inputs, const int* offs
     return check_launch("grid_encode_backward(sum)");
 }
 
-template int grid_backward_binned<float, 2>(const float*, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
-template int grid_backward_binned<float, 3>(const float*, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
-template int grid_backward_binned<half_t, 2>(const half_t*, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
-template int grid_backward_binned<half_t, 3>(const half_t*, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
+template int grid_backward_binned<float, 2>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
+template int grid_backward_binned<float, 3>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
+template int grid_backward_binned<half_t, 2>(const half_t*, bool, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
+template int grid_backward_binned<half_t, 3>(const half_t*, bool, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
 
 }  // namespace gridenc
 }  // namespace nerftex

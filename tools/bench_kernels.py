@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--ops", default="grid_fwd,grid_bwd,sh,ffmlp,march,composite")
     ap.add_argument("--random-points", action="store_true")
+    ap.add_argument("--dtypes", default="f16,f32")
     ap.add_argument("--kernels", action="store_true", help="also report the library's per-kernel hipEvent averages")
     args = ap.parse_args()
     ops = set(args.ops.split(","))
@@ -74,6 +75,8 @@ def main():
     off = enc.offsets
 
     for name, tdt, tag, s in (("f16", torch.float16, F16, 2), ("f32", torch.float32, F32, 4)):
+        if name not in args.dtypes.split(","):
+            continue
         emb = enc.embeddings.detach().to(tdt).contiguous()
         out = torch.empty(M, L * C, dtype=tdt, device=dev)
         dummy = torch.zeros(1, dtype=tdt, device=dev)
