@@ -78,10 +78,12 @@ struct Pcg32 {
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+    // v * 0x00010001 == v | v << 16 for the 10-bit inputs (no carries): shift-or form, one v_lshl_or_b32 per step instead of a
+    // quarter-rate integer multiply on the DDA's critical path
+    v = (v | (v << 16)) & 0xFF0000FFu;
+    v = (v | (v << 8)) & 0x0F00F00Fu;
+    v = (v | (v << 4)) & 0xC30C30C3u;
+    v = (v | (v << 2)) & 0x49249249u;
     return v;
 }
 __device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
@@ -106,7 +108,7 @@ __device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max
     return (int)fminf(max_cascade - 1, fmaxf(0, (float)frexp_exponent(mx)));
 }
 __device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
-    const float mx = (float)((double)(dt * H) * 0.5);
+    const float mx = (dt * H) * 0.5f;  // the reference halves in double: exact either way
     return (int)fminf(max_cascade - 1, fmaxf(0, (float)frexp_exponent(mx)));
 }
 
@@ -132,9 +134,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, rH;
     float bound, dt_gamma, dt_min, dt_max, far;
-    float Cf, Hf, sx, sy, sz, hi;
+    float Cf, Hf, sx, sy, sz, hi, rbound, halfH;
     uint32_t H, H3;
     double Hd;
+    bool pow2H;
     const uint8_t* __restrict__ grid;
 
     __device__ Dda(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps, uint32_t C, uint32_t H_,
@@ -149,6 +152,9 @@ struct Dda {
         far = far_;
         Cf = (float)C; Hf = (float)H_; H = H_; H3 = H_ * H_ * H_; Hd = (double)H_;
         hi = (float)(H_ - 1);
+        rbound = 1 / bound_;
+        halfH = 0.5f * (float)H_;
+        pow2H = (H_ & (H_ - 1)) == 0;
         sx = copysignf(1.0f, dx); sy = copysignf(1.0f, dy); sz = copysignf(1.0f, dz);
         grid = grid_;
     }
@@ -162,11 +168,27 @@ struct Dda {
         dt = clampf(t * dt_gamma, dt_min, dt_max);
         const int la = mip_from_pos(x, y, z, Cf), lb = mip_from_dt(dt, Hf, Cf);
         const int level = la > lb ? la : lb;
-        const float mip_bound = fminf((float)(1 << level), bound);
-        const float mip_rbound = 1 / mip_bound;
-        const int nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * Hd), 0.0f, hi);
-        const int ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * Hd), 0.0f, hi);
-        const int nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * Hd), 0.0f, hi);
+        // The DDA is issue-bound on ONE wave per 64 rays (~230 iterations x ~1200 clocks, measured with s_memtime; occupancy loads,
+        // rays per wave and workgroup placement make no difference), so every instruction off this path counts -- as long as
+        // the result stays bit-identical:
+        // 1 / min(2^level, bound): the reciprocal of a power of two is exact, so only 1 / bound needs the IEEE division, once per ray
+        const float p2 = (float)(1 << level);
+        const float mip_bound = fminf(p2, bound);
+        const float mip_rbound = p2 <= bound ? __builtin_bit_cast(float, (uint32_t)(127 - level) << 23) : rbound;
+        // 0.5 * (double)v * H rounded to float == v * (H / 2) in float when H is a power of two (scaling is exact)
+        float fx, fy, fz;
+        if (pow2H) {
+            fx = fmaf(x, mip_rbound, 1.0f) * halfH;
+            fy = fmaf(y, mip_rbound, 1.0f) * halfH;
+            fz = fmaf(z, mip_rbound, 1.0f) * halfH;
+        } else {
+            fx = (float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * Hd);
+            fy = (float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * Hd);
+            fz = (float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * Hd);
+        }
+        const int nx = (int)clampf(fx, 0.0f, hi);
+        const int ny = (int)clampf(fy, 0.0f, hi);
+        const int nz = (int)clampf(fz, 0.0f, hi);
         const uint32_t index = (uint32_t)level * H3 + morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
         const bool occ = grid[index >> 3] & (1u << (index & 7u));
         if (occ) return true;

@@ -53,7 +53,7 @@ class _ffmlp_forward(Function):
         grad = grad.contiguous().half()
         inputs, weights, outputs, forward_buffer = ctx.saved_tensors
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
-        grad_inputs = torch.zeros_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
+        grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
         # the reference zero-fills both (ffmlp.py:72-73) because its kernels accumulate / skip rows; the HIP kernels
         # overwrite every element of both, so the fills (2 x num_layers x B x hidden x 2 B per call) are dropped
         grad_weights = torch.empty_like(weights)
