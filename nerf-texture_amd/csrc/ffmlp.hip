@@ -424,6 +424,243 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_kernel(const WgradA
     }
 }
 
+// per-workgroup combine of one weight-gradient matrix held as NA x NB result tiles per wave: LDS sum over the 4 waves, one fp32
+// write per element.  Everything is indexed at compile time so the accumulators stay in registers.
+template <int NA, int NB>
+__device__ __forceinline__ void flush_tiles(const float4_t (&tiles)[NA][NB], float* __restrict__ red, float* __restrict__ out, uint32_t K, int wave,
+                                            int lane) {
+    static_assert(NA * NB <= 16, "combine buffer holds 16 tiles per wave");
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[((wave * 16 + a * NB + b) * 4 + q) * 64 + lane] = tiles[a][b][q];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NA * NB * 256; e += kBlockThreads) {
+        const int tile = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+        const int a = tile / NB, b = tile % NB;
+        const uint32_t o = 16 * a + 4 * (ln >> 4) + q, i = 16 * b + (ln & 15);
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) sum += red[((w * 16 + tile) * 4 + q) * 64 + ln];
+        out[(size_t)o * K + i] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, fused: activation gradients AND weight gradients in one pass over the batch
+// ------------------------------------------------------------------------------------------------
+// The dgrad chain already holds, per 32 batch rows, every dPre tile (fp32 result tiles -> the permuted 32-deep operand `bop`)
+// and loads every saved activation tile (for the activation derivative) in the same (lane = batch row, slots = features)
+// form.  That is exactly the input form of the transposing MFMAs of the weight-gradient kernel above -- so the weight gradients
+// are accumulated right here, in fp32 registers that live across the whole batch loop, and
+//   * backward_buffer is never written nor read (it is scratch in the reference's contract),
+//   * forward_buffer and the inputs are read once instead of twice:  ~52 % less HBM traffic for the whole MLP backward.
+// One wave per SIMD (the dW accumulators are 112-176 registers); the loads of a 32-row step are issued together.
+template <int HIDDEN, int NL, int IT>  // IT = input_dim / 16
+__global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(const half_t* __restrict__ grad, const half_t* __restrict__ X,
+                                                                               const half_t* __restrict__ W, const half_t* __restrict__ fwd,
+                                                                               half_t* __restrict__ grad_inputs, uint32_t B, uint32_t act,
+                                                                               float* __restrict__ partials, uint32_t n_params) {
+    constexpr int OT = HIDDEN / 16;
+    constexpr int KSH = (HIDDEN + 31) / 32;
+    constexpr int NT = 2;               // 32 batch rows per wave step = one 32-deep contraction step of the weight gradients
+    constexpr int IN = 16 * IT;
+    constexpr int KS0 = (IN + 31) / 32;
+    static_assert(HIDDEN % 32 == 0 && kTilesPerWave == NT, "fused backward: hidden width must be a multiple of 32");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8_t* frags = reinterpret_cast<half8_t*>(smem);
+
+    const half_t* W_hidden = W + (size_t)HIDDEN * IN;
+    const half_t* W_out = W_hidden + (size_t)(NL - 1) * HIDDEN * HIDDEN;
+    constexpr int per_hidden = OT * KSH;
+    constexpr int base_hidden = OT;
+    constexpr int base_in = base_hidden + (NL - 1) * per_hidden;
+    stage_fragments(frags, W_out, HIDDEN, true, HIDDEN, 16, false);
+    for (int j = 1; j < NL; j++)
+        stage_fragments(frags + (size_t)(base_hidden + (j - 1) * per_hidden) * 64, W_hidden + (size_t)(NL - 1 - j) * HIDDEN * HIDDEN, HIDDEN, true,
+                        HIDDEN, HIDDEN, true);
+    if (grad_inputs) stage_fragments(frags + (size_t)base_in * 64, W, IN, true, IN, HIDDEN, true);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const size_t layer_stride = (size_t)B * HIDDEN;
+    const float4_t zero{0, 0, 0, 0};
+
+    // 0/1 selection operands: X . Sel moves 16 of the 32 features of X onto the lane axis (batch rows into registers)
+    //   natural order (operand read from row-major memory): slot (g, j) <-> feature 8g + j
+    //   permuted order (operand packed from two result tiles / two half4 activation loads): j < 4 <-> tile 2s feature 4g + j,
+    //                                                                                       j >= 4 <-> tile 2s+1 feature 4g + j - 4
+    half8_t sel0, sel1, selP0, selP1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        sel0[j] = (8 * g + j == r) ? (half_t)1.0f : (half_t)0.0f;
+        sel1[j] = (8 * g + j == 16 + r) ? (half_t)1.0f : (half_t)0.0f;
+        selP0[j] = (j < 4 && 4 * g + j == r) ? (half_t)1.0f : (half_t)0.0f;
+        selP1[j] = (j >= 4 && 4 * g + j - 4 == r) ? (half_t)1.0f : (half_t)0.0f;
+    }
+
+    float4_t gw_out[1][OT];                         // dW_out [16 x HIDDEN]
+    float4_t gw_hid[NL > 1 ? NL - 1 : 1][OT][OT];   // dW_l, l = 1..NL-1 [HIDDEN x HIDDEN]
+    float4_t gw_in[OT][IT];                         // dW_0 [HIDDEN x IN]
+#pragma unroll
+    for (int b = 0; b < OT; b++) gw_out[0][b] = zero;
+#pragma unroll
+    for (int l = 0; l < NL - 1; l++)
+#pragma unroll
+        for (int a = 0; a < OT; a++)
+#pragma unroll
+            for (int b = 0; b < OT; b++) gw_hid[l][a][b] = zero;
+#pragma unroll
+    for (int a = 0; a < OT; a++)
+#pragma unroll
+        for (int b = 0; b < IT; b++) gw_in[a][b] = zero;
+
+    // (requesting the NEXT step's operands before computing the current one was tried: +64 live registers push the 3-layer
+    //  instantiation to 256 + 256 registers with spills, 130 -> 160 us.  The four waves of a CU overlap each other instead.)
+    for (uint32_t row0 = blockIdx.x * kRowsPerBlock + wave * 16 * NT; row0 < B; row0 += gridDim.x * kRowsPerBlock) {
+        // ---- all loads of this step first: output gradient, inputs, saved activations of every layer
+        half8_t bg[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (g < 2) bg[t] = *reinterpret_cast<const half8_t*>(grad + (size_t)(row0 + 16 * t + r) * 16 + 8 * g);
+            else bg[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        half8_t xin[NT][KS0];
+#pragma unroll
+        for (int ks = 0; ks < KS0; ks++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (32 * ks + 8 * g < IN) xin[t][ks] = *reinterpret_cast<const half8_t*>(X + (size_t)(row0 + 16 * t + r) * IN + 32 * ks + 8 * g);
+                else xin[t][ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        half4_t y[NL][NT][OT];
+#pragma unroll
+        for (int j = 0; j < NL; j++)
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++)
+                    y[j][t][ot] = *reinterpret_cast<const half4_t*>(fwd + (size_t)(NL - 1 - j) * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN +
+                                                                    16 * ot + 4 * g);
+
+        // ---- dL/d(last hidden activation) = W_out^T . grad^T
+        float4_t acc[NT][OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) {
+            const half8_t a = frags[(size_t)ot * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t][ot] = mfma16(a, bg[t], zero);
+        }
+        // A operands (lane = output neuron, slots = the 32 batch rows) of the gradient whose matrix comes next: first dL/dOut
+        half8_t Aprev[OT];
+        Aprev[0] = pack_operand(mfma16(bg[0], sel0, zero), mfma16(bg[1], sel0, zero));
+
+        half8_t bop[NT][KSH];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            // B operands (lane = input neuron, slots = batch rows) from the activations of layer NL-1-j = the inputs of the matrix
+            // whose gradient Aprev holds
+            half8_t Bm[OT];
+#pragma unroll
+            for (int s = 0; s < KSH; s++) {
+                half8_t x0, x1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    x0[q] = y[j][0][2 * s][q]; x0[4 + q] = y[j][0][2 * s + 1][q];
+                    x1[q] = y[j][1][2 * s][q]; x1[4 + q] = y[j][1][2 * s + 1][q];
+                }
+                Bm[2 * s] = pack_operand(mfma16(x0, selP0, zero), mfma16(x1, selP0, zero));
+                Bm[2 * s + 1] = pack_operand(mfma16(x0, selP1, zero), mfma16(x1, selP1, zero));
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int b = 0; b < OT; b++) gw_out[0][b] = mfma16(Aprev[0], Bm[b], gw_out[0][b]);
+            } else {
+#pragma unroll
+                for (int a = 0; a < OT; a++)
+#pragma unroll
+                    for (int b = 0; b < OT; b++) gw_hid[NL - 1 - j][a][b] = mfma16(Aprev[a], Bm[b], gw_hid[NL - 1 - j][a][b]);
+            }
+
+            // through the activation of layer NL-1-j (same arithmetic as ffmlp_dgrad_kernel), repack as next operand
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[t][ot][q] = act_backward(act, (float)(half_t)acc[t][ot][q], (float)y[j][t][ot][q]);
+#pragma unroll
+                for (int s = 0; s < KSH; s++) bop[t][s] = pack_operand(acc[t][2 * s], acc[t][2 * s + 1]);
+            }
+#pragma unroll
+            for (int s = 0; s < KSH; s++) {
+                Aprev[2 * s] = pack_operand(mfma16(bop[0][s], selP0, zero), mfma16(bop[1][s], selP0, zero));
+                Aprev[2 * s + 1] = pack_operand(mfma16(bop[0][s], selP1, zero), mfma16(bop[1][s], selP1, zero));
+            }
+            if (j + 1 < NL) {
+                const half8_t* fl = frags + (size_t)(base_hidden + j * per_hidden) * 64;  // W_{NL-1-j}^T
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) {
+                    float4_t c[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) c[t] = zero;
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ks++) {
+                        const half8_t a = fl[(size_t)(ot * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t][ot] = c[t];
+                }
+            }
+        }
+
+        // ---- first matrix: dW_0 += dPre_0^T . X
+        {
+            half8_t Bx[2 * KS0];
+#pragma unroll
+            for (int ks = 0; ks < KS0; ks++) {
+                Bx[2 * ks] = pack_operand(mfma16(xin[0][ks], sel0, zero), mfma16(xin[1][ks], sel0, zero));
+                Bx[2 * ks + 1] = pack_operand(mfma16(xin[0][ks], sel1, zero), mfma16(xin[1][ks], sel1, zero));
+            }
+#pragma unroll
+            for (int a = 0; a < OT; a++)
+#pragma unroll
+                for (int b = 0; b < IT; b++) gw_in[a][b] = mfma16(Aprev[a], Bx[b], gw_in[a][b]);
+        }
+
+        if (grad_inputs) {  // dL/dX = W_0^T . dPre_0, no activation (ffmlp.cu:880-887)
+            const half8_t* fi = frags + (size_t)base_in * 64;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                float4_t c[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) c[t] = zero;
+#pragma unroll
+                for (int ks = 0; ks < KSH; ks++) {
+                    const half8_t a = fi[(size_t)(it * KSH + ks) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) store4(grad_inputs + (size_t)(row0 + 16 * t + r) * IN + 16 * it + 4 * g, c[t]);
+            }
+        }
+    }
+
+    // ---- combine the 4 waves in LDS (one matrix at a time, <= 16 tiles = 64 KiB), one fp32 partial row per workgroup
+    float* red = reinterpret_cast<float*>(smem);
+    float* out = partials + (size_t)blockIdx.x * n_params;
+    flush_tiles<OT, IT>(gw_in, red, out, IN, wave, lane);
+#pragma unroll
+    for (int l = 0; l < NL - 1; l++) flush_tiles<OT, OT>(gw_hid[l], red, out + HIDDEN * IN + l * HIDDEN * HIDDEN, HIDDEN, wave, lane);
+    flush_tiles<1, OT>(gw_out, red, out + HIDDEN * IN + (NL - 1) * HIDDEN * HIDDEN, HIDDEN, wave, lane);
+}
+
 // sum the per-workgroup partials: 64 consecutive parameters x 4 slices of the partial list per workgroup
 // (256-B coalesced reads), LDS combine of the 4 slices, one fp16 store per parameter
 __global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_parts,
@@ -558,6 +795,47 @@ int launch_dgrad(const void* grad, const void* weights, const void* fwd, void* b
     return check_launch("ffmlp_backward(dgrad)");
 }
 
+template <int H, int NL, int IT>
+int launch_fused(const void* grad, const void* inputs, const void* weights, const void* fwd, void* grad_inputs, uint32_t B, uint32_t act,
+                 uint32_t n_params, void* grad_weights, hipStream_t st) {
+    size_t lds = lds_bytes_dgrad(H, 16 * IT, NL, true);
+    if (lds < 64 * 1024) lds = 64 * 1024;  // the end-of-kernel combine reuses the fragment area
+    int rc = lds_check(lds);
+    if (rc != NERFTEX_OK) return rc;
+    auto kernel = ffmlp_backward_fused_kernel<H, NL, IT>;
+    NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    uint32_t n_parts = B / kRowsPerBlock;
+    if (n_parts > (uint32_t)num_cus()) n_parts = (uint32_t)num_cus();  // one workgroup (4 waves, one per SIMD) per CU
+    float* partials = static_cast<float*>(workspace(kWsMlp, sizeof(float) * (size_t)n_parts * n_params));
+    if (!partials) return NERFTEX_ERR_HIP;
+    {
+        KernelTimer kt("ffmlp_backward_fused_kernel", st);
+        hipLaunchKernelGGL(kernel, dim3(n_parts), dim3(kBlockThreads), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
+                           (const half_t*)fwd, (half_t*)grad_inputs, B, act, partials, n_params);
+    }
+    rc = check_launch("ffmlp_backward(fused)");
+    if (rc != NERFTEX_OK) return rc;
+    {
+        KernelTimer kt("ffmlp_wgrad_reduce_kernel", st);
+        hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, 64u)), dim3(kBlockThreads), 0, st, partials, n_parts, n_params,
+                           static_cast<half_t*>(grad_weights));
+    }
+    return check_launch("ffmlp_backward(reduce)");
+}
+
+// -1: no fused instantiation for this shape
+int launch_backward_fused(const void* grad, const void* inputs, const void* weights, const void* fwd, void* grad_inputs, uint32_t B, uint32_t IN,
+                          uint32_t H, uint32_t NL, uint32_t act, uint32_t n_params, void* grad_weights, hipStream_t st) {
+    if (H != 64 || IN % 16 != 0 || IN > 64 || NL < 2 || NL > 4) return -1;
+#define NERFTEX_FUSED_CASE(nl, it) \
+    if (NL == nl && IN == 16 * it) return launch_fused<64, nl, it>(grad, inputs, weights, fwd, grad_inputs, B, act, n_params, grad_weights, st);
+    NERFTEX_FUSED_CASE(2, 1) NERFTEX_FUSED_CASE(2, 2) NERFTEX_FUSED_CASE(2, 3) NERFTEX_FUSED_CASE(2, 4)
+    NERFTEX_FUSED_CASE(3, 1) NERFTEX_FUSED_CASE(3, 2) NERFTEX_FUSED_CASE(3, 3) NERFTEX_FUSED_CASE(3, 4)
+    NERFTEX_FUSED_CASE(4, 1) NERFTEX_FUSED_CASE(4, 2) NERFTEX_FUSED_CASE(4, 3) NERFTEX_FUSED_CASE(4, 4)
+#undef NERFTEX_FUSED_CASE
+    return -1;
+}
+
 }  // namespace
 }  // namespace nerftex
 
@@ -602,6 +880,15 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     hipStream_t st = as_stream(stream);
     const uint32_t H = hidden_dim, IN = input_dim, NL = num_layers;
     void* gi = calc_grad_inputs ? grad_inputs : nullptr;
+    const uint32_t n_params = H * (IN + H * (NL - 1) + 16);
+
+    {   // fused activation + weight gradients (the default where instantiated): backward_buffer stays untouched
+        const char* mode = getenv("NERFTEX_FFMLP_BWD");  // "split" = dgrad kernel, then wgrad kernel through backward_buffer
+        if (!(mode && mode[0] == 's')) {
+            rc = launch_backward_fused(grad, inputs, weights, forward_buffer, gi, B, IN, H, NL, activation, n_params, grad_weights, st);
+            if (rc >= 0) return rc;  // rc < 0: shape not instantiated -> split path below
+        }
+    }
 
     switch (H) {
         case 16: rc = launch_dgrad<16>(grad, weights, forward_buffer, backward_buffer, gi, B, IN, NL, activation, st); break;
@@ -613,7 +900,6 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     if (rc != NERFTEX_OK) return rc;
 
     // weight gradients: one launch over (batch chunks, matrices), then the cross-workgroup reduction
-    const uint32_t n_params = H * (IN + H * (NL - 1) + 16);
     const size_t LS = (size_t)B * H;
     const half_t* fb = static_cast<const half_t*>(forward_buffer);
     const half_t* bb = static_cast<const half_t*>(backward_buffer);

@@ -86,11 +86,16 @@ def test_ffmlp_forward_and_inference(oracle, dev, case):
     assert np.array_equal(inf_out, got_out), "inference kernel must equal the training forward bit for bit"
 
 
+@pytest.mark.parametrize("mode", ["fused", "split"])
 @pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4], CASES[5]], ids=lambda c: f"in{c[0]}_h{c[1]}_L{c[2]}_act{c[3]}")
-def test_ffmlp_backward(oracle, dev, case):
+def test_ffmlp_backward(oracle, dev, case, mode, monkeypatch):
+    """mode "fused" (default): activation + weight gradients in one kernel, backward_buffer untouched (hidden 64, 2-4 layers,
+    input <= 64; other shapes fall through to the split kernels).  mode "split": dgrad kernel -> backward_buffer -> wgrad kernel."""
     from nerftex_hip import check, lib, ptr, stream
 
+    monkeypatch.setenv("NERFTEX_FFMLP_BWD", mode)
     IN, H, NL, act, B, w, x = _setup(case, 32)
+    fused = mode == "fused" and H == 64 and 2 <= NL <= 4 and IN <= 64
     _, fb = oracle.ffmlp_forward(x, w, IN, 16, H, NL, act, 6)  # same forward activations on both sides
     rng = np.random.default_rng(33)
     grad = (rng.standard_normal((B, 16)) * 1e-2).astype(np.float16)
@@ -104,9 +109,13 @@ def test_ffmlp_backward(oracle, dev, case):
     torch.cuda.synchronize()
     bb, gi, gw = bb.cpu().numpy(), gi.cpu().numpy(), gw.cpu().numpy()
     gscale = float(np.abs(want_bb.astype(np.float32)).max())
-    _close_half(bb[0], want_bb[0], ulps=1.5, floor=1e-3 * gscale)
-    for j in range(1, NL):
-        _close_half(bb[j], want_bb[j], ulps=6.0, floor=2e-2 * gscale)
+    if fused:
+        assert not bb.any(), "the fused backward must not touch backward_buffer"
+        bb = want_bb  # the isolated dW0 check below then runs against the oracle's dPre
+    else:
+        _close_half(bb[0], want_bb[0], ulps=1.5, floor=1e-3 * gscale)
+        for j in range(1, NL):
+            _close_half(bb[j], want_bb[j], ulps=6.0, floor=2e-2 * gscale)
     _close_half(gi, want_gi, ulps=8.0, floor=0.1 * float(np.abs(want_gi.astype(np.float32)).max()))
     # weight gradients: the oracle uses ITS OWN bb; feed differences are <= a few half-ulps per element and average out
     wscale = float(np.abs(want_gw.astype(np.float32)).max())
@@ -115,7 +124,7 @@ def test_ffmlp_backward(oracle, dev, case):
     # exact check of the wgrad kernel in isolation: recompute from the HIP bb in float64
     P0 = H * IN
     dW0 = bb[NL - 1].astype(np.float64).T @ x.astype(np.float64)
-    np.testing.assert_allclose(gw[:P0].astype(np.float64).reshape(H, IN), dW0, rtol=2e-3, atol=2e-3 * np.abs(dW0).max())
+    np.testing.assert_allclose(gw[:P0].astype(np.float64).reshape(H, IN), dW0, rtol=2e-3, atol=(4e-3 if fused else 2e-3) * np.abs(dW0).max())
     dWo = grad.astype(np.float64).T @ fb[NL - 1].astype(np.float64)
     np.testing.assert_allclose(gw[-16 * H:].astype(np.float64).reshape(16, H), dWo, rtol=2e-3, atol=2e-3 * np.abs(dWo).max())
 
