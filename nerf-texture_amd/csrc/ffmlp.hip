@@ -114,7 +114,7 @@ __device__ __forceinline__ void store4(half_t* p, const float4_t& v) {
 // ------------------------------------------------------------------------------------------------
 // forward / inference
 // ------------------------------------------------------------------------------------------------
-template <int HIDDEN, bool INFERENCE>
+template <int HIDDEN, bool INFERENCE, bool STAGED>  // STAGED: forward_buffer rows leave through an LDS patch (needs the LDS room)
 __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half_t* __restrict__ X, const half_t* __restrict__ W,
                                                                       half_t* __restrict__ fwd, half_t* __restrict__ out, uint32_t B,
                                                                       uint32_t IN, uint32_t NL, uint32_t act, uint32_t out_act) {
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half
     const int base_hidden = OT * KS0;             // first fragment of matrix 1
     const int per_hidden = OT * KSH;
     const int base_out = base_hidden + (NL - 1) * per_hidden;
+    const size_t patch_offset = (size_t)(base_out + KSH) * 1024;  // after the last fragment (16 x HIDDEN output matrix)
     stage_fragments(frags, W, IN, false, HIDDEN, IN, false);
     for (uint32_t l = 1; l < NL; l++)
         stage_fragments(frags + (size_t)(base_hidden + (l - 1) * per_hidden) * 64, W + (size_t)HIDDEN * IN + (size_t)(l - 1) * HIDDEN * HIDDEN,
@@ -138,6 +139,10 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const size_t layer_stride = (size_t)B * HIDDEN;
+    // training: a wave's 32 x HIDDEN activation block goes through a private LDS patch so that it leaves as whole rows
+    // (1 KiB contiguous per store instruction) instead of 8-B pieces of 16 different rows
+    constexpr int kRowPitch = HIDDEN + 8;  // halfs; +16 B keeps ds_read_b128 alignment and staggers the banks
+    half_t* patch = reinterpret_cast<half_t*>(smem + patch_offset) + (size_t)wave * 16 * NT * kRowPitch;
 
     for (uint32_t row0 = blockIdx.x * kRowsPerBlock + wave * 16 * NT; row0 < B; row0 += gridDim.x * kRowsPerBlock) {
         float4_t acc[NT][OT];
@@ -172,13 +177,25 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half
                 for (int ot = 0; ot < OT; ot++) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[t][ot][j] = act_forward(act, acc[t][ot][j]);
-                    if constexpr (!INFERENCE)
-                        store4(fwd + l * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g, acc[t][ot]);
+                    if constexpr (!INFERENCE) {
+                        if constexpr (STAGED) store4(patch + (size_t)(16 * t + r) * kRowPitch + 16 * ot + 4 * g, acc[t][ot]);
+                        else store4(fwd + l * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g, acc[t][ot]);
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < KSH; s++) {
                     const float4_t zero{0, 0, 0, 0};
                     bop[t][s] = pack_operand(acc[t][2 * s], (2 * s + 1 < OT) ? acc[t][(2 * s + 1 < OT) ? 2 * s + 1 : 0] : zero);
+                }
+            }
+            if constexpr (!INFERENCE && STAGED) {  // patch -> forward_buffer[l], 16 B per lane, rows are contiguous in memory
+                constexpr int kPieces = HIDDEN / 8;  // 16-B pieces per row
+                half_t* dst = fwd + l * layer_stride + (size_t)row0 * HIDDEN;
+#pragma unroll
+                for (int it = 0; it < 16 * NT * kPieces / 64; it++) {
+                    const int c = it * 64 + lane, row = c / kPieces, piece = c % kPieces;
+                    *reinterpret_cast<half8_t*>(dst + (size_t)row * HIDDEN + 8 * piece) =
+                        *reinterpret_cast<const half8_t*>(patch + (size_t)row * kRowPitch + 8 * piece);
                 }
             }
             if (l + 1 >= NL) break;
@@ -719,8 +736,9 @@ int validate(uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidde
     return NERFTEX_OK;
 }
 
-size_t lds_bytes_forward(uint32_t H, uint32_t IN, uint32_t NL) {
-    return (size_t)(frag_count(H, IN) + (NL - 1) * frag_count(H, H) + frag_count(16, H)) * 1024;
+size_t lds_bytes_forward(uint32_t H, uint32_t IN, uint32_t NL, bool training) {
+    const size_t frags = (size_t)(frag_count(H, IN) + (NL - 1) * frag_count(H, H) + frag_count(16, H)) * 1024;
+    return frags + (training ? (size_t)4 * 16 * kTilesPerWave * (H + 8) * sizeof(half_t) : 0);  // + the per-wave store patches
 }
 size_t lds_bytes_dgrad(uint32_t H, uint32_t IN, uint32_t NL, bool with_inputs) {
     return (size_t)(frag_count(H, 16) + (NL - 1) * frag_count(H, H) + (with_inputs ? frag_count(IN, H) : 0)) * 1024;
@@ -752,10 +770,11 @@ uint32_t persistent_grid(uint32_t B, size_t lds) {
 template <int H, bool INF>
 int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t IN, uint32_t NL, uint32_t act, uint32_t out_act,
                    void* fwd, void* outputs, hipStream_t st) {
-    const size_t lds = lds_bytes_forward(H, IN, NL);
+    const bool staged = !INF && lds_bytes_forward(H, IN, NL, true) <= kLdsLimit / 2;  // keep two workgroups per CU
+    const size_t lds = lds_bytes_forward(H, IN, NL, staged);
     int rc = lds_check(lds);
     if (rc != NERFTEX_OK) return rc;
-    auto kernel = ffmlp_forward_kernel<H, INF>;
+    auto kernel = staged ? ffmlp_forward_kernel<H, INF, true> : ffmlp_forward_kernel<H, INF, false>;
     rc = set_lds(kernel, lds);
     if (rc != NERFTEX_OK) return rc;
     {
