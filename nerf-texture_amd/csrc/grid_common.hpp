@@ -102,6 +102,21 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, float (&v)[C])
     }
 }
 
+// two adjacent rows (2C consecutive features) in one load; the address is only row-aligned (C * sizeof(T))
+template <typename T, int C>
+inline constexpr bool kHasPairLoad = (C == 1) || (C == 2) || (C == 4 && sizeof(T) == 2);
+template <typename T, int C>
+__device__ __forceinline__ void load_row_pair(const T* __restrict__ p, float (&a)[C], float (&b)[C]) {
+    using V = typename Vec<T, 2 * C>::type;
+    typedef V __attribute__((aligned(C * sizeof(T)))) VU;
+    const V v = *reinterpret_cast<const VU*>(p);
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        a[i] = (float)v[i];
+        b[i] = (float)v[C + i];
+    }
+}
+
 template <typename T, int C>
 __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]) {
     if constexpr (C == 8 && sizeof(T) == 4) {

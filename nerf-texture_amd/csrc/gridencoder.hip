@@ -214,21 +214,35 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     float g[1 << D][C];
     float w[1 << D];
 #pragma unroll
-    for (int idx = 0; idx < (1 << D); idx++) {
+    for (int idx = 0; idx < (1 << D); idx++) {  // weights in the reference's dimension order (gridencoder.cu:150-164)
         float wi = 1;
-        uint32_t p[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            if ((idx & (1 << d)) == 0) {
-                wi *= 1 - pos[d];
-                p[d] = pos_grid[d];
-            } else {
-                wi *= pos[d];
-                p[d] = pos_grid[d] + 1;
-            }
-        }
+        for (int d = 0; d < D; d++) wi *= (idx & (1 << d)) ? pos[d] : 1 - pos[d];
         w[idx] = wi;
-        load_row<T, C>(table + (size_t)index_of(p) * C, g[idx]);
+    }
+    // corners come in x-neighbour pairs (idx = 2q, 2q+1).  Their rows are adjacent on dense levels and, prime[0] being 1, on
+    // hashed levels whenever the cell's x is even: one 2-row load then replaces two gathers -- the gather pipe retires about one
+    // LANE-request per clock per CU, so requests are what this kernel is made of.  Same values, same accumulation order.
+#pragma unroll
+    for (int q = 0; q < (1 << (D - 1)); q++) {
+        uint32_t p[D];
+        p[0] = pos_grid[0];
+#pragma unroll
+        for (int d = 1; d < D; d++) p[d] = pos_grid[d] + ((q >> (d - 1)) & 1);
+        const uint32_t ra = index_of(p);
+        p[0] = pos_grid[0] + 1;
+        const uint32_t rb = index_of(p);
+        if constexpr (kHasPairLoad<T, C>) {
+            if (rb == ra + 1) {
+                load_row_pair<T, C>(table + (size_t)ra * C, g[2 * q], g[2 * q + 1]);
+            } else {
+                load_row<T, C>(table + (size_t)ra * C, g[2 * q]);
+                load_row<T, C>(table + (size_t)rb * C, g[2 * q + 1]);
+            }
+        } else {
+            load_row<T, C>(table + (size_t)ra * C, g[2 * q]);
+            load_row<T, C>(table + (size_t)rb * C, g[2 * q + 1]);
+        }
     }
     float r[C];
 #pragma unroll
