@@ -162,6 +162,60 @@ struct Dda {
     // One iteration at parameter t.  Occupied: returns true with the sample (x,y,z,dt), t untouched.
     // Empty: advances t past the voxel and returns false.
     __device__ __forceinline__ bool step(float& t, float& x, float& y, float& z, float& dt) const {
+        float tt;
+        if (probe(t, x, y, z, dt, tt)) return true;
+        do {
+            t += next_dt(t);
+        } while (t < tt);
+        return false;
+    }
+
+    // the step rule shared by both branches of the reference loop: an accepted sample advances by dt = clamp(t * dt_gamma, ..),
+    // a skipped voxel by repeating exactly that until its exit parameter is passed (raymarching.cu:385-401)
+    __device__ __forceinline__ float next_dt(float t) const { return clampf(t * dt_gamma, dt_min, dt_max); }
+
+    // probe() in two halves for the data-parallel count pass (same expressions): locate() finds the voxel of parameter t and
+    // returns its bit index in the occupancy field, exit_of() computes the parameter at which the ray leaves that voxel.
+    struct Cell {
+        float x, y, z;
+        uint32_t packed;  // nx | ny << 8 | nz << 16 | level << 24 | (bit index & 7) << 29   (H <= 256, level < 16)
+    };
+    __device__ __forceinline__ uint32_t locate(float t, Cell& c) const {
+        c.x = clampf(fmaf(t, dx, ox), -bound, bound);
+        c.y = clampf(fmaf(t, dy, oy), -bound, bound);
+        c.z = clampf(fmaf(t, dz, oz), -bound, bound);
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const int la = mip_from_pos(c.x, c.y, c.z, Cf), lb = mip_from_dt(dt, Hf, Cf);
+        const int level = la > lb ? la : lb;
+        const float p2 = (float)(1 << level);
+        const float mip_rbound = p2 <= bound ? __builtin_bit_cast(float, (uint32_t)(127 - level) << 23) : rbound;
+        float fx, fy, fz;
+        if (pow2H) {
+            fx = fmaf(c.x, mip_rbound, 1.0f) * halfH;
+            fy = fmaf(c.y, mip_rbound, 1.0f) * halfH;
+            fz = fmaf(c.z, mip_rbound, 1.0f) * halfH;
+        } else {
+            fx = (float)(0.5 * (double)fmaf(c.x, mip_rbound, 1.0f) * Hd);
+            fy = (float)(0.5 * (double)fmaf(c.y, mip_rbound, 1.0f) * Hd);
+            fz = (float)(0.5 * (double)fmaf(c.z, mip_rbound, 1.0f) * Hd);
+        }
+        const uint32_t nx = (uint32_t)(int)clampf(fx, 0.0f, hi), ny = (uint32_t)(int)clampf(fy, 0.0f, hi), nz = (uint32_t)(int)clampf(fz, 0.0f, hi);
+        const uint32_t index = (uint32_t)level * H3 + morton3D(nx, ny, nz);
+        c.packed = nx | (ny << 8) | (nz << 16) | ((uint32_t)level << 24) | ((index & 7u) << 29);
+        return index;
+    }
+    __device__ __forceinline__ float exit_of(float t, const Cell& c) const {
+        const uint32_t nx = c.packed & 0xffu, ny = (c.packed >> 8) & 0xffu, nz = (c.packed >> 16) & 0xffu, level = (c.packed >> 24) & 0x1fu;
+        const float mip_bound = fminf((float)(1u << level), bound);
+        const float tx = fmaf(fmaf(fmaf(0.5f, sx, (float)nx + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -c.x) * rdx;
+        const float ty = fmaf(fmaf(fmaf(0.5f, sy, (float)ny + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -c.y) * rdy;
+        const float tz = fmaf(fmaf(fmaf(0.5f, sz, (float)nz + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -c.z) * rdz;
+        return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+
+    // Classify parameter t without advancing: true = occupied, sample (x,y,z,dt); false = empty, tt = parameter at which the ray
+    // leaves the voxel.  A pure function of t.
+    __device__ __forceinline__ bool probe(float t, float& x, float& y, float& z, float& dt, float& tt) const {
         x = clampf(fmaf(t, dx, ox), -bound, bound);
         y = clampf(fmaf(t, dy, oy), -bound, bound);
         z = clampf(fmaf(t, dz, oz), -bound, bound);
@@ -191,14 +245,12 @@ struct Dda {
         const int nz = (int)clampf(fz, 0.0f, hi);
         const uint32_t index = (uint32_t)level * H3 + morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
         const bool occ = grid[index >> 3] & (1u << (index & 7u));
+        tt = t;
         if (occ) return true;
         const float tx = fmaf(fmaf(fmaf(0.5f, sx, (float)nx + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
         const float ty = fmaf(fmaf(fmaf(0.5f, sy, (float)ny + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
         const float tz = fmaf(fmaf(fmaf(0.5f, sz, (float)nz + 0.5f) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        do {
-            t += clampf(t * dt_gamma, dt_min, dt_max);
-        } while (t < tt);
+        tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         return false;
     }
 };
@@ -292,6 +344,195 @@ __device__ __forceinline__ float ray_t0(const Dda& s, float near, uint32_t pertu
         t0 = fmaf(s.dt_min, rng.next_float(), t0);
     }
     return t0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// R6 count pass, data-parallel form
+// ------------------------------------------------------------------------------------------------
+// The serial DDA costs ~230 iterations x ~1200 clocks per wave whatever is done to its memory accesses: it is issue-bound on
+// ONE wave per 64 rays.  But the parameters a ray can visit do not depend on the occupancy at all: both branches of the loop
+// advance by the same rule, so every visited t is a member of the fixed sequence T_0 = t0, T_{k+1} = T_k + clamp(T_k*dt_gamma,..),
+// and the loop merely decides which members it lands on:
+//     k -> k + 1                              if the voxel at T_k is occupied (T_k is a sample),
+//     k -> first j > k with T_j >= tt(T_k)    otherwise (tt = exit parameter of the voxel at T_k).
+// So, per workgroup of 32 rays and per segment of 128 sequence members:
+//   phase 1  one lane per ray generates T (3 dependent instructions per member instead of a whole DDA iteration),
+//   phase 2  all 256 threads classify all (ray, k) in parallel with the very same probe() and store the jump distance,
+//   phase 3  one lane per ray follows the jumps through LDS and logs the members it lands on as samples.
+// Same floating-point expressions on the same values as the serial loop: the samples are bit-identical.
+constexpr uint32_t kMcRays = 32;      // rays per workgroup (8 threads per ray in phases 2 and 4)
+constexpr uint32_t kMcSeg = 128;      // sequence members per segment (jump distances fit a byte)
+constexpr uint32_t kMcThreads = 256;
+constexpr uint32_t kMcPer = kMcSeg / 8;      // members per thread in phases 2 / 4
+constexpr uint32_t kMcTPitch = kMcRays + 1;  // T[k][ray], +1: conflict-free for both access patterns
+constexpr uint32_t kMcJPitch = kMcSeg + 4;   // jump[ray][k] / visited[ray][k] bytes, +4: rows start in different banks
+
+__global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                         const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                                         const float* __restrict__ nears, const float* __restrict__ fars,
+                                                                         int* __restrict__ rays, const int* __restrict__ counter,
+                                                                         uint32_t* __restrict__ ws, uint32_t perturb, float* __restrict__ tlog) {
+    __shared__ float s_T[kMcSeg * kMcTPitch];
+    __shared__ uint8_t s_jump[kMcRays * kMcJPitch];
+    __shared__ uint8_t s_vis[kMcRays * kMcJPitch];  // 1 = this member is a sample of the ray
+    __shared__ uint32_t s_cnt[kMcRays];             // members of this segment below far
+    __shared__ uint32_t s_full[kMcRays];            // the sequence continues in the next segment
+    __shared__ uint32_t s_base[kMcRays];            // samples of this ray logged before this segment
+    __shared__ uint32_t s_live;
+
+    const uint32_t tid = threadIdx.x;
+    // phase-1/3 role: lane r < 32 of wave 0 owns ray r.  phase-2/4 role: thread tid works for ray tid / 8
+    const uint32_t own = tid, n_own = blockIdx.x * kMcRays + own;
+    const bool owner = tid < kMcRays && n_own < N;
+    const uint32_t r2 = tid / 8, sub = tid % 8, n2 = blockIdx.x * kMcRays + r2;
+    const bool has2 = n2 < N;
+    const Dda s2(rays_o + 3 * (size_t)(has2 ? n2 : 0), rays_d + 3 * (size_t)(has2 ? n2 : 0), bound, dt_gamma, max_steps, C, H, grid,
+                 has2 ? fars[n2] : 0.0f);
+    float* log_row2 = tlog + (size_t)(has2 ? n2 : 0) * max_steps;
+
+    // owner state
+    float t_next = 0.0f, far = 0.0f, pending_tt = 0.0f;
+    bool pending = false, done = true;
+    uint32_t num = 0;
+    if (owner) {
+        far = fars[n_own];
+        t_next = ray_t0(s2, nears[n_own], perturb, n_own, 42);  // s2.dt_min is all ray_t0 reads: the same for every ray
+        done = !(t_next < far);
+    }
+    const float dt_min = s2.dt_min, dt_max = s2.dt_max;
+
+    for (;;) {
+        if (tid == 0) s_live = 0;
+        for (uint32_t i = tid; i < kMcRays * kMcJPitch / 4; i += kMcThreads) reinterpret_cast<uint32_t*>(s_vis)[i] = 0u;
+        __syncthreads();
+        // ---- phase 1: the next kMcSeg members of the sequence (a 4-instruction dependent chain per member)
+        if (tid < kMcRays) {
+            uint32_t cnt = 0;
+            if (owner && !done) {
+                float t = t_next;
+#pragma unroll 4
+                while (cnt < kMcSeg && t < far) {
+                    s_T[cnt * kMcTPitch + own] = t;
+                    t += clampf(t * dt_gamma, dt_min, dt_max);
+                    cnt++;
+                }
+                t_next = t;
+                atomicOr(&s_live, 1u);
+            }
+            s_cnt[own] = cnt;
+            s_full[own] = (owner && !done && cnt == kMcSeg && t_next < far) ? 1u : 0u;
+            s_base[own] = num;
+        }
+        __syncthreads();
+        if (s_live == 0) break;
+
+        // ---- phase 2: classify every member; jump = 0 for a sample, else the distance to the first member at or past the voxel exit.
+        // All occupancy bytes of a thread's 16 members are requested before any is used (one memory latency, not sixteen); the
+        // voxel found on the way is kept (4 registers per member) for the exit computation.
+        {
+            const uint32_t cnt = s_cnt[r2];
+            Dda::Cell cell[kMcPer];
+            uint8_t occ_byte[kMcPer];
+#pragma unroll
+            for (uint32_t i = 0; i < kMcPer; i++) {
+                const uint32_t k = sub + 8 * i;
+                occ_byte[i] = 0;
+                cell[i] = Dda::Cell{};
+                if (k < cnt) {
+                    const uint32_t index = s2.locate(s_T[k * kMcTPitch + r2], cell[i]);
+                    occ_byte[i] = grid[index >> 3];
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kMcPer; i++) {
+                const uint32_t k = sub + 8 * i;
+                if (k < cnt) {
+                    uint32_t jump = 0;
+                    if (!((occ_byte[i] >> (cell[i].packed >> 29)) & 1u)) {
+                        const float t = s_T[k * kMcTPitch + r2];
+                        const float tt = s2.exit_of(t, cell[i]);
+                        uint32_t j = k + 1;  // the reference's do-while moves at least one member on
+                        while (j < cnt && s_T[j * kMcTPitch + r2] < tt) j++;
+                        jump = j - k;
+                    }
+                    s_jump[r2 * kMcJPitch + k] = (uint8_t)jump;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: follow the jumps; nothing but the hop itself is on the dependent chain (samples are only MARKED here)
+        if (owner && !done) {
+            const uint32_t cnt = s_cnt[own];
+            const bool full = s_full[own] != 0;
+            const uint8_t* jr = s_jump + own * kMcJPitch;
+            uint8_t* vr = s_vis + own * kMcJPitch;
+            uint32_t k = 0;
+            if (pending) {  // a voxel skipped across the segment boundary: keep skipping until its exit is passed
+                while (k < cnt && s_T[k * kMcTPitch + own] < pending_tt) k++;
+                pending = k == cnt && full;
+            }
+            uint32_t last_skip = 0xffffffffu;  // member whose skip ran to the end of a full segment
+            while (k < cnt && num < max_steps) {
+                const uint32_t j = jr[k];
+                if (j == 0) {
+                    vr[k] = 1;
+                    num++;
+                    k++;
+                } else {
+                    if (k + j == cnt) last_skip = k;
+                    k += j;
+                }
+            }
+            if (full && last_skip != 0xffffffffu && k == cnt && num < max_steps) {  // the skip may continue into the next segment
+                Dda::Cell c;
+                const float t = s_T[last_skip * kMcTPitch + own];
+                const Dda so(rays_o + 3 * (size_t)n_own, rays_d + 3 * (size_t)n_own, bound, dt_gamma, max_steps, C, H, grid, far);
+                (void)so.locate(t, c);
+                pending_tt = so.exit_of(t, c);
+                pending = true;
+            }
+            if (!full || num >= max_steps) done = true;
+        }
+        __syncthreads();
+
+        // ---- phase 4: log the marked members, 8 threads per ray, in order
+        {
+            uint32_t mine = 0;
+            uint32_t flags = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kMcPer; i++) {
+                const uint32_t k = sub * kMcPer + i;  // consecutive members per thread
+                const uint32_t v = s_vis[r2 * kMcJPitch + k];
+                flags |= v << i;
+                mine += v;
+            }
+            uint32_t incl = mine;  // inclusive scan over the 8 threads of the ray (lanes 8 r2' .. 8 r2' + 7 of the wave)
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 8);
+                if ((int)sub >= off) incl += o;
+            }
+            uint32_t at = s_base[r2] + incl - mine;
+            if (has2 && flags) {
+#pragma unroll
+                for (uint32_t i = 0; i < kMcPer; i++)
+                    if ((flags >> i) & 1u) log_row2[at++] = s_T[(sub * kMcPer + i) * kMcTPitch + r2];
+            }
+        }
+        __syncthreads();  // s_vis / s_T are rewritten by the next segment
+    }
+
+    if (owner) rays[3 * (size_t)n_own + 2] = (int)num;
+    // sample totals per 64-ray block (what the expand pass scans), integer atomics into the pre-zeroed ws[1..]
+    if (tid < kWave) {
+        const uint32_t wsum = wave_sum(tid < kMcRays ? num : 0u);
+        if (tid == 0) {
+            if (wsum) atomicAdd(&ws[1 + (blockIdx.x * kMcRays) / kRayBlock], wsum);
+            if (blockIdx.x == 0) ws[0] = (uint32_t)counter[0];
+        }
+    }
 }
 
 __global__ __launch_bounds__(kRayBlock) void march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -762,7 +1003,13 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     uint32_t* ws = reinterpret_cast<uint32_t*>(base);
     float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
     hipStream_t st = as_stream(stream);
-    {
+    const char* serial = getenv("NERFTEX_MARCH_COUNT");  // "serial": the one-ray-per-lane DDA (A/B switch)
+    if (use_log && H <= 256 && !(serial && serial[0] == 's')) {  // (the packed voxel of the parallel pass holds 8-bit coordinates)
+        NERFTEX_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(uint32_t) * (1 + (size_t)nblocks), st), "hipMemsetAsync");
+        KernelTimer kt("march_count_parallel_kernel", st);
+        hipLaunchKernelGGL(march_count_parallel_kernel, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                           max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog);
+    } else {
         KernelTimer kt("march_count_kernel", st);
         hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
                            C, H, nears, fars, rays, counter, ws, perturb, tlog);
