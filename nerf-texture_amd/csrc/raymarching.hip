@@ -360,10 +360,11 @@ __device__ __forceinline__ float ray_t0(const Dda& s, float near, uint32_t pertu
 //   phase 2  all 256 threads classify all (ray, k) in parallel with the very same probe() and store the jump distance,
 //   phase 3  one lane per ray follows the jumps through LDS and logs the members it lands on as samples.
 // Same floating-point expressions on the same values as the serial loop: the samples are bit-identical.
-constexpr uint32_t kMcRays = 32;      // rays per workgroup (8 threads per ray in phases 2 and 4)
+constexpr uint32_t kMcRays = 32;      // rays per workgroup
 constexpr uint32_t kMcSeg = 128;      // sequence members per segment (jump distances fit a byte)
-constexpr uint32_t kMcThreads = 256;
-constexpr uint32_t kMcPer = kMcSeg / 8;      // members per thread in phases 2 / 4
+constexpr uint32_t kMcSub = 16;       // threads per ray in phases 2 and 4 (two waves per SIMD: the phases are latency-bound)
+constexpr uint32_t kMcThreads = kMcRays * kMcSub;
+constexpr uint32_t kMcPer = kMcSeg / kMcSub;  // members per thread in phases 2 / 4
 constexpr uint32_t kMcTPitch = kMcRays + 1;  // T[k][ray], +1: conflict-free for both access patterns
 constexpr uint32_t kMcJPitch = kMcSeg + 4;   // jump[ray][k] / visited[ray][k] bytes, +4: rows start in different banks
 
@@ -382,10 +383,10 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
     __shared__ uint32_t s_live;
 
     const uint32_t tid = threadIdx.x;
-    // phase-1/3 role: lane r < 32 of wave 0 owns ray r.  phase-2/4 role: thread tid works for ray tid / 8
+    // phase-1/3 role: lane r < 32 of wave 0 owns ray r.  phase-2/4 role: thread tid works for ray tid / kMcSub
     const uint32_t own = tid, n_own = blockIdx.x * kMcRays + own;
     const bool owner = tid < kMcRays && n_own < N;
-    const uint32_t r2 = tid / 8, sub = tid % 8, n2 = blockIdx.x * kMcRays + r2;
+    const uint32_t r2 = tid / kMcSub, sub = tid % kMcSub, n2 = blockIdx.x * kMcRays + r2;
     const bool has2 = n2 < N;
     const Dda s2(rays_o + 3 * (size_t)(has2 ? n2 : 0), rays_d + 3 * (size_t)(has2 ? n2 : 0), bound, dt_gamma, max_steps, C, H, grid,
                  has2 ? fars[n2] : 0.0f);
@@ -410,12 +411,25 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
         if (tid < kMcRays) {
             uint32_t cnt = 0;
             if (owner && !done) {
+                // four members per round; clamp as one v_med3_f32 (x = t * dt_gamma is a positive finite number, so the median of
+                // (x, dt_min, dt_max) IS fmin(dt_max, fmax(dt_min, x))): 3 dependent instructions per member
                 float t = t_next;
-#pragma unroll 4
-                while (cnt < kMcSeg && t < far) {
-                    s_T[cnt * kMcTPitch + own] = t;
-                    t += clampf(t * dt_gamma, dt_min, dt_max);
-                    cnt++;
+                while (cnt < kMcSeg) {  // kMcSeg % 4 == 0
+                    const float t0 = t;
+                    const float t1 = t0 + __builtin_amdgcn_fmed3f(t0 * dt_gamma, dt_min, dt_max);
+                    const float t2 = t1 + __builtin_amdgcn_fmed3f(t1 * dt_gamma, dt_min, dt_max);
+                    const float t3 = t2 + __builtin_amdgcn_fmed3f(t2 * dt_gamma, dt_min, dt_max);
+                    s_T[(cnt + 0) * kMcTPitch + own] = t0;
+                    s_T[(cnt + 1) * kMcTPitch + own] = t1;
+                    s_T[(cnt + 2) * kMcTPitch + own] = t2;
+                    s_T[(cnt + 3) * kMcTPitch + own] = t3;
+                    if (!(t3 < far)) {  // the sequence leaves the box inside this round (members are increasing)
+                        cnt += (t0 < far ? 1u : 0u) + (t1 < far ? 1u : 0u) + (t2 < far ? 1u : 0u);
+                        t = far;  // anything not below far: the ray is finished after this segment
+                        break;
+                    }
+                    cnt += 4;
+                    t = t3 + __builtin_amdgcn_fmed3f(t3 * dt_gamma, dt_min, dt_max);
                 }
                 t_next = t;
                 atomicOr(&s_live, 1u);
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
             uint8_t occ_byte[kMcPer];
 #pragma unroll
             for (uint32_t i = 0; i < kMcPer; i++) {
-                const uint32_t k = sub + 8 * i;
+                const uint32_t k = sub + kMcSub * i;
                 occ_byte[i] = 0;
                 cell[i] = Dda::Cell{};
                 if (k < cnt) {
@@ -446,14 +460,20 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
             }
 #pragma unroll
             for (uint32_t i = 0; i < kMcPer; i++) {
-                const uint32_t k = sub + 8 * i;
+                const uint32_t k = sub + kMcSub * i;
                 if (k < cnt) {
                     uint32_t jump = 0;
                     if (!((occ_byte[i] >> (cell[i].packed >> 29)) & 1u)) {
                         const float t = s_T[k * kMcTPitch + r2];
                         const float tt = s2.exit_of(t, cell[i]);
                         uint32_t j = k + 1;  // the reference's do-while moves at least one member on
-                        while (j < cnt && s_T[j * kMcTPitch + r2] < tt) j++;
+                        for (;;) {           // members are increasing: count the leading ones below tt, four independent reads at a time
+                            uint32_t c = 0;
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; q++) c += (j + q < cnt && s_T[(j + q) * kMcTPitch + r2] < tt) ? 1u : 0u;
+                            j += c;
+                            if (c < 4) break;
+                        }
                         jump = j - k;
                     }
                     s_jump[r2 * kMcJPitch + k] = (uint8_t)jump;
@@ -474,16 +494,13 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
                 pending = k == cnt && full;
             }
             uint32_t last_skip = 0xffffffffu;  // member whose skip ran to the end of a full segment
-            while (k < cnt && num < max_steps) {
+            while (k < cnt && num < max_steps) {  // branch-free body: the LDS read of the jump is the whole dependent chain
                 const uint32_t j = jr[k];
-                if (j == 0) {
-                    vr[k] = 1;
-                    num++;
-                    k++;
-                } else {
-                    if (k + j == cnt) last_skip = k;
-                    k += j;
-                }
+                const uint32_t sample = j == 0 ? 1u : 0u;
+                vr[k] = (uint8_t)sample;
+                num += sample;
+                last_skip = (j != 0 && k + j == cnt) ? k : last_skip;
+                k += j + sample;
             }
             if (full && last_skip != 0xffffffffu && k == cnt && num < max_steps) {  // the skip may continue into the next segment
                 Dda::Cell c;
@@ -508,10 +525,10 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
                 flags |= v << i;
                 mine += v;
             }
-            uint32_t incl = mine;  // inclusive scan over the 8 threads of the ray (lanes 8 r2' .. 8 r2' + 7 of the wave)
+            uint32_t incl = mine;  // inclusive scan over the kMcSub threads of the ray (an aligned lane group of the wave)
 #pragma unroll
-            for (int off = 1; off < 8; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, 8);
+            for (int off = 1; off < (int)kMcSub; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, kMcSub);
                 if ((int)sub >= off) incl += o;
             }
             uint32_t at = s_base[r2] + incl - mine;
