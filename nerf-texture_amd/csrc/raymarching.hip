@@ -362,7 +362,7 @@ __device__ __forceinline__ float ray_t0(const Dda& s, float near, uint32_t pertu
 // Same floating-point expressions on the same values as the serial loop: the samples are bit-identical.
 constexpr uint32_t kMcRays = 32;      // rays per workgroup
 constexpr uint32_t kMcSeg = 128;      // sequence members per segment (jump distances fit a byte)
-constexpr uint32_t kMcSub = 16;       // threads per ray in phases 2 and 4 (two waves per SIMD: the phases are latency-bound)
+constexpr uint32_t kMcSub = 32;       // threads per ray in phases 2 and 4 (two waves per SIMD: the phases are latency-bound)
 constexpr uint32_t kMcThreads = kMcRays * kMcSub;
 constexpr uint32_t kMcPer = kMcSeg / kMcSub;  // members per thread in phases 2 / 4
 constexpr uint32_t kMcTPitch = kMcRays + 1;  // T[k][ray], +1: conflict-free for both access patterns
