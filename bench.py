@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=8192, help="rays per batch PER GPU (weak scaling; 8 GPUs x 8192 = configs[4]'s 65536)")
     ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other single-GPU configuration")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
     ap.add_argument("--bound", type=float, default=2.0)
@@ -136,7 +137,7 @@ def cpu_baseline(args, sc, bits, field_state, n_rays):
 
 
 # ----------------------------------------------------------------------------------------------------- training leg
-def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid, bits, time_grid_kernels):
+def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid, bits, time_grid_kernels, graph=False):
     """K timed training steps of one configuration. Returns (result dict, field, renderer)."""
     import nerftex_hip
     from ngp_harness import dp, scene
@@ -162,7 +163,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
 
     # same optimizer as main_nerf.py:128 (Adam, betas (0.9, 0.99), eps 1e-15); fused=True keeps GradScaler.step free of its
     # per-step found_inf .item() read-back (the unscale / skip-on-inf logic runs inside the fused kernel instead)
-    opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+    use_graph = graph and world == 1  # RCCL inside a captured graph is not something this round could test on 8 GPUs: eager there
+    opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
     reducer = dp.FlatGradAllReduce(field.parameters())
     reducer.broadcast_parameters()
     use_amp = args.dtype == "fp16"
@@ -187,6 +189,53 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             renderer.update_mean_count()
             renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
 
+    # ---- the same step as ONE replayed HIP graph: ~100 launches per 1.6 ms step put the eager loop at the edge of being bound by
+    # the host's launch rate (the same kernels took 1.60 or 1.83 ms per step depending on the box's host); a graph takes the
+    # host out of it.  Static inputs: the batch is picked on the device by an index tensor, the sample buffers are sized by a
+    # fixed count (the ring's mean rounded up to 4096 + 4096), the counter is a fixed tensor committed to the ring after replay.
+    pool_o = torch.stack([p[0] for p in pool])
+    pool_d = torch.stack([p[1] for p in pool])
+    batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+    graph_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    gstate = {"graph": None, "M": 0}
+
+    def step_body():
+        ro, rd, tgt = pool_o.index_select(0, batch_idx)[0], pool_d.index_select(0, batch_idx)[0], gt.index_select(0, batch_idx)[0]
+        reducer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+            image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
+                                                          counter=graph_counter, mean_count=gstate["M"])
+            loss = torch.nn.functional.mse_loss(image, tgt)
+        scaler.scale(loss).backward()
+        reducer.all_reduce()
+        scaler.step(opt)
+        scaler.update()
+        total_samples.add_(graph_counter[0].to(torch.int64))
+
+    def capture():
+        gstate["M"] = (renderer.mean_count + 4095) // 4096 * 4096 + 4096
+        kept = total_samples.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):  # allocator / library workspaces at this size, outside the capture
+                step_body()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step_body()
+        total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
+        gstate["graph"] = g
+
+    def graph_step(k):
+        batch_idx.fill_(k % n_pool)
+        gstate["graph"].replay()
+        renderer.commit_counter(graph_counter)
+        if renderer.local_step == 16:
+            renderer.update_mean_count()
+            if renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]:
+                capture()  # the sample count left the captured buffer size (does not happen on a static scene)
+
     # priming = the reference's first "epoch-0" steps: full-size buffers until a mean sample count exists
     for k in range(2):
         train_step(k, count=False)
@@ -194,19 +243,33 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
     for k in range(warmup):
         train_step(k, count=False)
+    if use_graph:
+        try:
+            capture()
+            for k in range(4):
+                graph_step(k)
+        except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+    total_samples.zero_()
 
-    if time_grid_kernels:
+    if time_grid_kernels and not use_graph:
         nerftex_hip.kernel_profile(2, reset=True)  # hipEvent pairs around the hash-grid kernels only (8 of ~90 launches per step)
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        train_step(k)
+        graph_step(k) if use_graph else train_step(k)
     torch.cuda.synchronize()
     dp.barrier()
     t1 = time.perf_counter()
+    samples_timed = total_samples.clone()
     kernel_us, all_kernel_us = {}, {}
     if time_grid_kernels:
+        if use_graph:  # event pairs cannot be read back from a replayed graph: the same step, launched eagerly, right after the timed region
+            nerftex_hip.kernel_profile(2, reset=True)
+            for k in range(16):
+                train_step(k, count=False)
         nerftex_hip.kernel_profile(0)
         kernel_us = nerftex_hip.kernel_profile()
         # outside the timed region: 8 more steps with every library kernel bracketed, for the per-kernel table
@@ -217,7 +280,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         all_kernel_us = nerftex_hip.kernel_profile()
         nerftex_hip.kernel_profile(reset=True)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    samples = total_samples.clone()
+    samples = samples_timed
     if world > 1:
         import torch.distributed as dist
 
@@ -226,7 +289,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     elapsed = float(elapsed.item())
     samples = int(samples.item())
     res = dict(value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
-               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, dt_gamma=dt_gamma, n_global=n_global)
+               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, graph=use_graph, use_amp=use_amp, dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
 
 
@@ -252,7 +315,7 @@ def main():
     sc = scene.Scene(bound=args.bound, seed=0)
     grid, thresh, bits = sc.bitfield()
     res, field, renderer = measure_training(args, args.mlp, args.rays, args.steps, args.warmup, dev, rank, world, sc, grid, bits,
-                                            not args.no_kernel_timing)
+                                            not args.no_kernel_timing, graph=not args.no_graph)
     use_amp, dt_gamma = res["use_amp"], res["dt_gamma"]
 
     # ---- roofline of the dominant hash-grid op, from the library's own per-kernel hipEvent pairs over the timed region
@@ -280,8 +343,9 @@ def main():
             "other": {k: v for k, v in kern.items() if k != dominant},
             "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(res["all_kernel_us"].items(), key=lambda kv: -kv[1]["total_us"])},
             "note": "avg_launch_ms = sum of the device durations of the kernels one C-ABI call launches (hipEvent pairs recorded by the library on the "
-                    "launch stream, names = rocprofv3 kernel names; bin_count/bin_fill are bin_kernel<..,false/true>); the 24 MiB table is "
-                    "Infinity-Cache resident and the gathers are bounded by the divergent-request rate, see DESIGN.md 4/6",
+                    "launch stream, names = rocprofv3 kernel names)" + ("; the timed region replays a captured graph, whose event pairs cannot be read "
+                    "back, so the pairs come from 16 eager launches of the same step right after it" if res["graph"] else " over the timed region") +
+                    "; the 24 MiB table is Infinity-Cache resident and the gathers are bounded by the divergent-request rate, see DESIGN.md 4/6",
         }
 
     # ---- rendered Mpix/s: one 800x800 frame through the reference's inference loop (nerf/renderer.py:436-487)
@@ -344,6 +408,7 @@ def main():
                 "rays_per_batch_per_gpu": args.rays, "global_rays": res["n_global"], "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
                 "optimizer": "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)",
+                "launch": "one replayed HIP graph per step" if res["graph"] else "eager launches",
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
             },
             "roofline": roofline,

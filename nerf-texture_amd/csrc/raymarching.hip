@@ -346,6 +346,11 @@ __device__ __forceinline__ float ray_t0(const Dda& s, float near, uint32_t pertu
     return t0;
 }
 
+__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // R6 count pass, data-parallel form
 // ------------------------------------------------------------------------------------------------
@@ -1022,7 +1027,11 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     hipStream_t st = as_stream(stream);
     const char* serial = getenv("NERFTEX_MARCH_COUNT");  // "serial": the one-ray-per-lane DDA (A/B switch)
     if (use_log && H <= 256 && !(serial && serial[0] == 's')) {  // (the packed voxel of the parallel pass holds 8-bit coordinates)
-        NERFTEX_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(uint32_t) * (1 + (size_t)nblocks), st), "hipMemsetAsync");
+        {   // a kernel, not hipMemsetAsync: the memset node did not re-zero the buffer when the launch sequence is replayed from a
+            // captured HIP graph (ROCm 7.2; the block sums then accumulate garbage on the second replay)
+            KernelTimer kt("zero_words_kernel", st);
+            hipLaunchKernelGGL(zero_words_kernel, grid_for(1 + nblocks), dim3(kBlock), 0, st, ws, 1 + nblocks);
+        }
         KernelTimer kt("march_count_parallel_kernel", st);
         hipLaunchKernelGGL(march_count_parallel_kernel, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                            max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog);

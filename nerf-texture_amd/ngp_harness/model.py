@@ -119,6 +119,11 @@ class Renderer(nn.Module):
         thresh = min(self.mean_density, self.density_thresh)
         self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
 
+    def commit_counter(self, counter):
+        """Ring bookkeeping for a step that ran with a caller-owned counter (graph replay)."""
+        self.step_counter[self.local_step % 16].copy_(counter)
+        self.local_step += 1
+
     def update_mean_count(self):
         """The step-counter half of update_extra_state (:656-660): one D2H read every 16 steps."""
         total = min(16, self.local_step)
@@ -126,17 +131,22 @@ class Renderer(nn.Module):
             self.mean_count = int(self.step_counter[:total, 0].sum().item() / total)
         self.local_step = 0
 
-    def render_train(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=True, force_all_rays=False, max_steps=1024):
-        """Training branch of run_cuda (:361-425). Returns image [N,3], depth [N], and the sample count tensor."""
+    def render_train(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=True, force_all_rays=False, max_steps=1024, counter=None,
+                     mean_count=None):
+        """Training branch of run_cuda (:361-425). Returns image [N,3], depth [N], and the sample count tensor.
+
+        counter / mean_count: for graph replay the caller supplies a fixed counter tensor and a fixed buffer size and does the
+        step-counter ring bookkeeping itself (`commit_counter`); by default both come from the ring like in the reference."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
-        counter = self.step_counter[self.local_step % 16]
+        if counter is None:
+            counter = self.step_counter[self.local_step % 16]
+            self.local_step += 1
         counter.zero_()
-        self.local_step += 1
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
-                                                                nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
-                                                                max_steps)
+                                                                nears, fars, counter, self.mean_count if mean_count is None else mean_count, perturb,
+                                                                128, force_all_rays, dt_gamma, max_steps)
         sigmas, rgbs, _ = self.field(xyzs, dirs)
         sigmas = self.density_scale * sigmas
         weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)

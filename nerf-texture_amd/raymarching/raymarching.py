@@ -21,7 +21,13 @@ _bwd = custom_bwd(device_type="cuda")
 def _rays(t):
     if not t.is_cuda:
         t = t.cuda()
-    return t.contiguous().view(-1, 3)
+    return _f32(t).view(-1, 3)
+
+
+def _f32(t):
+    """The kernels read float32.  Under autocast custom_fwd(cast_inputs=float32) has already made it so; outside autocast a half
+    tensor (e.g. straight from the fp16 MLP) must not reach them as-is (the reference dispatches on the scalar type instead)."""
+    return (t if t.dtype == torch.float32 else t.float()).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------- utils
@@ -125,7 +131,7 @@ def _march_train(differentiable, rays_o, rays_d, bound, density_bitfield, C, H, 
     if not density_bitfield.is_cuda:
         density_bitfield = density_bitfield.cuda()
     density_bitfield = density_bitfield.contiguous()
-    nears, fars = nears.contiguous(), fars.contiguous()
+    nears, fars = _f32(nears), _f32(fars)
     dev, dt = rays_o.device, rays_o.dtype
     N = rays_o.shape[0]
     M = _point_budget(N, max_steps, mean_count, align, force_all_rays)
@@ -208,7 +214,7 @@ class _composite_rays_train(Function):
     @_fwd32
     def forward(ctx, sigmas, rgbs, deltas, rays):
         """Volume-rendering quadrature per ray record: -> weights_sum [N], depth [N], image [N,3]."""
-        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        sigmas, rgbs, deltas = _f32(sigmas), _f32(rgbs), _f32(deltas)
         M, N = sigmas.shape[0], rays.shape[0]
         weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
         depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
@@ -225,7 +231,7 @@ class _composite_rays_train(Function):
     @_bwd
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         # grad_depth is ignored, exactly as in the reference (raymarching.py:330).
-        grad_weights_sum, grad_image = grad_weights_sum.contiguous(), grad_image.contiguous()
+        grad_weights_sum, grad_image = _f32(grad_weights_sum), _f32(grad_image)
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N = ctx.dims
         grad_sigmas = torch.zeros_like(sigmas)
@@ -271,8 +277,9 @@ class _composite_rays(Function):
     @_fwd32
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
         """Accumulate n_step samples of each alive ray IN PLACE into weights_sum/depth/image; rays_t <- -1 when a ray ends."""
-        check(lib.nerftex_composite_rays(int(n_alive), int(n_step), ptr(rays_alive), ptr(rays_t), ptr(sigmas.contiguous()),
-                                         ptr(rgbs.contiguous()), ptr(deltas), ptr(weights_sum), ptr(depth), ptr(image), stream()))
+        sigmas, rgbs, deltas = _f32(sigmas), _f32(rgbs), _f32(deltas)  # named: the tensors must outlive the launch
+        check(lib.nerftex_composite_rays(int(n_alive), int(n_step), ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                         ptr(weights_sum), ptr(depth), ptr(image), stream()))
         return tuple()
 
 

@@ -552,3 +552,57 @@ def test_empty_and_ragged(dev):
     c = torch.zeros(2, dtype=torch.int32, device=dev)
     xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, 1.0, bits, 1, 128, n, f, c, -1, False, 128, False, 0, 1024)
     assert c.cpu().tolist() == [0, 77] and rays[:, 2].sum().item() == 0 and xyzs.shape[0] == 128
+
+
+def test_march_replays_from_a_captured_graph(dev, scene_data):
+    """The training march as a node sequence of a captured HIP graph: every replay must reproduce the eager result
+    (regression: a hipMemsetAsync in the launch sequence was not re-executed correctly on replay)."""
+    import raymarching
+
+    sc, _, _, bits = scene_data
+    N = 2048
+    o, d = _rays(N, 21)
+    ro, rd, bt = t(o, dev), t(d, dev), t(bits, dev)
+    aabb = torch.tensor([-2, -2, -2, 2, 2, 2.0], device=dev)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def body(M):
+        nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+        counter.zero_()
+        return raymarching.march_rays_train(ro, rd, 2.0, bt, sc.cascade, 128, nears, fars, counter, M, True, 128, False, 1 / 128, 1024)
+
+    body(-1)
+    M = int(counter[0].item()) + 1000
+    want = [x.clone() for x in body(M)]
+    want_counter = counter.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body(M)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = body(M)
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(counter, want_counter)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
+def test_render_train_without_autocast(dev, scene_data):
+    """fp16 MLP outputs reaching the fp32-only raymarching kernels outside autocast must be converted, not reinterpreted."""
+    from ngp_harness.model import NGPField, Renderer
+
+    sc, grid, _, _ = scene_data
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp").to(dev)
+    r = Renderer(field, bound=2.0, min_near=0.2, density_thresh=10.0).to(dev)
+    r.set_occupancy(t(grid, dev))
+    o, d = _rays(512, 22)
+    image, depth, counter = r.render_train(t(o, dev), t(d, dev), dt_gamma=1 / 128)
+    image.sum().backward()
+    torch.cuda.synchronize()
+    assert image.shape == (512, 3) and torch.isfinite(image).all() and int(counter[0]) > 0
+    assert field.encoder.embeddings.grad is not None and torch.isfinite(field.encoder.embeddings.grad).all()
