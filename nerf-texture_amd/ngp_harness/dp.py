@@ -47,23 +47,33 @@ def shard(n_global, rank, world):
 
 
 class FlatGradAllReduce:
-    """Owns one flat fp32 gradient buffer; parameters' .grad are views into it."""
+    """Gradient exchange of data-parallel training: one collective for everything small, one per big tensor.
 
-    def __init__(self, params, average=True):
-        self.params = [p for p in params if p.requires_grad]
-        assert self.params, "no trainable parameters"
-        dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    Small parameters (the MLP weights) get `.grad` views into ONE flat fp32 buffer, zeroed per step and all-reduced in one call.
+    A big parameter (the hash table: 12.6 M floats) is left to autograd instead: its `.grad` is dropped every step, so the backward
+    pass hands its freshly computed gradient tensor over without the 3 x 48 MB read-add-write into a persistent buffer and
+    without the 48 MB zero fill; that tensor is all-reduced in place."""
+
+    def __init__(self, params, average=True, big_numel=1 << 20):
+        params = [p for p in params if p.requires_grad]
+        assert params, "no trainable parameters"
+        self.big = [p for p in params if p.numel() >= big_numel]
+        self.small = [p for p in params if p.numel() < big_numel]
+        self.params = params
+        dev = params[0].device
+        total = sum(p.numel() for p in self.small)
+        self.flat = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
         self.average = average
         off = 0
-        for p in self.params:
+        for p in self.small:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
 
     def zero_grad(self):
         self.flat.zero_()
+        for p in self.big:
+            p.grad = None
 
     def broadcast_parameters(self, src=0):
         if world_size() > 1:
@@ -71,12 +81,16 @@ class FlatGradAllReduce:
                 dist.broadcast(p.data, src)
 
     def all_reduce(self, extra=None):
-        """Sum (then average) the whole gradient in one collective. `extra`: optional 1-D float tensor (e.g. loss,
-        found-inf flag) reduced in the same call by riding at the end of the buffer is not needed here: it is a
-        second, tiny all-reduce."""
+        """Sum (then average) the gradients: biggest tensors first, then the flat buffer of the small ones; `extra` (e.g. a
+        loss or found-inf flag) is a further tiny all-reduce."""
         w = world_size()
         if w == 1:
             return extra
+        for p in self.big:
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                if self.average:
+                    p.grad.div_(w)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if self.average:
             self.flat.div_(w)

@@ -75,8 +75,10 @@ class NGPField(nn.Module):
         sigma, geo_feat = self._sigma_feat(x)
         d = self.encoder_dir(d)
         if self.mlp == "ffmlp":
-            pad = torch.zeros_like(geo_feat[..., :1])  # manual padding to 32 inputs (network_ff.py:94-96)
-            h = self.color_net(torch.cat([d, geo_feat, pad], dim=-1))
+            # manual padding to 32 inputs (network_ff.py:94-96).  The fp32 SH block is narrowed to the MLP's fp16 BEFORE the
+            # concatenation: FFMLP casts its input to half anyway, so the values are the same and the [B,32] fp32 copy is not made
+            pad = torch.zeros_like(geo_feat[..., :1])
+            h = self.color_net(torch.cat([d.to(geo_feat.dtype), geo_feat, pad], dim=-1))
         else:
             h = self._chain(self.color_net, torch.cat([d.to(geo_feat.dtype), geo_feat], dim=-1))
         return sigma, torch.sigmoid(h), {}

@@ -1,4 +1,5 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the ray sharding + the single flat-gradient all-reduce."""
+"""N>1 path on CPU: world_size-2 gloo processes exercise the ray sharding + the gradient exchange (one flat all-reduce for the
+small parameters, an in-place all-reduce of autograd's own tensor for each big one)."""
 import os
 import sys
 
@@ -19,7 +20,9 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world)
     torch.manual_seed(rank)  # different init per rank: broadcast must fix it
     model = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
-    red = dp.FlatGradAllReduce(model.parameters())
+    # threshold 100: the first layer (128 weights) takes the "big tensor" route, the second (48) the flat-buffer route
+    red = dp.FlatGradAllReduce(model.parameters(), big_numel=100)
+    assert len(red.big) == 1 and len(red.small) == 1
     red.broadcast_parameters()
     opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
 
@@ -32,7 +35,8 @@ def _worker(rank, world, port, q):
         red.zero_grad()
         loss = torch.nn.functional.mse_loss(model(x_global[lo:hi]), y_global[lo:hi])
         loss.backward()
-        assert model[0].weight.grad.data_ptr() == red.flat.data_ptr(), ".grad must stay a view of the flat buffer"
+        assert model[2].weight.grad.data_ptr() == red.flat.data_ptr(), "a small .grad must stay a view of the flat buffer"
+        assert model[0].weight.grad is not None and model[0].weight.grad.data_ptr() != red.flat.data_ptr()
         red.all_reduce()
         opt.step()
     mc = dp.all_reduce_max_int(100 + rank, torch.device("cpu"))
