@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=8192, help="rays per batch PER GPU (weak scaling; 8 GPUs x 8192 = configs[4]'s 65536)")
     ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other single-GPU configuration")
+    ap.add_argument("--no-fused-glue", action="store_true", help="run the ops between/after the two FFMLPs as framework ops (reference structure)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
@@ -144,7 +145,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     from ngp_harness.model import NGPField, Renderer
 
     torch.manual_seed(0)
-    field = NGPField(bound=args.bound, mlp=mlp).to(dev)
+    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=not args.no_fused_glue).to(dev)
     torch.manual_seed(1)  # FFMLP.reset_parameters reseeds with 42; give the table its own stream
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
     renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)

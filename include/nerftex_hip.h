@@ -226,6 +226,23 @@ int nerftex_raytracer_trace(const nerftex_raytracer* rt, const float* rays_o, co
                             float* positions, float* normals, float* depth, int64_t* face_idx,
                             uint32_t N, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * field glue  (no counterpart among the reference's native exports: these four
+ *              fuse the framework-level ops nerf/network_ff.py:60-110 runs
+ *              between and after the two FFMLPs -- SURVEY 8(f) N1, first step)
+ * ------------------------------------------------------------------------- */
+
+/* h [B,16] fp16 (sigma-net outputs), dirs [B,3] fp32  ->  sigma [B] fp32 = exp(h[:,0]) (trunc_exp forward,
+ * tools/activation.py:9-12), cin [B,32] fp16 = [SH degree 4 of dir | h[:,1:16] | 0] (network_ff.py:88-96).     */
+int nerftex_field_mid_forward(const void* h, const float* dirs, uint32_t B, float* sigma, void* cin, void* stream);
+/* grad_h [B,16] fp16: column 0 = grad_sigma * exp(clamp(h0,-15,15)) (activation.py:14-17), 1..15 = grad_cin[:,16:31] */
+int nerftex_field_mid_backward(const float* grad_sigma, const void* grad_cin, const void* h, uint32_t B, void* grad_h,
+                               void* stream);
+/* hc [B,16] fp16 (colour-net outputs) -> rgbs [B,3] fp32 = sigmoid(hc[:,:3]) rounded through fp16 (network_ff.py:99-100) */
+int nerftex_field_out_forward(const void* hc, uint32_t B, float* rgbs, void* stream);
+/* grad_hc [B,16] fp16 = sigmoid backward of the fp16-narrowed grad_rgbs, columns 3..15 zero                      */
+int nerftex_field_out_backward(const float* grad_rgbs, const float* rgbs, uint32_t B, void* grad_hc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,10 @@ _u32, _f32, _i, _vp, _sz = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_size_
 
 # name -> argument ctypes, in the order of include/nerftex_hip.h
 _SIGNATURES = {
+    "nerftex_field_mid_forward": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "nerftex_field_mid_backward": [_vp, _vp, _vp, _u32, _vp, _vp],
+    "nerftex_field_out_forward": [_vp, _u32, _vp, _vp],
+    "nerftex_field_out_backward": [_vp, _vp, _u32, _vp, _vp],
     "nerftex_profile_enable": [_i],
     "nerftex_profile_reset": [],
     "nerftex_profile_report": [C.c_char_p, _sz],

@@ -39,11 +39,15 @@ trunc_exp = _trunc_exp.apply
 
 
 class NGPField(nn.Module):
-    def __init__(self, bound=2.0, mlp="torch", num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64):
+    def __init__(self, bound=2.0, mlp="torch", num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
+                 fused_glue=False):
         super().__init__()
         assert mlp in ("torch", "ffmlp")
         self.bound = bound
         self.mlp = mlp
+        # fused_glue: the elementwise ops between / after the two FFMLPs as two HIP kernels per direction (ngp_harness/fused.py),
+        # and the FFMLPs fed without the reference's extra 128-row pad copy (the sample buffers are multiples of 128 already)
+        self.fused_glue = bool(fused_glue) and mlp == "ffmlp" and geo_feat_dim == 15
         self.geo_feat_dim = geo_feat_dim
         self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                                    desired_resolution=2048 * bound, gridtype="hash", align_corners=True)
@@ -71,7 +75,24 @@ class NGPField(nn.Module):
         h = self.sigma_net(x) if self.mlp == "ffmlp" else self._chain(self.sigma_net, x)
         return trunc_exp(h[..., 0]), h[..., 1:]
 
+    def _forward_fused(self, x, d):
+        from ffmlp.ffmlp import ffmlp_forward
+
+        from . import fused
+
+        feats = self.encoder(x, bound=self.bound)
+        infer = not self.training
+        s, c = self.sigma_net, self.color_net
+        h = ffmlp_forward(feats, s.weights, s.input_dim, s.padded_output_dim, s.hidden_dim, s.num_layers, s.activation, s.output_activation,
+                          infer, True)
+        sigma, cin = fused.sigma_geo_dir(h, d)
+        hc = ffmlp_forward(cin, c.weights, c.input_dim, c.padded_output_dim, c.hidden_dim, c.num_layers, c.activation, c.output_activation,
+                           infer, True)
+        return sigma, fused.color_out(hc), {}
+
     def forward(self, x, d, **kwargs):
+        if self.fused_glue and x.shape[0] % 128 == 0 and torch.is_autocast_enabled():
+            return self._forward_fused(x, d)
         sigma, geo_feat = self._sigma_feat(x)
         d = self.encoder_dir(d)
         if self.mlp == "ffmlp":

@@ -1,0 +1,102 @@
+"""The fused field glue (nerftex_field_*) against the framework ops it replaces (nerf/network_ff.py:60-110 as restated in
+ngp_harness/model.py): same values, same roundings."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _unfused_mid(h, dirs):
+    from ngp_harness.model import trunc_exp
+    from shencoder import SHEncoder
+
+    with torch.autocast("cuda", dtype=torch.float16):
+        sigma = trunc_exp(h[..., 0])
+        geo = h[..., 1:]
+        d = SHEncoder(input_dim=3, degree=4)(dirs)
+        cin = torch.cat([d.to(geo.dtype), geo, torch.zeros_like(geo[..., :1])], dim=-1)
+    return sigma, cin
+
+
+def test_mid_forward_backward_match_framework_ops(dev):
+    from ngp_harness import fused
+
+    torch.manual_seed(0)
+    B = 4096
+    h = (torch.randn(B, 16, device=dev) * 3).half()
+    h[:64, 0] = torch.linspace(-20, 20, 64, device=dev).half()  # beyond the +-15 clamp of the backward
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
+    gs = torch.randn(B, device=dev)
+    gc = (torch.randn(B, 32, device=dev) * 1e-2).half()
+
+    h1 = h.clone().requires_grad_(True)
+    s1, c1 = fused.sigma_geo_dir(h1, dirs)
+    torch.autograd.backward([s1, c1], [gs, gc])
+    h2 = h.clone().requires_grad_(True)
+    s2, c2 = _unfused_mid(h2, dirs)
+    torch.autograd.backward([s2, c2], [gs, gc])
+    assert s1.dtype == torch.float32 and c1.dtype == torch.float16 and c1.shape == (B, 32)
+    assert torch.equal(s1, s2.float())
+    assert torch.equal(c1, c2)
+    assert torch.equal(h1.grad, h2.grad)
+
+
+def test_out_forward_backward_match_framework_ops(dev):
+    from ngp_harness import fused
+
+    torch.manual_seed(1)
+    B = 4096
+    hc = (torch.randn(B, 16, device=dev) * 4).half()
+    g = torch.randn(B, 3, device=dev) * 1e-2
+    a = hc.clone().requires_grad_(True)
+    r1 = fused.color_out(a)
+    r1.backward(g)
+    b = hc.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        r2 = torch.sigmoid(b[:, :3]).float()
+    r2.backward(g)
+    assert r1.dtype == torch.float32 and torch.equal(r1, r2)
+    assert torch.equal(a.grad, b.grad)
+
+
+def test_field_fused_equals_unfused(dev):
+    """Whole field, fused glue vs the reference's op sequence: identical outputs; parameter gradients up to summation order."""
+    from ngp_harness.model import NGPField
+
+    torch.manual_seed(2)
+    f1 = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev)
+    f2 = NGPField(bound=2.0, mlp="ffmlp", fused_glue=False).to(dev)
+    f1.encoder.embeddings.data.uniform_(-1e-1, 1e-1)
+    f2.load_state_dict(f1.state_dict())
+    B = 2048
+    x = (torch.rand(B, 3, device=dev) * 2 - 1) * 1.9
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
+    outs = []
+    for f in (f1, f2):
+        f.train()
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, color, _ = f(x, d)
+        loss = (sigma.float().clamp(max=50) * 1e-2).sum() + color.float().sum()
+        loss.backward()
+        outs.append((sigma.float(), color.float()))
+    assert f1.fused_glue and not f2.fused_glue
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for (n1, p1), (n2, p2) in zip(f1.named_parameters(), f2.named_parameters()):
+        g1, g2 = p1.grad.float(), p2.grad.float()
+        scale = float(g2.abs().max())
+        assert scale > 0, n1
+        np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), rtol=0, atol=2e-2 * scale, err_msg=n1)
+    f1.eval()
+    f2.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s1, c1, _ = f1(x, d)
+        s2, c2, _ = f2(x, d)
+    assert torch.equal(s1.float(), s2.float()) and torch.equal(c1.float(), c2.float())
