@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other single-GPU configuration")
     ap.add_argument("--no-fused-glue", action="store_true", help="run the ops between/after the two FFMLPs as framework ops (reference structure)")
+    ap.add_argument("--graph-split", action="store_true", help="1 GPU: use the two-graph form of the multi-GPU path (for testing it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
     ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
@@ -164,7 +165,10 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
 
     # same optimizer as main_nerf.py:128 (Adam, betas (0.9, 0.99), eps 1e-15); fused=True keeps GradScaler.step free of its
     # per-step found_inf .item() read-back (the unscale / skip-on-inf logic runs inside the fused kernel instead)
-    use_graph = graph and world == 1  # RCCL inside a captured graph is not something this round could test on 8 GPUs: eager there
+    # 1 GPU: the whole step is one graph.  N GPUs: RCCL inside a captured graph is not something this round could test, so the step
+    # is two graphs (forward + backward | optimizer) with the gradient all-reduce launched eagerly between them.
+    use_graph = graph
+    split_graph = use_graph and (world > 1 or args.graph_split)
     opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
     reducer = dp.FlatGradAllReduce(field.parameters())
     reducer.broadcast_parameters()
@@ -200,7 +204,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     graph_counter = torch.zeros(2, dtype=torch.int32, device=dev)
     gstate = {"graph": None, "M": 0}
 
-    def step_body():
+    def body_fb():
         ro, rd, tgt = pool_o.index_select(0, batch_idx)[0], pool_d.index_select(0, batch_idx)[0], gt.index_select(0, batch_idx)[0]
         reducer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
@@ -208,10 +212,16 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                                                           counter=graph_counter, mean_count=gstate["M"])
             loss = torch.nn.functional.mse_loss(image, tgt)
         scaler.scale(loss).backward()
-        reducer.all_reduce()
+        total_samples.add_(graph_counter[0].to(torch.int64))
+
+    def body_opt():
         scaler.step(opt)
         scaler.update()
-        total_samples.add_(graph_counter[0].to(torch.int64))
+
+    def step_body():
+        body_fb()
+        reducer.all_reduce()
+        body_opt()
 
     def capture():
         gstate["M"] = (renderer.mean_count + 4095) // 4096 * 4096 + 4096
@@ -222,18 +232,31 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             for _ in range(3):  # allocator / library workspaces at this size, outside the capture
                 step_body()
         torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step_body()
+        if split_graph:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                body_fb()
+            reducer.all_reduce()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                body_opt()
+            gstate["graph"] = (ga, gb)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step_body()
+            gstate["graph"] = (g,)
         total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
-        gstate["graph"] = g
 
     def graph_step(k):
         batch_idx.fill_(k % n_pool)
-        gstate["graph"].replay()
+        gstate["graph"][0].replay()
+        if split_graph:
+            reducer.all_reduce()
+            gstate["graph"][1].replay()
         renderer.commit_counter(graph_counter)
         if renderer.local_step == 16:
             renderer.update_mean_count()
+            renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
             if renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]:
                 capture()  # the sample count left the captured buffer size (does not happen on a static scene)
 
@@ -247,11 +270,11 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     if use_graph:
         try:
             capture()
-            for k in range(4):
+            for k in range(32):  # past the first two mean_count read-backs after the capture (the first one costs ~13 ms once)
                 graph_step(k)
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            use_graph = False
+            use_graph = split_graph = False
     total_samples.zero_()
 
     if time_grid_kernels and not use_graph:
@@ -290,7 +313,9 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     elapsed = float(elapsed.item())
     samples = int(samples.item())
     res = dict(value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
-               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, graph=use_graph, use_amp=use_amp, dt_gamma=dt_gamma, n_global=n_global)
+               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp,
+               graph=("two replayed HIP graphs per step (forward+backward | optimizer), eager all-reduce between" if split_graph else
+                      "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
 
 
@@ -409,7 +434,7 @@ def main():
                 "rays_per_batch_per_gpu": args.rays, "global_rays": res["n_global"], "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
                 "optimizer": "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)",
-                "launch": "one replayed HIP graph per step" if res["graph"] else "eager launches",
+                "launch": res["graph"] if res["graph"] else "eager launches",
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
             },
             "roofline": roofline,
