@@ -678,19 +678,34 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
     flush_tiles<1, OT>(gw_out, red, out + HIDDEN * IN + (NL - 1) * HIDDEN * HIDDEN, HIDDEN, wave, lane);
 }
 
-// sum the per-workgroup partials: 64 consecutive parameters x 4 slices of the partial list per workgroup
-// (256-B coalesced reads), LDS combine of the 4 slices, one fp16 store per parameter
+// sum the per-workgroup partials: kRedParams consecutive parameters x (256 / kRedParams) slices of the partial list per workgroup
+// (128-B coalesced reads, twice the workgroups of a 64 x 4 split: the pass is latency-bound), LDS combine of the slices, one
+// fp16 store per parameter.  Fixed order: deterministic.
+constexpr uint32_t kRedParams = 32, kRedSlices = kBlockThreads / kRedParams;
 __global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_parts,
                                                                            uint32_t n_params, half_t* __restrict__ grad_weights) {
-    __shared__ float red[4][64];
-    const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const uint32_t p = blockIdx.x * 64 + lane;
+    __shared__ float red[kRedSlices][kRedParams];
+    const uint32_t lane = threadIdx.x % kRedParams, slice = threadIdx.x / kRedParams;
+    const uint32_t p = blockIdx.x * kRedParams + lane;
     float s = 0.0f;
-    if (p < n_params)
-        for (uint32_t k = slice; k < n_parts; k += 4) s += partials[(size_t)k * n_params + p];
+    if (p < n_params) {
+        float s0 = 0.0f, s1 = 0.0f;  // two independent chains: more loads in flight
+        uint32_t k = slice;
+        for (; k + kRedSlices < n_parts; k += 2 * kRedSlices) {
+            s0 += partials[(size_t)k * n_params + p];
+            s1 += partials[(size_t)(k + kRedSlices) * n_params + p];
+        }
+        if (k < n_parts) s0 += partials[(size_t)k * n_params + p];
+        s = s0 + s1;
+    }
     red[slice][lane] = s;
     __syncthreads();
-    if (slice == 0 && p < n_params) grad_weights[p] = (half_t)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (slice == 0 && p < n_params) {
+        float t = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < kRedSlices; i++) t += red[i][lane];
+        grad_weights[p] = (half_t)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -836,7 +851,7 @@ int launch_fused(const void* grad, const void* inputs, const void* weights, cons
     if (rc != NERFTEX_OK) return rc;
     {
         KernelTimer kt("ffmlp_wgrad_reduce_kernel", st);
-        hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, 64u)), dim3(kBlockThreads), 0, st, partials, n_parts, n_params,
+        hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, kRedParams)), dim3(kBlockThreads), 0, st, partials, n_parts, n_params,
                            static_cast<half_t*>(grad_weights));
     }
     return check_launch("ffmlp_backward(reduce)");
@@ -944,7 +959,7 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     if (rc != NERFTEX_OK) return rc;
     {
         KernelTimer kt("ffmlp_wgrad_reduce_kernel", st);
-        hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, 64u)), dim3(kBlockThreads), 0, st, partials, n_parts,
+        hipLaunchKernelGGL(ffmlp_wgrad_reduce_kernel, dim3(div_up(n_params, kRedParams)), dim3(kBlockThreads), 0, st, partials, n_parts,
                            n_params, static_cast<half_t*>(grad_weights));
     }
     return check_launch("ffmlp_backward(reduce)");

@@ -660,28 +660,31 @@ __global__ __launch_bounds__(kRayBlock) void march_write_kernel(const float* __r
     }
 }
 
-// Sample-parallel second pass (used when the count pass logged the accepted t's): a 256-thread workgroup owns 64 rays,
-// rebuilds their offsets (workgroup sums + wave64 scan, as above), then its 4 waves expand the rays one after the
-// other with 64 lanes over the samples of a ray -- coalesced log reads and coalesced xyz / dir / delta stores instead
-// of a second serial DDA per ray.  x = clamp(o + t d), dt = clamp(t dt_gamma, ..) and t_next = t + dt are recomputed
+// Sample-parallel second pass (used when the count pass logged the accepted t's): a workgroup owns 64 rays, rebuilds their
+// offsets (workgroup sums + wave64 scan, as above) and expands their samples as one flat list, a thread per sample --
+// coalesced xyz / dir / delta stores instead of a second serial DDA per ray.  x = clamp(o + t d), dt = clamp(t dt_gamma, ..) and t_next = t + dt are recomputed
 // with the very expressions of the DDA, so the samples are bit-identical to the replay.
+constexpr uint32_t kExpandThreads = 1024;  // per 64-ray block: the pass is latency-bound, so as many samples in flight as a workgroup allows
+
 template <bool WITH_TS>
-__global__ __launch_bounds__(256) void march_expand_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
+__global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
                                                            float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                            const float* __restrict__ nears, float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas, float* __restrict__ rays_ts, int* __restrict__ rays,
                                                            int* __restrict__ counter, const uint32_t* __restrict__ ws, uint32_t perturb,
                                                            const float* __restrict__ tlog) {
-    __shared__ uint32_t red[4];
+    __shared__ uint32_t red[kExpandThreads / kWave];
     __shared__ uint32_t s_off[kRayBlock], s_cnt[kRayBlock];
     const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
     uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += ws[1 + j];
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kExpandThreads) part += ws[1 + j];
     part = wave_sum(part);
     if (lane == 0) red[wid] = part;
     __syncthreads();
-    const uint32_t before = ws[0] + red[0] + red[1] + red[2] + red[3];
+    uint32_t before = ws[0];
+#pragma unroll
+    for (uint32_t i = 0; i < kExpandThreads / kWave; i++) before += red[i];
     if (wid == 0) {  // one wave = the 64 rays of this workgroup
         const uint32_t n = blockIdx.x * kRayBlock + lane;
         const uint32_t num_steps = n < N ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
@@ -702,38 +705,51 @@ __global__ __launch_bounds__(256) void march_expand_kernel(const float* __restri
 
     const float dt_min = 2 * kSqrt3 / (float)max_steps;
     const float dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
-    for (uint32_t r = wid; r < kRayBlock; r += 4) {
-        const uint32_t cnt = s_cnt[r];
-        if (cnt == 0) continue;
+    // the block's kept samples as one flat list: thread i takes list entries i, i + 256, ...; the ray of an entry is found by a
+    // 6-step search in the 64 LDS offsets.  Consecutive threads -> consecutive samples -> coalesced stores, all four waves busy
+    // whatever the distribution of samples over the rays.
+    __shared__ uint32_t s_start[kRayBlock + 1];  // exclusive prefix of s_cnt inside the block
+    if (wid == 0) {
+        const uint32_t c = s_cnt[lane];
+        const uint32_t incl = wave_inclusive_scan(c);
+        s_start[lane] = incl - c;
+        if (lane == kWave - 1) s_start[kRayBlock] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = s_start[kRayBlock];
+    for (uint32_t i = threadIdx.x; i < total; i += kExpandThreads) {
+        uint32_t r = 0;  // largest r with s_start[r] <= i
+#pragma unroll
+        for (uint32_t step = kRayBlock / 2; step > 0; step >>= 1)
+            if (s_start[r + step] <= i) r += step;
+        const uint32_t k = i - s_start[r];
         const uint32_t n = blockIdx.x * kRayBlock + r;
-        const uint32_t off = s_off[r];
         const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
         const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
-        float t0 = nears[n];
-        if (perturb) {
-            Pcg32 rng(42);
-            rng.advance((uint64_t)n);
-            t0 = fmaf(dt_min, rng.next_float(), t0);
-        }
         const float* log_row = tlog + (size_t)n * max_steps;
-        for (uint32_t k = lane; k < cnt; k += kWave) {
-            const float t = log_row[k];
-            const float dt = clampf(t * dt_gamma, dt_min, dt_max);
-            float last_t = t0;
-            if (k > 0) {
-                const float tp = log_row[k - 1];
-                last_t = tp + clampf(tp * dt_gamma, dt_min, dt_max);
+        const float t = log_row[k];
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        float last_t;
+        if (k > 0) {
+            const float tp = log_row[k - 1];
+            last_t = tp + clampf(tp * dt_gamma, dt_min, dt_max);
+        } else {
+            last_t = nears[n];
+            if (perturb) {
+                Pcg32 rng(42);
+                rng.advance((uint64_t)n);
+                last_t = fmaf(dt_min, rng.next_float(), last_t);
             }
-            const float t_next = t + dt;
-            const size_t i = (size_t)off + k;
-            xyzs[3 * i] = clampf(fmaf(t, dx, ox), -bound, bound);
-            xyzs[3 * i + 1] = clampf(fmaf(t, dy, oy), -bound, bound);
-            xyzs[3 * i + 2] = clampf(fmaf(t, dz, oz), -bound, bound);
-            dirs[3 * i] = dx; dirs[3 * i + 1] = dy; dirs[3 * i + 2] = dz;
-            deltas[2 * i] = dt;
-            deltas[2 * i + 1] = t_next - last_t;
-            if constexpr (WITH_TS) rays_ts[i] = t_next;
         }
+        const float t_next = t + dt;
+        const size_t o = (size_t)s_off[r] + k;
+        xyzs[3 * o] = clampf(fmaf(t, dx, ox), -bound, bound);
+        xyzs[3 * o + 1] = clampf(fmaf(t, dy, oy), -bound, bound);
+        xyzs[3 * o + 2] = clampf(fmaf(t, dz, oz), -bound, bound);
+        dirs[3 * o] = dx; dirs[3 * o + 1] = dy; dirs[3 * o + 2] = dz;
+        deltas[2 * o] = dt;
+        deltas[2 * o + 1] = t_next - last_t;
+        if constexpr (WITH_TS) rays_ts[o] = t_next;
     }
 }
 
@@ -1045,7 +1061,7 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     if (use_log) {
         {
             KernelTimer kt("march_expand_kernel", st);
-            hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(256), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+            hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(kExpandThreads), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
                                nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog);
         }
         return check_launch("march_rays_train(expand)");
