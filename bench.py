@@ -170,7 +170,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     use_graph = graph
     split_graph = use_graph and (world > 1 or args.graph_split)
     opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
-    reducer = dp.FlatGradAllReduce(field.parameters())
+    # the hash-table gradient crosses xGMI as fp16 (it is fp16-valued under autocast): half the all-reduce bytes
+    reducer = dp.FlatGradAllReduce(field.parameters(), big_comm_dtype=torch.float16 if args.dtype == "fp16" else None)
     reducer.broadcast_parameters()
     use_amp = args.dtype == "fp16"
     scaler = torch.amp.GradScaler("cuda", enabled=use_amp)

@@ -54,7 +54,7 @@ class FlatGradAllReduce:
     pass hands its freshly computed gradient tensor over without the 3 x 48 MB read-add-write into a persistent buffer and
     without the 48 MB zero fill; that tensor is all-reduced in place."""
 
-    def __init__(self, params, average=True, big_numel=1 << 20):
+    def __init__(self, params, average=True, big_numel=1 << 20, big_comm_dtype=None):
         params = [p for p in params if p.requires_grad]
         assert params, "no trainable parameters"
         self.big = [p for p in params if p.numel() >= big_numel]
@@ -64,6 +64,11 @@ class FlatGradAllReduce:
         total = sum(p.numel() for p in self.small)
         self.flat = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
         self.average = average
+        # big_comm_dtype=torch.float16: a big gradient travels as fp16.  Under autocast the hash-table gradient IS fp16-valued (the
+        # kernel accumulates into an fp16 tensor, autograd widens it), so the narrowing is lossless locally; only the cross-rank sum
+        # rounds, and a sum that overflows becomes inf, which GradScaler treats like any other overflow (skip + rescale).
+        # Halves the bytes on xGMI, which at 2 GPUs (one link) is most of the all-reduce time.
+        self.big_comm_dtype = big_comm_dtype
         off = 0
         for p in self.small:
             n = p.numel()
@@ -88,7 +93,12 @@ class FlatGradAllReduce:
             return extra
         for p in self.big:
             if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                if self.big_comm_dtype is not None and p.grad.dtype != self.big_comm_dtype:
+                    wire = p.grad.to(self.big_comm_dtype)
+                    dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+                    p.grad.copy_(wire)
+                else:
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                 if self.average:
                     p.grad.div_(w)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

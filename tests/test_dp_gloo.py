@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, comm_dtype=None):
     sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from ngp_harness import dp
@@ -21,7 +21,7 @@ def _worker(rank, world, port, q):
     torch.manual_seed(rank)  # different init per rank: broadcast must fix it
     model = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
     # threshold 100: the first layer (128 weights) takes the "big tensor" route, the second (48) the flat-buffer route
-    red = dp.FlatGradAllReduce(model.parameters(), big_numel=100)
+    red = dp.FlatGradAllReduce(model.parameters(), big_numel=100, big_comm_dtype=comm_dtype)
     assert len(red.big) == 1 and len(red.small) == 1
     red.broadcast_parameters()
     opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
@@ -62,12 +62,13 @@ def _single_process_reference():
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_gloo_matches_single_process():
+@pytest.mark.parametrize("comm_dtype", [None, torch.float16], ids=["fp32-wire", "fp16-wire"])
+def test_two_rank_gloo_matches_single_process(comm_dtype):
     world = 2
-    port = 29600 + os.getpid() % 300
+    port = 29600 + os.getpid() % 300 + (17 if comm_dtype is not None else 0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, comm_dtype)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=150) for _ in range(world)]
@@ -79,7 +80,8 @@ def test_two_rank_gloo_matches_single_process():
     assert torch.equal(w0, w1), "replicas must stay bit-identical"
     assert results[0][2] == results[1][2] == 101
     ref = _single_process_reference()
-    assert torch.allclose(w0, ref, atol=1e-6), "2-rank DP == single-process training on the global batch"
+    # fp16 on the wire rounds the big tensor's summed gradient to 11 bits; Adam's normalised step keeps the effect at ~1e-3 of lr
+    assert torch.allclose(w0, ref, atol=1e-6 if comm_dtype is None else 2e-3), "2-rank DP == single-process training on the global batch"
 
 
 def test_shard_covers_batch():
