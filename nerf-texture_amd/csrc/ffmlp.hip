@@ -59,6 +59,19 @@ __device__ __forceinline__ float act_backward(uint32_t a, float g, float y) {
     }
 }
 
+// ACT >= 0: activation known at compile time (the switch folds away -- with a run-time id every element drags a chain of scalar
+// compares and branches through all seven formulas: 1100 branches per 32-row step of the fused backward); ACT < 0: run-time id
+template <int ACT>
+__device__ __forceinline__ float act_fwd(uint32_t act_rt, float x) {
+    if constexpr (ACT >= 0) return act_forward((uint32_t)ACT, x);
+    else return act_forward(act_rt, x);
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd(uint32_t act_rt, float g, float y) {
+    if constexpr (ACT >= 0) return act_backward((uint32_t)ACT, g, y);
+    else return act_backward(act_rt, g, y);
+}
+
 __device__ __forceinline__ float4_t mfma16(const half8_t& a, const half8_t& b, const float4_t& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -114,7 +127,7 @@ __device__ __forceinline__ void store4(half_t* p, const float4_t& v) {
 // ------------------------------------------------------------------------------------------------
 // forward / inference
 // ------------------------------------------------------------------------------------------------
-template <int HIDDEN, bool INFERENCE, bool STAGED>  // STAGED: forward_buffer rows leave through an LDS patch (needs the LDS room)
+template <int HIDDEN, bool INFERENCE, bool STAGED, int ACT, int OUT_ACT>  // STAGED: forward_buffer rows leave through an LDS patch; ACT: see act_fwd
 __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half_t* __restrict__ X, const half_t* __restrict__ W,
                                                                       half_t* __restrict__ fwd, half_t* __restrict__ out, uint32_t B,
                                                                       uint32_t IN, uint32_t NL, uint32_t act, uint32_t out_act) {
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half
 #pragma unroll
                 for (int ot = 0; ot < OT; ot++) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[t][ot][j] = act_forward(act, acc[t][ot][j]);
+                    for (int j = 0; j < 4; j++) acc[t][ot][j] = act_fwd<ACT>(act, acc[t][ot][j]);
                     if constexpr (!INFERENCE) {
                         if constexpr (STAGED) store4(patch + (size_t)(16 * t + r) * kRowPitch + 16 * ot + 4 * g, acc[t][ot]);
                         else store4(fwd + l * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g, acc[t][ot]);
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_forward_kernel(const half
 #pragma unroll
             for (int t = 0; t < NT; t++) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) c[t][j] = act_forward(out_act, c[t][j]);
+                for (int j = 0; j < 4; j++) c[t][j] = act_fwd<OUT_ACT>(out_act, c[t][j]);
                 store4(out + (size_t)(row0 + 16 * t + r) * 16 + 4 * g, c[t]);
             }
         }
@@ -476,7 +489,10 @@ __device__ __forceinline__ void flush_tiles(const float4_t (&tiles)[NA][NB], flo
 //   * backward_buffer is never written nor read (it is scratch in the reference's contract),
 //   * forward_buffer and the inputs are read once instead of twice:  ~52 % less HBM traffic for the whole MLP backward.
 // One wave per SIMD (the dW accumulators are 112-176 registers); the loads of a 32-row step are issued together.
-template <int HIDDEN, int NL, int IT>  // IT = input_dim / 16
+// RECOMPUTE: forward_buffer is not read at all -- the saved activations are rebuilt from the inputs with the forward kernel's own
+// chain (bit-identical halfs), which costs a few dozen MFMAs per 32 rows and removes 70 % of this kernel's loads; the training
+// forward then has no forward_buffer to write either.
+template <int HIDDEN, int NL, int IT, bool RECOMPUTE, int ACT>  // IT = input_dim / 16; ACT: see act_fwd
 __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(const half_t* __restrict__ grad, const half_t* __restrict__ X,
                                                                                const half_t* __restrict__ W, const half_t* __restrict__ fwd,
                                                                                half_t* __restrict__ grad_inputs, uint32_t B, uint32_t act,
@@ -500,6 +516,15 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
         stage_fragments(frags + (size_t)(base_hidden + (j - 1) * per_hidden) * 64, W_hidden + (size_t)(NL - 1 - j) * HIDDEN * HIDDEN, HIDDEN, true,
                         HIDDEN, HIDDEN, true);
     if (grad_inputs) stage_fragments(frags + (size_t)base_in * 64, W, IN, true, IN, HIDDEN, true);
+    // forward-orientation fragments for the recomputation: [W_0 (HIDDEN x IN)] [W_l, l = 1 .. NL-1]
+    constexpr int base_f0 = base_in + IT * KSH;
+    constexpr int base_fh = base_f0 + OT * KS0;
+    if constexpr (RECOMPUTE) {
+        stage_fragments(frags + (size_t)base_f0 * 64, W, IN, false, HIDDEN, IN, false);
+        for (int l = 1; l < NL; l++)
+            stage_fragments(frags + (size_t)(base_fh + (l - 1) * per_hidden) * 64, W_hidden + (size_t)(l - 1) * HIDDEN * HIDDEN, HIDDEN, false, HIDDEN,
+                            HIDDEN, true);
+    }
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -553,18 +578,60 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
                 if (32 * ks + 8 * g < IN) xin[t][ks] = *reinterpret_cast<const half8_t*>(X + (size_t)(row0 + 16 * t + r) * IN + 32 * ks + 8 * g);
                 else xin[t][ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
             }
-        half4_t y[NL][NT][OT];
+        half4_t y[NL][NT][OT];  // y[j] = post-activations of hidden layer NL-1-j, lane (r, g) holds features 16 ot + 4 g .. + 3 of row r
+        float4_t acc[NT][OT];
+        if constexpr (RECOMPUTE) {
+            // the forward kernel's chain, verbatim (layer 0 from the row-major input, then register to register), one 16-row tile
+            // at a time to keep the transient registers at one tile's worth
 #pragma unroll
-        for (int j = 0; j < NL; j++)
+            for (int t = 0; t < NT; t++) {
+                asm volatile("" ::: "memory");  // re-read the weight fragments from LDS per tile instead of keeping 20 of them in registers
+                float4_t fa[OT];
 #pragma unroll
-            for (int t = 0; t < NT; t++)
+                for (int ot = 0; ot < OT; ot++) fa[ot] = zero;
 #pragma unroll
-                for (int ot = 0; ot < OT; ot++)
-                    y[j][t][ot] = *reinterpret_cast<const half4_t*>(fwd + (size_t)(NL - 1 - j) * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN +
-                                                                    16 * ot + 4 * g);
+                for (int ks = 0; ks < KS0; ks++)
+#pragma unroll
+                    for (int ot = 0; ot < OT; ot++) fa[ot] = mfma16(frags[(size_t)(base_f0 + ot * KS0 + ks) * 64 + lane], xin[t][ks], fa[ot]);
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    half8_t fop[KSH];
+#pragma unroll
+                    for (int ot = 0; ot < OT; ot++) {
+                        half4_t v;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            fa[ot][q] = act_fwd<ACT>(act, fa[ot][q]);
+                            v[q] = (half_t)fa[ot][q];
+                        }
+                        y[NL - 1 - l][t][ot] = v;
+                    }
+#pragma unroll
+                    for (int s = 0; s < KSH; s++) fop[s] = pack_operand(fa[2 * s], fa[2 * s + 1]);
+                    if (l + 1 < NL) {
+                        const half8_t* fl = frags + (size_t)(base_fh + l * per_hidden) * 64;
+#pragma unroll
+                        for (int ot = 0; ot < OT; ot++) {
+                            float4_t c = zero;
+#pragma unroll
+                            for (int ks = 0; ks < KSH; ks++) c = mfma16(fl[(size_t)(ot * KSH + ks) * 64 + lane], fop[ks], c);
+                            fa[ot] = c;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; j++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int ot = 0; ot < OT; ot++)
+                        y[j][t][ot] = *reinterpret_cast<const half4_t*>(fwd + (size_t)(NL - 1 - j) * layer_stride +
+                                                                        (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g);
+        }
 
         // ---- dL/d(last hidden activation) = W_out^T . grad^T
-        float4_t acc[NT][OT];
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) {
             const half8_t a = frags[(size_t)ot * 64 + lane];
@@ -608,7 +675,7 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
 #pragma unroll
                 for (int ot = 0; ot < OT; ot++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[t][ot][q] = act_backward(act, (float)(half_t)acc[t][ot][q], (float)y[j][t][ot][q]);
+                    for (int q = 0; q < 4; q++) acc[t][ot][q] = act_bwd<ACT>(act, (float)(half_t)acc[t][ot][q], (float)y[j][t][ot][q]);
 #pragma unroll
                 for (int s = 0; s < KSH; s++) bop[t][s] = pack_operand(acc[t][2 * s], acc[t][2 * s + 1]);
             }
@@ -789,7 +856,11 @@ int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t
     const size_t lds = lds_bytes_forward(H, IN, NL, staged);
     int rc = lds_check(lds);
     if (rc != NERFTEX_OK) return rc;
-    auto kernel = staged ? ffmlp_forward_kernel<H, INF, true> : ffmlp_forward_kernel<H, INF, false>;
+    auto kernel = staged ? ffmlp_forward_kernel<H, INF, true, -1, -1> : ffmlp_forward_kernel<H, INF, false, -1, -1>;
+    if constexpr (H == 64) {  // the field's networks: ReLU inside, no output activation -> both folded in at compile time
+        if (act == kRelu && out_act == kNone)
+            kernel = staged ? ffmlp_forward_kernel<H, INF, true, (int)kRelu, (int)kNone> : ffmlp_forward_kernel<H, INF, false, (int)kRelu, (int)kNone>;
+    }
     rc = set_lds(kernel, lds);
     if (rc != NERFTEX_OK) return rc;
     {
@@ -829,21 +900,22 @@ int launch_dgrad(const void* grad, const void* weights, const void* fwd, void* b
     return check_launch("ffmlp_backward(dgrad)");
 }
 
-template <int H, int NL, int IT>
+template <int H, int NL, int IT, int ACT>
 int launch_fused(const void* grad, const void* inputs, const void* weights, const void* fwd, void* grad_inputs, uint32_t B, uint32_t act,
                  uint32_t n_params, void* grad_weights, hipStream_t st) {
-    size_t lds = lds_bytes_dgrad(H, 16 * IT, NL, true);
+    const bool recompute = fwd == nullptr;
+    size_t lds = lds_bytes_dgrad(H, 16 * IT, NL, true) + (recompute ? (size_t)(frag_count(H, 16 * IT) + (NL - 1) * frag_count(H, H)) * 1024 : 0);
     if (lds < 64 * 1024) lds = 64 * 1024;  // the end-of-kernel combine reuses the fragment area
     int rc = lds_check(lds);
     if (rc != NERFTEX_OK) return rc;
-    auto kernel = ffmlp_backward_fused_kernel<H, NL, IT>;
+    auto kernel = recompute ? ffmlp_backward_fused_kernel<H, NL, IT, true, ACT> : ffmlp_backward_fused_kernel<H, NL, IT, false, ACT>;
     NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
     uint32_t n_parts = B / kRowsPerBlock;
     if (n_parts > (uint32_t)num_cus()) n_parts = (uint32_t)num_cus();  // one workgroup (4 waves, one per SIMD) per CU
     float* partials = static_cast<float*>(workspace(kWsMlp, sizeof(float) * (size_t)n_parts * n_params));
     if (!partials) return NERFTEX_ERR_HIP;
     {
-        KernelTimer kt("ffmlp_backward_fused_kernel", st);
+        KernelTimer kt(recompute ? "ffmlp_backward_recompute_kernel" : "ffmlp_backward_fused_kernel", st);
         hipLaunchKernelGGL(kernel, dim3(n_parts), dim3(kBlockThreads), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                            (const half_t*)fwd, (half_t*)grad_inputs, B, act, partials, n_params);
     }
@@ -861,8 +933,11 @@ int launch_fused(const void* grad, const void* inputs, const void* weights, cons
 int launch_backward_fused(const void* grad, const void* inputs, const void* weights, const void* fwd, void* grad_inputs, uint32_t B, uint32_t IN,
                           uint32_t H, uint32_t NL, uint32_t act, uint32_t n_params, void* grad_weights, hipStream_t st) {
     if (H != 64 || IN % 16 != 0 || IN > 64 || NL < 2 || NL > 4) return -1;
+    // the two networks of the ngp field (32 inputs, 2 or 3 hidden layers, ReLU) get the activation folded in at compile time
+    if (act == kRelu && IN == 32 && NL == 2) return launch_fused<64, 2, 2, (int)kRelu>(grad, inputs, weights, fwd, grad_inputs, B, act, n_params, grad_weights, st);
+    if (act == kRelu && IN == 32 && NL == 3) return launch_fused<64, 3, 2, (int)kRelu>(grad, inputs, weights, fwd, grad_inputs, B, act, n_params, grad_weights, st);
 #define NERFTEX_FUSED_CASE(nl, it) \
-    if (NL == nl && IN == 16 * it) return launch_fused<64, nl, it>(grad, inputs, weights, fwd, grad_inputs, B, act, n_params, grad_weights, st);
+    if (NL == nl && IN == 16 * it) return launch_fused<64, nl, it, -1>(grad, inputs, weights, fwd, grad_inputs, B, act, n_params, grad_weights, st);
     NERFTEX_FUSED_CASE(2, 1) NERFTEX_FUSED_CASE(2, 2) NERFTEX_FUSED_CASE(2, 3) NERFTEX_FUSED_CASE(2, 4)
     NERFTEX_FUSED_CASE(3, 1) NERFTEX_FUSED_CASE(3, 2) NERFTEX_FUSED_CASE(3, 3) NERFTEX_FUSED_CASE(3, 4)
     NERFTEX_FUSED_CASE(4, 1) NERFTEX_FUSED_CASE(4, 2) NERFTEX_FUSED_CASE(4, 3) NERFTEX_FUSED_CASE(4, 4)
@@ -907,10 +982,7 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     clear_error();
     int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NERFTEX_OK || B == 0) return rc;
-    if (!backward_buffer || !forward_buffer) {
-        set_error("ffmlp_backward: forward_buffer and backward_buffer must not be NULL");
-        return NERFTEX_ERR_INVALID;
-    }
+
     hipStream_t st = as_stream(stream);
     const uint32_t H = hidden_dim, IN = input_dim, NL = num_layers;
     void* gi = calc_grad_inputs ? grad_inputs : nullptr;
@@ -922,6 +994,10 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
             rc = launch_backward_fused(grad, inputs, weights, forward_buffer, gi, B, IN, H, NL, activation, n_params, grad_weights, st);
             if (rc >= 0) return rc;  // rc < 0: shape not instantiated -> split path below
         }
+    }
+    if (!backward_buffer || !forward_buffer) {  // forward_buffer == NULL (recompute the activations) exists in the fused kernel only
+        set_error("ffmlp_backward: forward_buffer and backward_buffer must not be NULL for this shape / mode");
+        return NERFTEX_ERR_INVALID;
     }
 
     switch (H) {

@@ -14,7 +14,16 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
+import os
+
 from nerftex_hip import check, lib, ptr, stream, timer
+
+
+def _recompute_ok(input_dim, hidden_dim, num_layers):
+    """Shapes for which the library's fused backward can rebuild the activations from the inputs (forward_buffer = NULL): the
+    training forward then writes no forward_buffer at all.  NERFTEX_FFMLP_RECOMPUTE=0 restores the stored-activation contract."""
+    return (os.environ.get("NERFTEX_FFMLP_RECOMPUTE", "1") != "0" and os.environ.get("NERFTEX_FFMLP_BWD", "") != "split"
+            and hidden_dim == 64 and 2 <= num_layers <= 4 and input_dim % 16 == 0 and input_dim <= 64)
 
 
 class _ffmlp_forward(Function):
@@ -30,7 +39,14 @@ class _ffmlp_forward(Function):
         B = inputs.shape[0]
         inputs, weights = inputs.contiguous(), weights.contiguous()
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
-        if not inference:
+        if not inference and _recompute_ok(input_dim, hidden_dim, num_layers):
+            tok = timer.start("ffmlp_forward")
+            check(lib.nerftex_ffmlp_inference(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                              output_activation, None, ptr(outputs), stream()))
+            timer.stop(tok)
+            ctx.save_for_backward(inputs, weights, outputs)
+            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
+        elif not inference:
             forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             tok = timer.start("ffmlp_forward")
             check(lib.nerftex_ffmlp_forward(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation,
@@ -51,13 +67,15 @@ class _ffmlp_forward(Function):
     def backward(ctx, grad):
         B = grad.shape[0]
         grad = grad.contiguous().half()
-        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        inputs, weights, outputs = saved[:3]
+        forward_buffer = saved[3] if len(saved) > 3 else None  # None: the library rebuilds the activations from the inputs
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
         grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
         # the reference zero-fills both (ffmlp.py:72-73) because its kernels accumulate / skip rows; the HIP kernels
         # overwrite every element of both, so the fills (2 x num_layers x B x hidden x 2 B per call) are dropped
         grad_weights = torch.empty_like(weights)
-        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        backward_buffer = None if forward_buffer is None else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         tok = timer.start("ffmlp_backward")
         check(lib.nerftex_ffmlp_backward(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim, output_dim, hidden_dim,
                                          num_layers, activation, output_activation, int(bool(calc_grad_inputs)), ptr(backward_buffer),

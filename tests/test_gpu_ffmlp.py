@@ -175,3 +175,28 @@ def test_ffmlp_errors(dev):
     assert "128" in lib.nerftex_last_error().decode()
     assert lib.nerftex_ffmlp_forward(ptr(x), ptr(w), 128, 32, 16, 256, 4, 0, 6, ptr(fb), ptr(out), stream()) != 0
     assert "LDS" in lib.nerftex_last_error().decode()
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[5], CASES[7], CASES[9]], ids=lambda c: f"in{c[0]}_h{c[1]}_L{c[2]}_act{c[3]}")
+def test_ffmlp_backward_recompute_equals_stored_activations(dev, case):
+    """forward_buffer = NULL: the fused backward rebuilds the activations from the inputs with the forward kernel's chain.
+    Same halfs, so the gradients must be bit-identical to the run that reads the stored forward_buffer."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    IN, H, NL, act, B, w, x = _setup(case, 41)
+    rng = np.random.default_rng(42)
+    grad = (rng.standard_normal((B, 16)) * 1e-2).astype(np.float16)
+    gt, xt, wt = t(grad, dev), t(x, dev), t(w, dev)
+    fb = torch.empty(NL, B, H, dtype=torch.float16, device=dev)
+    out = torch.empty(B, 16, dtype=torch.float16, device=dev)
+    check(lib.nerftex_ffmlp_forward(ptr(xt), ptr(wt), B, IN, 16, H, NL, act, 6, ptr(fb), ptr(out), stream()))
+    res = []
+    for fwd in (fb, None):
+        gi = torch.zeros(B, IN, dtype=torch.float16, device=dev)
+        gw = torch.zeros_like(wt)
+        bb = torch.zeros(NL, B, H, dtype=torch.float16, device=dev)
+        check(lib.nerftex_ffmlp_backward(ptr(gt), ptr(xt), ptr(wt), ptr(fwd), B, IN, 16, H, NL, act, 6, 1, ptr(bb), ptr(gi), ptr(gw), stream()))
+        torch.cuda.synchronize()
+        res.append((gi.cpu().numpy(), gw.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.count_nonzero(res[1][1]) > 0
