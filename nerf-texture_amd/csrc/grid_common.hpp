@@ -56,6 +56,24 @@ struct IndexFn {
         pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
     }
 
+    // The same index, factored: every corner coordinate is pg[d] or pg[d] + 1, so the per-dimension terms are computed once (one
+    // integer multiply per dimension instead of one per dimension per corner; (p + 1) * k == p * k + k in uint32 arithmetic) and a
+    // corner only combines D of them.
+    __device__ __forceinline__ void terms(const uint32_t (&pg)[D], uint32_t (&t)[D][2]) const {
+        constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint32_t k = hashed ? primes[d] : ((uint32_t)d < ndense ? stride[d] : 0u);
+            t[d][0] = pg[d] * k;
+            t[d][1] = t[d][0] + k;
+        }
+    }
+    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return hashed ? (a ^ b) : (a + b); }
+    __device__ __forceinline__ uint32_t wrap(uint32_t index) const {
+        if (pow2) return index & (size - 1);
+        return index >= size ? index % size : index;
+    }
+
     __device__ __forceinline__ uint32_t operator()(const uint32_t (&p)[D]) const {
         uint32_t index;
         if (hashed) {

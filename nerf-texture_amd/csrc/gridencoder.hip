@@ -223,15 +223,15 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     // corners come in x-neighbour pairs (idx = 2q, 2q+1).  Their rows are adjacent on dense levels and, prime[0] being 1, on
     // hashed levels whenever the cell's x is even: one 2-row load then replaces two gathers -- the gather pipe retires about one
     // LANE-request per clock per CU, so requests are what this kernel is made of.  Same values, same accumulation order.
+    uint32_t term[D][2];
+    index_of.terms(pos_grid, term);
 #pragma unroll
     for (int q = 0; q < (1 << (D - 1)); q++) {
-        uint32_t p[D];
-        p[0] = pos_grid[0];
+        uint32_t yz = 0;  // neutral for both xor and add
 #pragma unroll
-        for (int d = 1; d < D; d++) p[d] = pos_grid[d] + ((q >> (d - 1)) & 1);
-        const uint32_t ra = index_of(p);
-        p[0] = pos_grid[0] + 1;
-        const uint32_t rb = index_of(p);
+        for (int d = 1; d < D; d++) yz = index_of.combine(yz, term[d][(q >> (d - 1)) & 1]);
+        const uint32_t ra = index_of.wrap(index_of.combine(term[0][0], yz));
+        const uint32_t rb = index_of.wrap(index_of.combine(term[0][1], yz));
         if constexpr (kHasPairLoad<T, C>) {
             if (rb == ra + 1) {
                 load_row_pair<T, C>(table + (size_t)ra * C, g[2 * q], g[2 * q + 1]);

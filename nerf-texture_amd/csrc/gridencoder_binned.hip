@@ -116,38 +116,20 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
         pos[d] -= (float)pg[d];
     }
 
-    const bool fast = index_of.hashed && index_of.pow2;
-    uint32_t h[D][2];
-    if (fast) {
-        constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            h[d][0] = pg[d] * primes[d];
-            h[d][1] = h[d][0] + primes[d];
-        }
-    }
+    uint32_t term[D][2];
+    index_of.terms(pg, term);
 #pragma unroll
     for (int q = 0; q < NP; q++) {  // q enumerates the corner bits of dimensions 1..D-1
         float wyz = 1;
-        uint32_t p[D];
+        uint32_t yz = 0;
 #pragma unroll
         for (int d = 1; d < D; d++) {
             const int bit = (q >> (d - 1)) & 1;
             wyz *= bit ? pos[d] : 1 - pos[d];
-            p[d] = pg[d] + bit;
+            yz = index_of.combine(yz, term[d][bit]);
         }
-        if (fast) {
-            uint32_t hyz = 0;
-#pragma unroll
-            for (int d = 1; d < D; d++) hyz ^= h[d][(q >> (d - 1)) & 1];
-            sm.row_a[q] = (h[0][0] ^ hyz) & (hashmap_size - 1);
-            sm.row_b[q] = (h[0][1] ^ hyz) & (hashmap_size - 1);
-        } else {
-            p[0] = pg[0];
-            sm.row_a[q] = index_of(p);
-            p[0] = pg[0] + 1;
-            sm.row_b[q] = index_of(p);
-        }
+        sm.row_a[q] = index_of.wrap(index_of.combine(term[0][0], yz));
+        sm.row_b[q] = index_of.wrap(index_of.combine(term[0][1], yz));
         if (FILL) {
             const float wa = (1 - pos[0]) * wyz, wb = pos[0] * wyz;  // products commute: same value as the dimension-ordered weight
             sm.va[q][0] = wa * g[0]; sm.va[q][1] = wa * g[1];

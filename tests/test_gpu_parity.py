@@ -83,6 +83,24 @@ def test_grid_forward_fp32_bit_exact(oracle, dev, case):
     assert np.array_equal(got_blc, want.transpose(1, 0, 2).reshape(B, -1))
 
 
+@pytest.mark.parametrize("case", GRID_CASES, ids=[c[0] for c in GRID_CASES])
+def test_grid_forward_large_batch_level_kernel(oracle, dev, case):
+    """B >= 8192 takes the XCD-pinned (sample, level) kernel with paired corner loads: same bits as the oracle in fp32 (with and
+    without dy_dx, both layouts), and half(fp32 interpolation) for an fp16 table."""
+    s = _grid_setup(oracle, case, 9001, 19, np.float32)
+    want, want_dyd = oracle.grid_encode_forward(s["x"], s["emb"], s["offsets"], s["S"], s["base"], True, s["gridtype"], s["align"])
+    got, got_dyd = _hip_grid_forward(s, dev, True, 0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got_dyd.view(np.uint32), want_dyd.view(np.uint32))
+    got_blc, _ = _hip_grid_forward(s, dev, False, 1)
+    assert np.array_equal(got_blc, want.transpose(1, 0, 2).reshape(s["x"].shape[0], -1))
+    if s["C"] % 2 == 0:
+        h = dict(s, emb=s["emb"].astype(np.float16))
+        f32, _ = oracle.grid_encode_forward(s["x"], h["emb"].astype(np.float32), s["offsets"], s["S"], s["base"], False, s["gridtype"], s["align"])
+        got16, _ = _hip_grid_forward(h, dev, False, 1)
+        assert np.array_equal(got16, f32.astype(np.float16).transpose(1, 0, 2).reshape(s["x"].shape[0], -1))
+
+
 @pytest.mark.parametrize("case", [GRID_CASES[0], GRID_CASES[2], GRID_CASES[4]], ids=lambda c: c[0])
 def test_grid_forward_fp16(oracle, dev, case):
     s = _grid_setup(oracle, case, 1500, 12, np.float16)
