@@ -192,8 +192,13 @@ int nerftex_ffmlp_inference(const void* inputs, const void* weights, uint32_t B,
                             uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                             uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                             void* inference_buffer, void* outputs, void* stream);
-/* grad [B,output_dim] half; grad_weights flat half, pre-zeroed; grad_inputs
- * [B,in] half (written iff calc_grad_inputs); backward_buffer pre-zeroed.    */
+/* grad [B,output_dim] half; grad_weights flat half (every element is overwritten);
+ * grad_inputs [B,in] half (written iff calc_grad_inputs); backward_buffer
+ * [num_layers,B,hidden] scratch: written only by the split dgrad/wgrad path, the
+ * fused kernel (hidden 64, 2..4 layers, input <= 64) leaves it untouched and
+ * accepts NULL.  forward_buffer == NULL (fused kernel only): the activations
+ * are rebuilt from `inputs` with the forward kernel's chain, bit-identical, so
+ * a training forward may be run with nerftex_ffmlp_inference.                  */
 int nerftex_ffmlp_backward(const void* grad, const void* inputs, const void* weights,
                            const void* forward_buffer, uint32_t B, uint32_t input_dim,
                            uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
