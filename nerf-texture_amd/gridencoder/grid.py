@@ -146,11 +146,24 @@ class GridEncoder(nn.Module):
                 f"resolution={self.base_resolution} -> {top} per_level_scale={self.per_level_scale:.4f} "
                 f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners}")
 
+    def _table(self):
+        """The table handed to grid_encode.  Training: the fp32 parameter (grid_encode narrows it under autocast, autograd widens
+        the gradient back).  No-grad inference under autocast: the narrowed copy is kept until the parameter changes -- an 800x800
+        frame calls the encoder ~60 times and the 24 MiB cast is the same every time."""
+        e = self.embeddings
+        if torch.is_grad_enabled() or not torch.is_autocast_enabled() or self.level_dim % 2 != 0 or e.dtype == torch.half:
+            return e
+        cache = getattr(self, "_half_cache", None)
+        if cache is None or cache[0] != e._version or cache[1] != e.data_ptr() or cache[2].device != e.device:
+            cache = (e._version, e.data_ptr(), e.detach().to(torch.half))
+            self._half_cache = cache
+        return cache[2]
+
     def forward(self, inputs, bound=1):
         # inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
         inputs = (inputs + bound) / (2 * bound)
         prefix = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
-        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+        outputs = grid_encode(inputs, self._table(), self.offsets, self.per_level_scale, self.base_resolution,
                               inputs.requires_grad, self.gridtype_id, self.align_corners)
         return outputs.view(prefix + [self.output_dim])

@@ -213,5 +213,6 @@ class Renderer(nn.Module):
             n_samples += xyzs.shape[0]
             step += n_step
             i += 1
+        self.last_iters = i
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         return image, depth, n_samples
