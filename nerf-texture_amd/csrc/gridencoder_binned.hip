@@ -269,16 +269,23 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(const T* __restri
     const bool in_batch = b < B;
     const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
 
+    // every wave requests its sample first; wave 0 then fetches the run table while those loads are in flight (it is the critical
+    // path of the first barrier: table latency + scan + its own samples)
+    float xs[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
+    float g[2] = {0.0f, 0.0f};
+    if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
     if (threadIdx.x < kWave) {  // wave 0: this workgroup's run lengths -> LDS offsets, and the runs' global starts
         const uint32_t t = threadIdx.x;  // kMaxTilesPerLevel == kWave
         const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
         uint32_t cnt = 0;
         if (t < ntiles) {
-            const uint32_t g = tab.tile_base[level] + t;
+            const uint32_t gt = tab.tile_base[level] + t;
             const uint32_t here = starts[((size_t)level * nchunks + chunk) * kMaxTilesPerLevel + t];
-            const uint32_t next = chunk + 1 < nchunks ? starts[((size_t)level * nchunks + chunk + 1) * kMaxTilesPerLevel + t] : tile_count[g];
+            const uint32_t next = chunk + 1 < nchunks ? starts[((size_t)level * nchunks + chunk + 1) * kMaxTilesPerLevel + t] : tile_count[gt];
             cnt = next - here;
-            gbase[t] = tile_start[g] + here;
+            gbase[t] = tile_start[gt] + here;
         }
         uint32_t incl = cnt;
 #pragma unroll
@@ -291,11 +298,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(const T* __restri
         if (t == kWave - 1) lbase[kMaxTilesPerLevel] = incl;
     }
 
-    float xs[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
-    float g[2] = {0.0f, 0.0f};
-    if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
     const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
     Sample<T, D> sm;
     make_sample<T, D, true>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, hashmap_size, merge_runs);
