@@ -146,6 +146,24 @@ def module_goldens():
     json.dump(rows, open(os.path.join(OUT, "ffmlp_params.json"), "w"), indent=1)
     print("ffmlp_params.json:", len(rows), "modules")
 
+    # checkpoint wire format: parameter / buffer names, shapes and dtypes of the --ff network
+    # (nerf/network_ff.py:11-56 = NeRFRenderer buffers + encoder + two FFMLPs).  The network class itself cannot be imported here
+    # (nerf/utils.py needs a dozen absent packages), so the entries come from the component classes it is built from, instantiated
+    # exactly as network_ff.py / tools/encoding.py:45 do, plus the register_buffer names read from nerf/renderer.py.
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048 * 2,
+                      align_corners=True)
+    sig = FFMLP(input_dim=32, output_dim=16, hidden_dim=64, num_layers=2)
+    col = FFMLP(input_dim=32, output_dim=3, hidden_dim=64, num_layers=3)
+    entries = {}
+    for prefix, mod in (("encoder", enc), ("sigma_net", sig), ("color_net", col)):
+        for k, v in mod.state_dict().items():
+            entries[f"{prefix}.{k}"] = [list(v.shape), str(v.dtype).replace("torch.", "")]
+    src = open(os.path.join(REF, "nerf/renderer.py")).read()
+    buffers = sorted(set(re.findall(r"register_buffer\(\s*['\"](\w+)['\"]", src)))
+    json.dump(dict(bound=2, cascade=2, grid_size=128, entries=entries, renderer_buffers=buffers),
+              open(os.path.join(OUT, "checkpoint_keys.json"), "w"), indent=1)
+    print("checkpoint_keys.json:", sorted(entries), buffers)
+
     # guard: nothing may have been written into the reference tree
     import subprocess
 
