@@ -235,15 +235,16 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         torch.cuda.current_stream().wait_stream(side)
         if split_graph:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 body_fb()
             reducer.all_reduce()
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                 body_opt()
             gstate["graph"] = (ga, gb)
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only this thread's calls can invalidate the capture (an RCCL watchdog thread may query events meanwhile)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 step_body()
             gstate["graph"] = (g,)
         total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
