@@ -171,7 +171,9 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     split_graph = use_graph and (world > 1 or args.graph_split)
     opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
     # the hash-table gradient crosses xGMI as fp16 (it is fp16-valued under autocast): half the all-reduce bytes
-    reducer = dp.FlatGradAllReduce(field.parameters(), big_comm_dtype=torch.float16 if args.dtype == "fp16" else None)
+    # (the 1/world of the gradient average is folded into the loss below, so the exchange is a plain sum: no division pass over 48 MB)
+    reducer = dp.FlatGradAllReduce(field.parameters(), average=False, big_comm_dtype=torch.float16 if args.dtype == "fp16" else None)
+    inv_world = 1.0 / world
     reducer.broadcast_parameters()
     use_amp = args.dtype == "fp16"
     scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
@@ -185,6 +187,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
             image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024)
             loss = torch.nn.functional.mse_loss(image, gt[k % n_pool])
+            if world > 1:
+                loss = loss * inv_world
         scaler.scale(loss).backward()
         reducer.all_reduce()
         scaler.step(opt)
@@ -212,6 +216,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
                                                           counter=graph_counter, mean_count=gstate["M"])
             loss = torch.nn.functional.mse_loss(image, tgt)
+            if world > 1:
+                loss = loss * inv_world
         scaler.scale(loss).backward()
         total_samples.add_(graph_counter[0].to(torch.int64))
 
