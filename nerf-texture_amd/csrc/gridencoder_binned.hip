@@ -39,8 +39,8 @@ namespace {
 constexpr uint32_t kBinWaves = 16;                      // levels per K1 / K3 workgroup (one wave each)
 constexpr uint32_t kBinThreads = kBinWaves * kWave;     // 1024
 constexpr uint32_t kBinSamples = 1024;                  // samples per K1 / K3 workgroup (16 rounds of 64)
-constexpr uint32_t kTileBytes = 128 * 1024;             // LDS accumulator tile of K4
-constexpr uint32_t kMaxTilesPerLevel = 64;
+constexpr uint32_t kTileBytes = 64 * 1024;              // LDS accumulator tile of K4: two workgroups per CU overlap their phases
+constexpr uint32_t kMaxTilesPerLevel = 128;             // 2^19 rows of an fp16 level
 constexpr uint32_t kSliceRecords = 32 * 1024;           // records per K4 work item
 constexpr uint32_t kSumThreads = 1024;
 constexpr uint32_t kSumUnroll = 8;                      // record loads in flight per lane in K4
@@ -59,7 +59,7 @@ template <> struct Rec<float> { uint32_t rows; float va0, va1, vb0, vb1; };     
 // accumulator bytes per table row in K4: fp16 -> 2 x int64 fixed point, fp32 -> 2 x float
 template <typename T>
 constexpr uint32_t rows_per_tile() { return sizeof(T) == 2 ? kTileBytes / 16u : kTileBytes / 8u; }
-static_assert(kMaxTilesPerLevel == kWave, "K3 scans one level's tiles with one wave");
+static_assert(kMaxTilesPerLevel == 2 * kWave, "K3 scans one level's tiles with one wave, two tiles per lane");
 static_assert(rows_per_tile<half_t>() <= (1u << kRowBits) && rows_per_tile<float>() <= (1u << kRowBits), "local row field");
 
 // ---- fp16 <-> 2^-24 fixed point ------------------------------------------------------------------------------------
@@ -276,26 +276,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(const T* __restri
     for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
     float g[2] = {0.0f, 0.0f};
     if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
-    if (threadIdx.x < kWave) {  // wave 0: this workgroup's run lengths -> LDS offsets, and the runs' global starts
-        const uint32_t t = threadIdx.x;  // kMaxTilesPerLevel == kWave
+    if (threadIdx.x < kWave) {  // wave 0: this workgroup's run lengths -> LDS offsets, and the runs' global starts (2 tiles per lane)
         const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
-        uint32_t cnt = 0;
-        if (t < ntiles) {
-            const uint32_t gt = tab.tile_base[level] + t;
-            const uint32_t here = starts[((size_t)level * nchunks + chunk) * kMaxTilesPerLevel + t];
-            const uint32_t next = chunk + 1 < nchunks ? starts[((size_t)level * nchunks + chunk + 1) * kMaxTilesPerLevel + t] : tile_count[gt];
-            cnt = next - here;
-            gbase[t] = tile_start[gt] + here;
+        uint32_t cnt[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t t = threadIdx.x + h * kWave;
+            if (t < ntiles) {
+                const uint32_t gt = tab.tile_base[level] + t;
+                const uint32_t here = starts[((size_t)level * nchunks + chunk) * kMaxTilesPerLevel + t];
+                const uint32_t next = chunk + 1 < nchunks ? starts[((size_t)level * nchunks + chunk + 1) * kMaxTilesPerLevel + t] : tile_count[gt];
+                cnt[h] = next - here;
+                gbase[t] = tile_start[gt] + here;
+            }
         }
-        uint32_t incl = cnt;
+        uint32_t incl[2] = {cnt[0], cnt[1]};
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, kWave);
-            if ((int)lane >= off) incl += o;
+            const uint32_t o0 = __shfl_up(incl[0], off, kWave), o1 = __shfl_up(incl[1], off, kWave);
+            if ((int)lane >= off) { incl[0] += o0; incl[1] += o1; }
         }
-        lbase[t] = incl - cnt;
-        lcount[t] = 0;
-        if (t == kWave - 1) lbase[kMaxTilesPerLevel] = incl;
+        const uint32_t first_half = __shfl(incl[0], kWave - 1, kWave);
+        lbase[lane] = incl[0] - cnt[0];
+        lbase[lane + kWave] = first_half + incl[1] - cnt[1];
+        lcount[lane] = 0;
+        lcount[lane + kWave] = 0;
+        if (lane == kWave - 1) lbase[kMaxTilesPerLevel] = first_half + incl[1];
     }
 
     const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
