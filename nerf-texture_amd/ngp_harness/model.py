@@ -160,6 +160,12 @@ class Renderer(nn.Module):
 
         counter / mean_count: for graph replay the caller supplies a fixed counter tensor and a fixed buffer size and does the
         step-counter ring bookkeeping itself (`commit_counter`); by default both come from the ring like in the reference."""
+        marched, counter = self.march_train(rays_o, rays_d, dt_gamma, perturb, force_all_rays, max_steps, counter, mean_count)
+        image, depth = self.shade_train(marched, bg_color)
+        return image, depth, counter
+
+    def march_train(self, rays_o, rays_d, dt_gamma=0.0, perturb=True, force_all_rays=False, max_steps=1024, counter=None, mean_count=None):
+        """First half of the training branch: everything that depends on the rays and the occupancy grid only (:361-387)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
@@ -170,12 +176,17 @@ class Renderer(nn.Module):
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
                                                                 nears, fars, counter, self.mean_count if mean_count is None else mean_count, perturb,
                                                                 128, force_all_rays, dt_gamma, max_steps)
+        return (nears, fars, xyzs, dirs, deltas, rays), counter
+
+    def shade_train(self, marched, bg_color=1):
+        """Second half (:389-425): field evaluation, compositing, background."""
+        nears, fars, xyzs, dirs, deltas, rays = marched
         sigmas, rgbs, _ = self.field(xyzs, dirs)
         sigmas = self.density_scale * sigmas
         weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        return image, depth, counter
+        return image, depth
 
     @torch.no_grad()
     def render_infer(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024):
