@@ -26,6 +26,8 @@ namespace {
 constexpr int kMaxDevices = 16;
 struct Slot { void* ptr = nullptr; size_t bytes = 0; };
 Slot g_ws[kMaxDevices][kWsSlots];
+std::vector<void*> g_retired;  // outgrown buffers: kept until release_workspaces() because a captured HIP graph may still launch
+                               // kernels that were recorded with the old pointer (growth is geometric, so there are only a few)
 std::mutex g_ws_mutex;
 }  // namespace
 
@@ -38,7 +40,7 @@ void* workspace(WorkspaceSlot slot, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     Slot& s = g_ws[dev][slot];
     if (s.bytes < bytes) {
-        if (s.ptr) (void)hipFree(s.ptr);  // hipFree synchronises the device: no kernel still reads the old buffer
+        if (s.ptr) g_retired.push_back(s.ptr);
         s.ptr = nullptr;
         s.bytes = 0;
         size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
@@ -59,6 +61,8 @@ void release_workspaces() {
             if (s.ptr) (void)hipFree(s.ptr);
             s = Slot{};
         }
+    for (void* p : g_retired) (void)hipFree(p);
+    g_retired.clear();
 }
 
 // ---- per-kernel timing ------------------------------------------------------------------------------
