@@ -496,6 +496,217 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_kernel(const Rec<T>* __
     }
 }
 
+// =====================================================================================================================
+// Single-pass variant ("directory"): no counting pass and no global scans.
+//   K3d  one workgroup per (1024 samples, level): the samples' records are counted per tile in LDS, laid out grouped by tile and
+//        copied, as ONE contiguous block, into the workgroup's own fixed-capacity region of the record buffer; a directory
+//        entry (offset << 16 | count) per (level, tile, chunk) says where each tile's run sits inside that block.
+//   K4d  one workgroup per (tile, range of chunks): reads its directory entries (64 per wave at once), then streams the runs.
+// The record buffer is addressed, not packed (capacity 8192 records per region, the worst case of every pair straddling a
+// tile edge), which is what 288 GB of HBM is for.
+constexpr uint32_t kRegionRecords = 2 * 4 * kBinSamples;  // capacity of one (chunk, level) region
+constexpr uint32_t kDirLdsBytes = (kSumThreads / kWave) * 2 * kWave * 4;  // K4d: per-wave run tables
+
+struct DirTable {
+    int32_t offsets[kMaxLevels + 1];
+    uint32_t tile_base[kMaxLevels + 1];  // global tile index of each level's first tile
+    uint32_t item_base[kMaxLevels + 1];  // first K4d work item of each level
+    uint32_t slices[kMaxLevels];         // work items per tile of the level (each takes a range of chunks)
+};
+
+template <typename T, int D, bool BLC>
+__global__ __launch_bounds__(kBinThreads) void bin_fill_dir_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                  const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
+                                                                  uint32_t gridtype, bool align_corners, const DirTable tab,
+                                                                  uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, bool merge_runs,
+                                                                  uint32_t nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel];
+    constexpr int NP = Sample<T, D>::NP;
+    constexpr uint32_t kRows = rows_per_tile<T>();
+    Rec<T>* stage = reinterpret_cast<Rec<T>*>(smem);
+    if (blockIdx.x == 0 && threadIdx.x <= L && offsets[threadIdx.x] != tab.offsets[threadIdx.x]) __builtin_trap();  // host copy vs device table
+    const uint32_t group = blockIdx.x / (kXcds * L), rem = blockIdx.x % (kXcds * L);
+    const uint32_t level = rem / kXcds, chunk = group * kXcds + rem % kXcds;  // id % 8 = chunk % 8 = the XCD that runs it
+    if (chunk >= nchunks) return;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t b = chunk * kBinSamples + threadIdx.x;
+    const bool in_batch = b < B;
+    const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
+    const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
+    Rec<T>* region = records + ((size_t)level * nchunks + chunk) * kRegionRecords;
+
+    if (threadIdx.x < kMaxTilesPerLevel) hist[threadIdx.x] = 0;
+    float xs[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
+    float g[2] = {0.0f, 0.0f};
+    if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
+    const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
+    Sample<T, D> sm;
+    make_sample<T, D, true>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, hashmap_size, merge_runs);
+    __syncthreads();
+
+    // ---- count per tile
+    if (sm.valid) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const uint32_t ta = sm.row_a[q] / kRows, tb = sm.row_b[q] / kRows;
+            atomicAdd(&hist[ta], 1u);
+            if (ta != tb) atomicAdd(&hist[tb], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWave) {  // wave 0: exclusive prefix over the level's tiles (two per lane) + the directory entries
+        uint32_t cnt[2] = {hist[lane], hist[lane + kWave]};
+        uint32_t incl[2] = {cnt[0], cnt[1]};
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o0 = __shfl_up(incl[0], off, kWave), o1 = __shfl_up(incl[1], off, kWave);
+            if ((int)lane >= off) { incl[0] += o0; incl[1] += o1; }
+        }
+        const uint32_t first_half = __shfl(incl[0], kWave - 1, kWave);
+        const uint32_t base[2] = {incl[0] - cnt[0], first_half + incl[1] - cnt[1]};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t t = lane + h * kWave;
+            lbase[t] = base[h];
+            lcount[t] = 0;
+            if (t < ntiles) dir[((size_t)level * kMaxTilesPerLevel + t) * nchunks + chunk] = (base[h] << 16) | cnt[h];  // both < 2^16
+        }
+        if (lane == kWave - 1) lbase[kMaxTilesPerLevel] = first_half + incl[1];
+    }
+    __syncthreads();
+
+    // ---- place: LDS for the first kStageRecords slots of the block, the rest straight to the region
+    if (sm.valid) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const uint32_t ta = sm.row_a[q] / kRows, tb = sm.row_b[q] / kRows;
+            const uint32_t la = sm.row_a[q] - ta * kRows, lb = sm.row_b[q] - tb * kRows;
+            const uint32_t sa = lbase[ta] + atomicAdd(&lcount[ta], 1u);
+            Rec<T>* da = sa < kStageRecords ? stage + sa : region + sa;
+            if (ta == tb) {
+                put_record<T>(da, la | (lb << kRowBits) | kHasB, sm.va[q], sm.vb[q]);
+            } else {
+                const uint32_t sb = lbase[tb] + atomicAdd(&lcount[tb], 1u);
+                put_record<T>(da, la, sm.va[q], sm.vb[q]);
+                put_record<T>(sb < kStageRecords ? stage + sb : region + sb, lb, sm.vb[q], sm.va[q]);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = min(lbase[kMaxTilesPerLevel], kStageRecords);
+#pragma unroll 5
+    for (uint32_t i = threadIdx.x; i < total; i += kBinThreads) region[i] = stage[i];  // one contiguous block, tile order preserved
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
+                                                                   const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t kRows = rows_per_tile<T>();
+    constexpr bool kFixed = sizeof(T) == 2;
+    uint32_t level = 0;
+    while (level + 1 < L && blockIdx.x >= tab.item_base[level + 1]) level++;
+    if (blockIdx.x >= tab.item_base[L]) return;
+    const uint32_t slices = tab.slices[level];
+    const uint32_t local = blockIdx.x - tab.item_base[level];
+    const uint32_t t = local / slices, item = local % slices;
+    const uint32_t per = div_up(nchunks, slices);
+    const uint32_t c_lo = item * per, c_hi = min(nchunks, c_lo + per);
+    const uint32_t rows_level = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
+    const uint32_t row0 = t * kRows;
+    const uint32_t nrows = min(kRows, rows_level - row0);
+    T* __restrict__ dst = grad_grid + ((size_t)(uint32_t)tab.offsets[level] + row0) * 2;
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    constexpr uint32_t kWaves = kSumThreads / kWave;
+
+    {   // zero the accumulators
+        float4_t* z = reinterpret_cast<float4_t*>(smem);
+        const uint32_t nq = kFixed ? nrows : (nrows + 1) / 2;
+        for (uint32_t i = threadIdx.x; i < nq; i += kSumThreads) z[i] = float4_t{0, 0, 0, 0};
+    }
+    __syncthreads();
+
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
+    float* acc32 = reinterpret_cast<float*>(smem);
+    const uint32_t* drow = dir + ((size_t)level * kMaxTilesPerLevel + t) * nchunks;
+    auto add_record = [&](const Rec<T>& r) {
+        const uint32_t ra = r.rows & kRowMask, rb = (r.rows >> kRowBits) & kRowMask;
+        const bool has_b = (r.rows & kHasB) != 0;
+        if constexpr (kFixed) {
+            atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)half_to_fixed(r.va[0]));
+            atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)half_to_fixed(r.va[1]));
+            if (has_b) {
+                atomicAdd(acc64 + (size_t)rb * 2, (unsigned long long)half_to_fixed(r.vb[0]));
+                atomicAdd(acc64 + (size_t)rb * 2 + 1, (unsigned long long)half_to_fixed(r.vb[1]));
+            }
+        } else {
+            atomicAdd(acc32 + (size_t)ra * 2, r.va0);
+            atomicAdd(acc32 + (size_t)ra * 2 + 1, r.va1);
+            if (has_b) {
+                atomicAdd(acc32 + (size_t)rb * 2, r.vb0);
+                atomicAdd(acc32 + (size_t)rb * 2 + 1, r.vb1);
+            }
+        }
+    };
+    // a wave takes 64 runs at a time (chunks c_lo + wave + 16 k): their lengths are prefix-summed into a per-wave LDS table and the
+    // wave walks the concatenation as ONE flat list -- every lane busy, loads independent -- finding the run of an element with a
+    // 6-step search in that table.  (A wave per run left half the lanes idle: 159 us; a lane per run made every load divergent: 410.)
+    uint32_t* s_excl = reinterpret_cast<uint32_t*>(smem + kTileBytes) + wave * 2 * kWave;  // [64] exclusive prefix, then [64] record index
+    uint32_t* s_base = s_excl + kWave;
+    for (uint32_t cb = c_lo + wave; cb < c_hi; cb += kWaves * kWave) {
+        const uint32_t c = cb + lane * kWaves;
+        const uint32_t entry = c < c_hi ? drow[c] : 0u;
+        const uint32_t cnt = entry & 0xffffu;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave);
+            if ((int)lane >= off) incl += o;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+        s_excl[lane] = incl - cnt;
+        s_base[lane] = (uint32_t)(((size_t)level * nchunks + (c < c_hi ? c : c_lo)) * kRegionRecords) + (entry >> 16);  // < 2^32 records
+        for (uint32_t i = lane; i < total; i += 2 * kWave) {
+            uint32_t k0 = 0, k1 = 0;
+            const uint32_t i1 = i + kWave;
+#pragma unroll
+            for (uint32_t step = kWave / 2; step > 0; step >>= 1) {
+                if (s_excl[k0 + step] <= i) k0 += step;
+                if (s_excl[k1 + step] <= i1) k1 += step;
+            }
+            const bool l1 = i1 < total;
+            const Rec<T> r0 = records[(size_t)s_base[k0] + (i - s_excl[k0])];
+            const Rec<T> r1 = records[(size_t)s_base[l1 ? k1 : k0] + (l1 ? i1 - s_excl[k1] : i - s_excl[k0])];
+            add_record(r0);
+            if (l1) add_record(r1);
+        }
+    }
+    __syncthreads();
+
+    const bool sole = slices == 1;
+    if constexpr (kFixed) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kSumThreads) {
+            const long long s0 = (long long)acc64[(size_t)i * 2], s1 = (long long)acc64[(size_t)i * 2 + 1];
+            if ((s0 | s1) == 0) continue;
+            const half2_t v = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
+            half2_t* p = reinterpret_cast<half2_t*>(dst) + i;
+            if (sole) *p = *p + v;
+            else unsafeAtomicAdd(reinterpret_cast<__half2*>(p), __builtin_bit_cast(__half2, v));
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < nrows * 2; i += kSumThreads) {
+            const float v = acc32[i];
+            if (v == 0.0f) continue;
+            float* p = reinterpret_cast<float*>(dst) + i;
+            if (sole) *p = *p + v;
+            else unsafeAtomicAdd(p, v);
+        }
+    }
+}
+
 // ---- host: cached copy of the level table -----------------------------------------------------------------------------
 struct TableKey {
     const void* ptr; uint32_t L; int dev;
@@ -543,6 +754,49 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
 
     constexpr uint32_t NP = 1u << (D - 1);
     const uint32_t nchunks = div_up(B, kBinSamples);
+    {   // single-pass directory variant (default); NERFTEX_GRID_BWD_PATH=counted selects the count / scan / fill / sum pipeline below
+        static const bool counted = getenv("NERFTEX_GRID_BWD_PATH") != nullptr && getenv("NERFTEX_GRID_BWD_PATH")[0] == 'c';
+        if (!counted) {
+            DirTable dt{};
+            uint32_t items = 0;
+            for (uint32_t l = 0; l < L; l++) {
+                dt.offsets[l] = tab.offsets[l];
+                dt.tile_base[l] = tab.tile_base[l];
+                const uint32_t nt = tab.tile_base[l + 1] - tab.tile_base[l];
+                const uint64_t expect = (uint64_t)B * NP / (nt ? nt : 1);  // records per tile if nothing merges
+                uint32_t sl = (uint32_t)div_up<uint64_t>(expect, kSliceRecords);
+                sl = sl < 1 ? 1 : (sl > nchunks ? nchunks : sl);
+                dt.slices[l] = sl;
+                dt.item_base[l] = items;
+                items += nt * sl;
+            }
+            dt.offsets[L] = tab.offsets[L];
+            dt.tile_base[L] = tiles;
+            dt.item_base[L] = items;
+            const size_t dir_bytes = (sizeof(uint32_t) * (size_t)L * kMaxTilesPerLevel * nchunks + 255) / 256 * 256;
+            char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords));
+            if (!dbase) return NERFTEX_ERR_HIP;
+            uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
+            Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes);
+            const bool merge = getenv("NERFTEX_GRID_BWD_NOMERGE") == nullptr;
+            {
+                auto fill = blc ? bin_fill_dir_kernel<T, D, true> : bin_fill_dir_kernel<T, D, false>;
+                const size_t lds = sizeof(Rec<T>) * (size_t)kStageRecords;
+                NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+                KernelTimer kt("bin_fill_dir_kernel", st, kTimeGrid);
+                hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), dim3(kBinThreads), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype,
+                                   align_corners, dt, dir, recs, merge, nchunks);
+            }
+            if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
+            {
+                auto kernel = sum_tiles_dir_kernel<T>;
+                NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
+                KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
+                hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid);
+            }
+            return check_launch("grid_encode_backward(sum)");
+        }
+    }
     const size_t n_counts = (size_t)L * nchunks * kMaxTilesPerLevel;
     const size_t max_records = (size_t)B * L * NP * 2;  // worst case: every pair straddles a tile edge
     static const uint32_t slice_records = [] {  // records per K4 work item (tuning switch; default kSliceRecords)
