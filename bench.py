@@ -41,8 +41,9 @@ TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backwar
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
-    "grid_encode_backward": ("grad_to_level_major_kernel", "bin_count_kernel", "scan_tiles_kernel", "scan_global_kernel", "bin_fill_kernel",
-                             "sum_tiles_kernel", "grid_backward_owner_kernel", "grid_backward_kernel", "grid_input_backward_kernel"),
+    "grid_encode_backward": ("bin_fill_dir_kernel", "sum_tiles_dir_kernel", "grad_to_level_major_kernel", "bin_count_kernel", "scan_tiles_kernel",
+                             "scan_global_kernel", "bin_fill_kernel", "sum_tiles_kernel", "grid_backward_owner_kernel", "grid_backward_kernel",
+                             "grid_input_backward_kernel"),
 }
 
 

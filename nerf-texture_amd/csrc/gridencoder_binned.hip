@@ -764,7 +764,8 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
                 dt.tile_base[l] = tab.tile_base[l];
                 const uint32_t nt = tab.tile_base[l + 1] - tab.tile_base[l];
                 const uint64_t expect = (uint64_t)B * NP / (nt ? nt : 1);  // records per tile if nothing merges
-                uint32_t sl = (uint32_t)div_up<uint64_t>(expect, kSliceRecords);
+                static const uint32_t dir_slice = getenv("NERFTEX_GRID_BWD_SLICE") && atol(getenv("NERFTEX_GRID_BWD_SLICE")) >= 1024 ? (uint32_t)atol(getenv("NERFTEX_GRID_BWD_SLICE")) : kSliceRecords;
+                uint32_t sl = (uint32_t)div_up<uint64_t>(expect, dir_slice);
                 sl = sl < 1 ? 1 : (sl > nchunks ? nchunks : sl);
                 dt.slices[l] = sl;
                 dt.item_base[l] = items;
