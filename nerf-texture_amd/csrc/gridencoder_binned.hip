@@ -5,7 +5,9 @@
 //     ~30 M distinct line updates per step (>= 1.4 ms);
 //   * LDS FLOAT atomics (ds_add_f32, ds_pk_add_f16) retire one lane every ~3 clocks per CU (0.2 T lane-ops/s chip-wide) with or
 //     without bank conflicts, LDS INTEGER atomics 16-27x faster (ds_add_u64: 3.3 T/s, ds_add_u32: 5.3 T/s).
-// So every contribution is binned once and the fp16 table is accumulated in 64-bit FIXED POINT:
+// So every contribution is binned once and the fp16 table is accumulated in 64-bit FIXED POINT.  Two pipelines live in this file:
+// the DEFAULT single-pass one (K3d fill into fixed-capacity regions + directory, K4d sum; see "Single-pass variant" below) and the
+// earlier four-stage one it replaced (NERFTEX_GRID_BWD_PATH=counted), described first because K3d / K4d reuse its pieces:
 //   K1 count   a wave per level, a workgroup per 1024 samples: 2^(D-1) records per (sample, level) -- a record is the pair of
 //              x-neighbour corners, whose rows are adjacent for dense levels and inside one aligned 2^k block for hashed
 //              levels (prime[0] == 1) -- histogrammed per table tile in LDS; per (workgroup, level, tile) counts
