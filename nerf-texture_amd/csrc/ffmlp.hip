@@ -578,7 +578,10 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
                 if (32 * ks + 8 * g < IN) xin[t][ks] = *reinterpret_cast<const half8_t*>(X + (size_t)(row0 + 16 * t + r) * IN + 32 * ks + 8 * g);
                 else xin[t][ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
             }
-        half4_t y[NL][NT][OT];  // y[j] = post-activations of hidden layer NL-1-j, lane (r, g) holds features 16 ot + 4 g .. + 3 of row r
+        // yop[j][t][s] = post-activations of hidden layer NL-1-j for 16 rows x 32 features, already in the packed-operand form
+        // (slot q < 4: feature 16(2s) + 4g + q, slot 4 + q: feature 16(2s+1) + 4g + q of row r): what the recomputation produces anyway,
+        // what the transposing MFMAs consume, and what the activation derivative reads element by element
+        half8_t yop[NL][NT][KSH];
         float4_t acc[NT][OT];
         if constexpr (RECOMPUTE) {
             // the forward kernel's chain, verbatim (layer 0 from the row-major input, then register to register), one 16-row tile
@@ -597,17 +600,14 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
                 for (int l = 0; l < NL; l++) {
                     half8_t fop[KSH];
 #pragma unroll
-                    for (int ot = 0; ot < OT; ot++) {
-                        half4_t v;
+                    for (int ot = 0; ot < OT; ot++)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            fa[ot][q] = act_fwd<ACT>(act, fa[ot][q]);
-                            v[q] = (half_t)fa[ot][q];
-                        }
-                        y[NL - 1 - l][t][ot] = v;
+                        for (int q = 0; q < 4; q++) fa[ot][q] = act_fwd<ACT>(act, fa[ot][q]);
+#pragma unroll
+                    for (int s = 0; s < KSH; s++) {
+                        fop[s] = pack_operand(fa[2 * s], fa[2 * s + 1]);
+                        yop[NL - 1 - l][t][s] = fop[s];
                     }
-#pragma unroll
-                    for (int s = 0; s < KSH; s++) fop[s] = pack_operand(fa[2 * s], fa[2 * s + 1]);
                     if (l + 1 < NL) {
                         const half8_t* fl = frags + (size_t)(base_fh + l * per_hidden) * 64;
 #pragma unroll
@@ -626,9 +626,12 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
 #pragma unroll
                 for (int t = 0; t < NT; t++)
 #pragma unroll
-                    for (int ot = 0; ot < OT; ot++)
-                        y[j][t][ot] = *reinterpret_cast<const half4_t*>(fwd + (size_t)(NL - 1 - j) * layer_stride +
-                                                                        (size_t)(row0 + 16 * t + r) * HIDDEN + 16 * ot + 4 * g);
+                    for (int s = 0; s < KSH; s++) {
+                        const half_t* row = fwd + (size_t)(NL - 1 - j) * layer_stride + (size_t)(row0 + 16 * t + r) * HIDDEN + 4 * g;
+                        const half4_t lo = *reinterpret_cast<const half4_t*>(row + 16 * (2 * s));
+                        const half4_t hi = *reinterpret_cast<const half4_t*>(row + 16 * (2 * s + 1));
+                        yop[j][t][s] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
         }
 
         // ---- dL/d(last hidden activation) = W_out^T . grad^T
@@ -650,14 +653,8 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
             half8_t Bm[OT];
 #pragma unroll
             for (int s = 0; s < KSH; s++) {
-                half8_t x0, x1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    x0[q] = y[j][0][2 * s][q]; x0[4 + q] = y[j][0][2 * s + 1][q];
-                    x1[q] = y[j][1][2 * s][q]; x1[4 + q] = y[j][1][2 * s + 1][q];
-                }
-                Bm[2 * s] = pack_operand(mfma16(x0, selP0, zero), mfma16(x1, selP0, zero));
-                Bm[2 * s + 1] = pack_operand(mfma16(x0, selP1, zero), mfma16(x1, selP1, zero));
+                Bm[2 * s] = pack_operand(mfma16(yop[j][0][s], selP0, zero), mfma16(yop[j][1][s], selP0, zero));
+                Bm[2 * s + 1] = pack_operand(mfma16(yop[j][0][s], selP1, zero), mfma16(yop[j][1][s], selP1, zero));
             }
             if (j == 0) {
 #pragma unroll
@@ -675,7 +672,14 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
 #pragma unroll
                 for (int ot = 0; ot < OT; ot++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[t][ot][q] = act_bwd<ACT>(act, (float)(half_t)acc[t][ot][q], (float)y[j][t][ot][q]);
+                    for (int q = 0; q < 4; q++) {
+                        const half_t yv = yop[j][t][ot / 2][4 * (ot & 1) + q];
+                        // ReLU: a 0/1 mask commutes with the rounding to half that pack_operand applies next, so the incoming gradient
+                        // need not be narrowed and widened first (two conversions per element saved); other activations keep the
+                        // dgrad kernel's order (narrow, multiply, narrow)
+                        if constexpr (ACT == (int)kRelu) acc[t][ot][q] = yv > (half_t)0.0f ? acc[t][ot][q] : 0.0f;
+                        else acc[t][ot][q] = act_bwd<ACT>(act, (float)(half_t)acc[t][ot][q], (float)yv);
+                    }
 #pragma unroll
                 for (int s = 0; s < KSH; s++) bop[t][s] = pack_operand(acc[t][2 * s], acc[t][2 * s + 1]);
             }
