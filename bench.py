@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
     ap.add_argument("--no-other", action="store_true", help="skip the short run of the other single-GPU configuration")
     ap.add_argument("--no-fused-glue", action="store_true", help="run the ops between/after the two FFMLPs as framework ops (reference structure)")
+    ap.add_argument("--no-fused-tail", action="store_true", help="background blend / depth / MSE as framework ops instead of one kernel per direction")
+    ap.add_argument("--no-fused-opt", action="store_true", help="torch.optim.Adam(fused=True) on an fp32 table instead of ngp_harness.optim.TableAdam")
     ap.add_argument("--graph-split", action="store_true", help="1 GPU: use the two-graph form of the multi-GPU path (for testing it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
@@ -170,13 +172,22 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # is two graphs (forward + backward | optimizer) with the gradient all-reduce launched eagerly between them.
     use_graph = graph
     split_graph = use_graph and (world > 1 or args.graph_split)
-    opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
+    use_amp = args.dtype == "fp16"
+    fused_opt = use_amp and not args.no_fused_opt
+    fused_tail = not args.no_fused_tail
+    dp.broadcast([p.data for p in field.parameters()])
+    if fused_opt:  # same Adam, the table's fp16 gradient consumed as produced (ngp_harness/optim.py)
+        from ngp_harness.optim import TableAdam
+
+        opt = TableAdam(field.encoder, [p for p in field.parameters() if p is not field.encoder.embeddings], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        trainable = opt.trainable()
+    else:
+        opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
+        trainable = list(field.parameters())
     # the hash-table gradient crosses xGMI as fp16 (it is fp16-valued under autocast): half the all-reduce bytes
     # (the 1/world of the gradient average is folded into the loss below, so the exchange is a plain sum: no division pass over 48 MB)
-    reducer = dp.FlatGradAllReduce(field.parameters(), average=False, big_comm_dtype=torch.float16 if args.dtype == "fp16" else None)
+    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=torch.float16 if args.dtype == "fp16" else None)
     inv_world = 1.0 / world
-    reducer.broadcast_parameters()
-    use_amp = args.dtype == "fp16"
     scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
     total_samples = torch.zeros((), dtype=torch.int64, device=dev)
     dt_gamma = 1 / 128
@@ -186,10 +197,14 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         ro, rd = pool[k % n_pool]
         reducer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
-            image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024)
-            loss = torch.nn.functional.mse_loss(image, gt[k % n_pool])
-            if world > 1:
-                loss = loss * inv_world
+            if fused_tail:
+                image, depth, loss, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
+                                                                    target=gt[k % n_pool], loss_mul=inv_world)
+            else:
+                image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024)
+                loss = torch.nn.functional.mse_loss(image, gt[k % n_pool])
+                if world > 1:
+                    loss = loss * inv_world
         scaler.scale(loss).backward()
         reducer.all_reduce()
         scaler.step(opt)
@@ -214,11 +229,16 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         ro, rd, tgt = pool_o.index_select(0, batch_idx)[0], pool_d.index_select(0, batch_idx)[0], gt.index_select(0, batch_idx)[0]
         reducer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
-            image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
-                                                          counter=graph_counter, mean_count=gstate["M"])
-            loss = torch.nn.functional.mse_loss(image, tgt)
-            if world > 1:
-                loss = loss * inv_world
+            if fused_tail:
+                image, depth, loss, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
+                                                                    counter=graph_counter, mean_count=gstate["M"], target=tgt,
+                                                                    loss_mul=inv_world)
+            else:
+                image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
+                                                              counter=graph_counter, mean_count=gstate["M"])
+                loss = torch.nn.functional.mse_loss(image, tgt)
+                if world > 1:
+                    loss = loss * inv_world
         scaler.scale(loss).backward()
         total_samples.add_(graph_counter[0].to(torch.int64))
 
@@ -322,7 +342,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     elapsed = float(elapsed.item())
     samples = int(samples.item())
     res = dict(value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
-               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp,
+               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt,
                graph=("two replayed HIP graphs per step (forward+backward | optimizer), eager all-reduce between" if split_graph else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
@@ -442,7 +462,8 @@ def main():
                 "workload": WORKLOADS[args.mlp],
                 "rays_per_batch_per_gpu": args.rays, "global_rays": res["n_global"], "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
-                "optimizer": "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)",
+                "optimizer": ("Adam(eps=1e-15)+GradScaler; table: one HIP kernel on the fp16 gradient (fp32 master + fp16 copy), MLPs: torch fused Adam"
+                              if res.get("fused_opt") else "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)"),
                 "launch": res["graph"] if res["graph"] else "eager launches",
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
             },

@@ -248,6 +248,31 @@ int nerftex_field_out_forward(const void* hc, uint32_t B, float* rgbs, void* str
 /* grad_hc [B,16] fp16 = sigmoid backward of the fp16-narrowed grad_rgbs, columns 3..15 zero                      */
 int nerftex_field_out_backward(const float* grad_rgbs, const float* rgbs, uint32_t B, void* grad_hc, void* stream);
 
+/* -------------------------------------------------------------------------
+ * train step ends (harness-level, not reference entry points: the reference leaves both to torch ops)
+ * ------------------------------------------------------------------------- */
+
+/* Tail of the training render + loss (nerf/renderer.py:417-425, MSE of nerf/utils.py:602-640), all fp32:
+ *   image_out [N,3] = image + (1 - weights_sum) * bg;   depth_out [N] = clamp(depth - nears, 0) / (fars - nears);
+ *   *loss = mean((image_out - target)^2) * loss_mul     (block partials added in index order: run-to-run identical).
+ * partial: >= ceil(N/256) floats of scratch; ticket: one uint32 that is 0 on entry and left 0.                       */
+int nerftex_render_tail_forward(const float* weights_sum, const float* depth, const float* image, const float* nears,
+                                const float* fars, const float* target, float bg, float loss_mul, uint32_t N,
+                                float* image_out, float* depth_out, float* partial, uint32_t* ticket, float* loss,
+                                void* stream);
+/* grad_image [N,3] = (2 / 3N) * (image_out - target) * (*grad_loss * loss_mul);  grad_weights_sum [N] = -sum_c(grad_image) * bg */
+int nerftex_render_tail_backward(const float* grad_loss, float loss_mul, const float* image_out, const float* target,
+                                 float bg, uint32_t N, float* grad_image, float* grad_weights_sum, void* stream);
+
+/* One Adam step (main_nerf.py:128: betas (0.9, 0.99), eps 1e-15, no weight decay) of an fp32 master table from the
+ * fp16 gradient the encoder backward produced, writing the fp16 copy the next forward reads: param, exp_avg,
+ * exp_avg_sq [n] fp32 in place, grad_half [n] fp16 in, param_half [n] fp16 out.  step: device float, already
+ * incremented (1 on the first step).  grad_scale / found_inf: device floats of a GradScaler or NULL -- the gradient
+ * is divided by *grad_scale; the whole step is skipped when *found_inf == 1.  Arithmetic as torch's fused Adam.    */
+int nerftex_table_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const void* grad_half, void* param_half,
+                            uint64_t n, const float* step, double lr, double beta1, double beta2, double eps,
+                            const float* grad_scale, const float* found_inf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,6 +150,9 @@ class GridEncoder(nn.Module):
         """The table handed to grid_encode.  Training: the fp32 parameter (grid_encode narrows it under autocast, autograd widens
         the gradient back).  No-grad inference under autocast: the narrowed copy is kept until the parameter changes -- an 800x800
         frame calls the encoder ~60 times and the 24 MiB cast is the same every time."""
+        leaf = getattr(self, "half_leaf", None)  # an optimizer that keeps the fp16 table itself (ngp_harness/optim.py): no cast, fp16 grad
+        if leaf is not None and torch.is_autocast_enabled():
+            return leaf
         e = self.embeddings
         if torch.is_grad_enabled() or not torch.is_autocast_enabled() or self.level_dim % 2 != 0 or e.dtype == torch.half:
             return e

@@ -20,6 +20,7 @@ from ._build import build  # noqa: E402,F401
 
 
 _u32, _f32, _i, _vp, _sz = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_size_t
+_u64, _f64 = C.c_uint64, C.c_double
 
 # name -> argument ctypes, in the order of include/nerftex_hip.h
 _SIGNATURES = {
@@ -27,6 +28,9 @@ _SIGNATURES = {
     "nerftex_field_mid_backward": [_vp, _vp, _vp, _u32, _vp, _vp],
     "nerftex_field_out_forward": [_vp, _u32, _vp, _vp],
     "nerftex_field_out_backward": [_vp, _vp, _u32, _vp, _vp],
+    "nerftex_render_tail_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_render_tail_backward": [_vp, _f32, _vp, _vp, _f32, _u32, _vp, _vp, _vp],
+    "nerftex_table_adam_step": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "nerftex_profile_enable": [_i],
     "nerftex_profile_reset": [],
     "nerftex_profile_report": [C.c_char_p, _sz],

@@ -46,6 +46,13 @@ def shard(n_global, rank, world):
     return lo, hi
 
 
+def broadcast(tensors, src=0):
+    """Rank `src`'s values to every rank (replica initialisation)."""
+    if world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t, src)
+
+
 class FlatGradAllReduce:
     """Gradient exchange of data-parallel training: one collective for everything small, one per big tensor.
 

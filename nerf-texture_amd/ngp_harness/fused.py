@@ -58,3 +58,55 @@ class _color_out(Function):
 
 sigma_geo_dir = _sigma_geo_dir.apply
 color_out = _color_out.apply
+
+
+class _render_tail(Function):
+    """image + (1 - weights_sum) * bg, depth normalisation and mean squared error against `target` in one launch
+    (nerf/renderer.py:417-425 + the MSE of nerf/utils.py:602-640); returns (image_out, depth_out, loss * loss_mul).
+    Only `loss` carries a gradient (to `image` and `weights_sum`); image_out / depth_out are outputs for display."""
+
+    @staticmethod
+    def forward(ctx, weights_sum, depth, image, nears, fars, target, bg, loss_mul):
+        args = [t.contiguous().float() for t in (weights_sum, depth, image, nears, fars, target)]
+        weights_sum, depth, image, nears, fars, target = args
+        N, dev = weights_sum.shape[0], weights_sum.device
+        assert image.shape == (N, 3) and target.shape == (N, 3) and depth.shape == (N,)
+        image_out = torch.empty_like(image)
+        depth_out = torch.empty_like(depth)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        scratch = _tail_scratch(dev, (N + 255) // 256)
+        check(lib.nerftex_render_tail_forward(ptr(weights_sum), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(target), float(bg),
+                                              float(loss_mul), N, ptr(image_out), ptr(depth_out), ptr(scratch[1]), ptr(scratch[0]), ptr(loss),
+                                              stream()))
+        ctx.save_for_backward(image_out, target)
+        ctx.consts = (float(bg), float(loss_mul))
+        ctx.mark_non_differentiable(image_out, depth_out)
+        return image_out, depth_out, loss
+
+    @staticmethod
+    def backward(ctx, _gi, _gd, grad_loss):
+        image_out, target = ctx.saved_tensors
+        bg, loss_mul = ctx.consts
+        N = image_out.shape[0]
+        grad_loss = grad_loss.contiguous().float()
+        grad_image = torch.empty_like(image_out)
+        grad_ws = torch.empty(N, dtype=torch.float32, device=image_out.device)
+        check(lib.nerftex_render_tail_backward(ptr(grad_loss), loss_mul, ptr(image_out), ptr(target), bg, N, ptr(grad_image), ptr(grad_ws),
+                                               stream()))
+        return grad_ws, None, grad_image, None, None, None, None, None
+
+
+_SCRATCH = {}
+
+
+def _tail_scratch(dev, blocks):
+    """(ticket uint32 [1] kept at zero by the kernel, partial sums float [blocks]) per device."""
+    s = _SCRATCH.get(dev)
+    if s is None or s[1].numel() < blocks:
+        s = (torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(max(blocks, 1024), dtype=torch.float32, device=dev))
+        _SCRATCH[dev] = s
+    return s
+
+
+def render_tail(weights_sum, depth, image, nears, fars, target, bg=1.0, loss_mul=1.0):
+    return _render_tail.apply(weights_sum, depth, image, nears, fars, target, bg, loss_mul)

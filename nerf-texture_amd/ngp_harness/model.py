@@ -155,12 +155,14 @@ class Renderer(nn.Module):
         self.local_step = 0
 
     def render_train(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=True, force_all_rays=False, max_steps=1024, counter=None,
-                     mean_count=None):
+                     mean_count=None, target=None, loss_mul=1.0):
         """Training branch of run_cuda (:361-425). Returns image [N,3], depth [N], and the sample count tensor.
 
         counter / mean_count: for graph replay the caller supplies a fixed counter tensor and a fixed buffer size and does the
         step-counter ring bookkeeping itself (`commit_counter`); by default both come from the ring like in the reference."""
         marched, counter = self.march_train(rays_o, rays_d, dt_gamma, perturb, force_all_rays, max_steps, counter, mean_count)
+        if target is not None:  # fused tail: (image, depth, loss, counter)
+            return (*self.shade_train(marched, bg_color, target, loss_mul), counter)
         image, depth = self.shade_train(marched, bg_color)
         return image, depth, counter
 
@@ -178,12 +180,20 @@ class Renderer(nn.Module):
                                                                 128, force_all_rays, dt_gamma, max_steps)
         return (nears, fars, xyzs, dirs, deltas, rays), counter
 
-    def shade_train(self, marched, bg_color=1):
-        """Second half (:389-425): field evaluation, compositing, background."""
+    def shade_train(self, marched, bg_color=1, target=None, loss_mul=1.0):
+        """Second half (:389-425): field evaluation, compositing, background.
+
+        target [N,3] (with a scalar bg_color): the blend, the depth normalisation and the MSE against the target pixels run as one
+        kernel (ngp_harness/fused.py render_tail); returns (image, depth, loss * loss_mul) instead of (image, depth)."""
         nears, fars, xyzs, dirs, deltas, rays = marched
         sigmas, rgbs, _ = self.field(xyzs, dirs)
-        sigmas = self.density_scale * sigmas
+        if self.density_scale != 1:  # x * 1.0 is x: not launched
+            sigmas = self.density_scale * sigmas
         weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
+        if target is not None:
+            from . import fused
+
+            return fused.render_tail(weights_sum, depth, image, nears, fars, target, float(bg_color), loss_mul)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth
@@ -219,7 +229,8 @@ class Renderer(nn.Module):
                                                         self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128, perturb, dt_gamma,
                                                         max_steps)
             sigmas, rgbs, _ = self.field(xyzs, dirs)
-            sigmas = self.density_scale * sigmas
+            if self.density_scale != 1:
+                sigmas = self.density_scale * sigmas
             raymarching.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], sigmas, rgbs, deltas, weights_sum, depth, image)
             n_samples += xyzs.shape[0]
             step += n_step
