@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--no-fused-glue", action="store_true", help="run the ops between/after the two FFMLPs as framework ops (reference structure)")
     ap.add_argument("--no-fused-tail", action="store_true", help="background blend / depth / MSE as framework ops instead of one kernel per direction")
     ap.add_argument("--no-fused-opt", action="store_true", help="torch.optim.Adam(fused=True) on an fp32 table instead of ngp_harness.optim.TableAdam")
+    ap.add_argument("--no-fused-amp", action="store_true", help="torch.amp.GradScaler instead of ngp_harness.optim.FusedAmp")
     ap.add_argument("--graph-split", action="store_true", help="1 GPU: use the two-graph form of the multi-GPU path (for testing it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
@@ -173,22 +174,53 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     use_graph = graph
     split_graph = use_graph and (world > 1 or args.graph_split)
     use_amp = args.dtype == "fp16"
-    fused_opt = use_amp and not args.no_fused_opt
+    fused_opt = use_amp and mlp == "ffmlp" and not args.no_fused_opt
     fused_tail = not args.no_fused_tail
+    fused_amp = fused_opt and not args.no_fused_amp
     dp.broadcast([p.data for p in field.parameters()])
-    if fused_opt:  # same Adam, the table's fp16 gradient consumed as produced (ngp_harness/optim.py)
-        from ngp_harness.optim import TableAdam
+    if fused_opt:  # same Adam; every parameter's fp16 copy is the autograd leaf, its fp16 gradient consumed as produced (ngp_harness/optim.py)
+        from ngp_harness.optim import FusedAmp, HalfLeafAdam
 
-        opt = TableAdam(field.encoder, [p for p in field.parameters() if p is not field.encoder.embeddings], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights"), (field.color_net, "weights")], lr=1e-2,
+                           betas=(0.9, 0.99), eps=1e-15)
         trainable = opt.trainable()
     else:
         opt = torch.optim.Adam(field.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=use_graph)
         trainable = list(field.parameters())
     # the hash-table gradient crosses xGMI as fp16 (it is fp16-valued under autocast): half the all-reduce bytes
     # (the 1/world of the gradient average is folded into the loss below, so the exchange is a plain sum: no division pass over 48 MB)
-    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=torch.float16 if args.dtype == "fp16" else None)
+    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=torch.float16 if args.dtype == "fp16" else None,
+                                   big_numel=0 if fused_opt else 1 << 20)
     inv_world = 1.0 / world
-    scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
+    # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
+    amp = FusedAmp(opt) if fused_amp else None
+    scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=use_amp)
+    one = torch.ones((), dtype=torch.float32, device=dev)  # root gradient, so that autograd does not fill one per step
+
+    def forward_backward(ro, rd, tgt, **kw):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+            if fused_tail:
+                image, depth, loss, scaled, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
+                                                                            target=tgt, loss_mul=inv_world, scale=amp.scale if amp else None, **kw)
+            else:
+                image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024, **kw)
+                scaled = torch.nn.functional.mse_loss(image, tgt)
+                if world > 1:
+                    scaled = scaled * inv_world
+                if amp:
+                    scaled = amp.scale_loss(scaled)
+        if amp:
+            scaled.backward(one)
+        else:
+            scaler.scale(scaled).backward()
+        return counter
+
+    def optimizer_step():
+        if amp:
+            amp.step()
+        else:
+            scaler.step(opt)
+            scaler.update()
     total_samples = torch.zeros((), dtype=torch.int64, device=dev)
     dt_gamma = 1 / 128
     field.train()
@@ -196,21 +228,11 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     def train_step(k, count=True):
         ro, rd = pool[k % n_pool]
         reducer.zero_grad()
-        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
-            if fused_tail:
-                image, depth, loss, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
-                                                                    target=gt[k % n_pool], loss_mul=inv_world)
-            else:
-                image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024)
-                loss = torch.nn.functional.mse_loss(image, gt[k % n_pool])
-                if world > 1:
-                    loss = loss * inv_world
-        scaler.scale(loss).backward()
+        counter = forward_backward(ro, rd, gt[k % n_pool])
         reducer.all_reduce()
-        scaler.step(opt)
-        scaler.update()
+        optimizer_step()
         if count:
-            total_samples.add_(counter[0].to(torch.int64))
+            total_samples.add_(counter[0])
         if renderer.local_step == 16:  # update_extra_state cadence (nerf/utils.py:1011): mean_count read-back
             renderer.update_mean_count()
             renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
@@ -228,23 +250,11 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     def body_fb():
         ro, rd, tgt = pool_o.index_select(0, batch_idx)[0], pool_d.index_select(0, batch_idx)[0], gt.index_select(0, batch_idx)[0]
         reducer.zero_grad()
-        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
-            if fused_tail:
-                image, depth, loss, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
-                                                                    counter=graph_counter, mean_count=gstate["M"], target=tgt,
-                                                                    loss_mul=inv_world)
-            else:
-                image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
-                                                              counter=graph_counter, mean_count=gstate["M"])
-                loss = torch.nn.functional.mse_loss(image, tgt)
-                if world > 1:
-                    loss = loss * inv_world
-        scaler.scale(loss).backward()
-        total_samples.add_(graph_counter[0].to(torch.int64))
+        forward_backward(ro, rd, tgt, counter=graph_counter, mean_count=gstate["M"])
+        total_samples.add_(graph_counter[0])
 
     def body_opt():
-        scaler.step(opt)
-        scaler.update()
+        optimizer_step()
 
     def step_body():
         body_fb()
@@ -462,7 +472,7 @@ def main():
                 "workload": WORKLOADS[args.mlp],
                 "rays_per_batch_per_gpu": args.rays, "global_rays": res["n_global"], "bound": args.bound, "dt_gamma": dt_gamma, "max_steps": 1024,
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
-                "optimizer": ("Adam(eps=1e-15)+GradScaler; table: one HIP kernel on the fp16 gradient (fp32 master + fp16 copy), MLPs: torch fused Adam"
+                "optimizer": ("Adam(eps=1e-15) + GradScaler rules, as HIP kernels on the fp16 gradients (fp32 masters + fp16 copies; bit-identical to torch fused Adam)"
                               if res.get("fused_opt") else "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)"),
                 "launch": res["graph"] if res["graph"] else "eager launches",
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",

@@ -259,10 +259,13 @@ int nerftex_field_out_backward(const float* grad_rgbs, const float* rgbs, uint32
 int nerftex_render_tail_forward(const float* weights_sum, const float* depth, const float* image, const float* nears,
                                 const float* fars, const float* target, float bg, float loss_mul, uint32_t N,
                                 float* image_out, float* depth_out, float* partial, uint32_t* ticket, float* loss,
-                                void* stream);
-/* grad_image [N,3] = (2 / 3N) * (image_out - target) * (*grad_loss * loss_mul);  grad_weights_sum [N] = -sum_c(grad_image) * bg */
-int nerftex_render_tail_backward(const float* grad_loss, float loss_mul, const float* image_out, const float* target,
-                                 float bg, uint32_t N, float* grad_image, float* grad_weights_sum, void* stream);
+                                const float* scale, float* scaled_loss, void* stream);
+/* scale (device float of a loss scaler, or NULL) / scaled_loss (or NULL): *scaled_loss = *loss * *scale, what
+ * GradScaler.scale(loss) would compute; the backward below then takes the same scale.
+ * grad_image [N,3] = (2 / 3N) * (image_out - target) * (*grad_loss * *scale * loss_mul);  grad_weights_sum [N] = -sum_c(grad_image) * bg */
+int nerftex_render_tail_backward(const float* grad_loss, const float* scale, float loss_mul, const float* image_out,
+                                 const float* target, float bg, uint32_t N, float* grad_image, float* grad_weights_sum,
+                                 void* stream);
 
 /* One Adam step (main_nerf.py:128: betas (0.9, 0.99), eps 1e-15, no weight decay) of an fp32 master table from the
  * fp16 gradient the encoder backward produced, writing the fp16 copy the next forward reads: param, exp_avg,
@@ -272,6 +275,19 @@ int nerftex_render_tail_backward(const float* grad_loss, float loss_mul, const f
 int nerftex_table_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const void* grad_half, void* param_half,
                             uint64_t n, const float* step, double lr, double beta1, double beta2, double eps,
                             const float* grad_scale, const float* found_inf, void* stream);
+/* The same for up to 8 tensors in one launch (host arrays of device pointers / lengths); the step number used is
+ * *step + step_offset.                                                                                            */
+int nerftex_adam_half_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                           const void* const* grads_half, void* const* params_half, const uint64_t* n, const float* step,
+                           float step_offset, double lr, double beta1, double beta2, double eps, const float* grad_scale,
+                           const float* found_inf, void* stream);
+/* Device side of torch.amp.GradScaler for fp16 gradients.  check: *found_inf = 1 if any element of up to 8 fp16 tensors
+ * is inf / nan (never cleared here).  update (amp_update_scale_): found_inf != 0 -> scale *= backoff_factor, tracker = 0;
+ * else tracker += 1, at growth_interval scale *= growth_factor (if finite) and tracker = 0, and *step += 1 (step may be
+ * NULL); found_inf is cleared for the next step.                                                                   */
+int nerftex_amp_check_half(int count, const void* const* grads_half, const uint64_t* n, float* found_inf, void* stream);
+int nerftex_amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, double growth_factor,
+                       double backoff_factor, int growth_interval, void* stream);
 
 #ifdef __cplusplus
 }

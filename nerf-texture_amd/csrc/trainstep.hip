@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kTailThreads) void render_tail_forward_kernel(const
                                                                            const float bg, const float loss_mul, const uint32_t N,
                                                                            float* __restrict__ image_out, float* __restrict__ depth_out,
                                                                            float* __restrict__ partial, uint32_t* __restrict__ ticket,
-                                                                           float* __restrict__ loss) {
+                                                                           float* __restrict__ loss, const float* __restrict__ scale,
+                                                                           float* __restrict__ scaled_loss) {
 #pragma clang fp contract(off)  // the framework's blend is a multiply, then an add
     __shared__ float lds[kTailThreads / 64];
     __shared__ bool last;
@@ -71,20 +72,22 @@ __global__ __launch_bounds__(kTailThreads) void render_tail_forward_kernel(const
     __syncthreads();
     const float total = block_sum(acc, lds);
     if (threadIdx.x == 0) {
-        *loss = total / (float)((size_t)N * 3) * loss_mul;
+        const float l = total / (float)((size_t)N * 3) * loss_mul;
+        *loss = l;
+        if (scaled_loss) *scaled_loss = scale ? l * *scale : l;  // GradScaler.scale(loss)
         *ticket = 0;
     }
 }
 
 // grad_image = (2 / 3N) * (image_out - target) * grad_loss   (mse_loss backward: norm * (a - b) * g),  grad_ws = -(sum_c grad_image) * bg
-__global__ __launch_bounds__(kTailThreads) void render_tail_backward_kernel(const float* __restrict__ grad_loss, const float loss_mul,
+__global__ __launch_bounds__(kTailThreads) void render_tail_backward_kernel(const float* __restrict__ grad_loss, const float* __restrict__ scale, const float loss_mul,
                                                                             const float* __restrict__ image_out, const float* __restrict__ target,
                                                                             const float bg, const uint32_t N, float* __restrict__ grad_image,
                                                                             float* __restrict__ grad_ws) {
 #pragma clang fp contract(off)
     const uint32_t n = blockIdx.x * kTailThreads + threadIdx.x;
     if (n >= N) return;
-    const float g = *grad_loss * loss_mul;
+    const float g = (scale ? *grad_loss * *scale : *grad_loss) * loss_mul;  // backward of (mse * loss_mul) * scale
     const float norm = (float)(2.0 / (double)((size_t)N * 3));
     float sum = 0.0f;
 #pragma unroll
@@ -118,12 +121,36 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float gra
     p -= step_size * m / denom;
 }
 
-__global__ __launch_bounds__(kAdamThreads) void table_adam_kernel(float* __restrict__ param, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                                                  const half_t* __restrict__ grad, half_t* __restrict__ param_half, const uint64_t n,
-                                                                  const float* __restrict__ step, const AdamConsts k,
-                                                                  const float* __restrict__ grad_scale, const float* __restrict__ found_inf) {
+constexpr int kMaxTensors = 8;
+
+struct AdamTensors {
+    float* param[kMaxTensors];
+    float* exp_avg[kMaxTensors];
+    float* exp_avg_sq[kMaxTensors];
+    const half_t* grad[kMaxTensors];
+    half_t* param_half[kMaxTensors];
+    uint64_t n[kMaxTensors];
+    uint32_t block_end[kMaxTensors];  // blocks [block_end[t-1], block_end[t]) work on tensor t
+    int count;
+};
+
+// up to 8 tensors per launch (the table and the MLP weight vectors): a block finds its tensor, then grid-strides inside it
+__global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTensors tens, const float* __restrict__ step, const float step_offset,
+                                                                 const AdamConsts k, const float* __restrict__ grad_scale,
+                                                                 const float* __restrict__ found_inf) {
     if (found_inf && *found_inf == 1.0f) return;  // GradScaler: skip the step, every buffer stays as it is
-    const double steps = (double)*step;
+    int t = 0;
+    while (t + 1 < tens.count && blockIdx.x >= tens.block_end[t]) t++;
+    const uint32_t first = t ? tens.block_end[t - 1] : 0u;
+    const uint32_t nblocks = tens.block_end[t] - first, block = blockIdx.x - first;
+    float* __restrict__ param = tens.param[t];
+    float* __restrict__ exp_avg = tens.exp_avg[t];
+    float* __restrict__ exp_avg_sq = tens.exp_avg_sq[t];
+    const half_t* __restrict__ grad = tens.grad[t];
+    half_t* __restrict__ param_half = tens.param_half[t];
+    const uint64_t n = tens.n[t];
+
+    const double steps = (double)(*step + step_offset);
     const float bc1 = (float)(1 - pow(k.beta1, steps));
     const float bc2_sqrt = (float)sqrt(1 - pow(k.beta2, steps));
     const float step_size = (float)(k.lr / (double)bc1);
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(kAdamThreads) void table_adam_kernel(float* __restr
     const double scale = unscale ? (double)*grad_scale : 1.0;
 
     const uint64_t groups = n / kAdamVec;
-    for (uint64_t i = (uint64_t)blockIdx.x * kAdamThreads + threadIdx.x; i < groups; i += (uint64_t)gridDim.x * kAdamThreads) {
+    for (uint64_t i = (uint64_t)block * kAdamThreads + threadIdx.x; i < groups; i += (uint64_t)nblocks * kAdamThreads) {
         float4 p[2], m[2], v[2];
         p[0] = reinterpret_cast<const float4*>(param)[2 * i];
         p[1] = reinterpret_cast<const float4*>(param)[2 * i + 1];
@@ -157,9 +184,9 @@ __global__ __launch_bounds__(kAdamThreads) void table_adam_kernel(float* __restr
         reinterpret_cast<float4*>(exp_avg_sq)[2 * i + 1] = v[1];
         reinterpret_cast<half8_t*>(param_half)[i] = h;
     }
-    // ragged end (n not a multiple of 8): the first block's first lanes
+    // ragged end (n not a multiple of 8): the tensor's first block, first lanes
     const uint64_t tail = groups * kAdamVec + threadIdx.x;
-    if (blockIdx.x == 0 && tail < n) {
+    if (block == 0 && tail < n) {
         float p = param[tail], m = exp_avg[tail], v = exp_avg_sq[tail];
         adam_one(p, m, v, (float)grad[tail], k, unscale, scale, step_size, bc2_sqrt);
         param[tail] = p;
@@ -169,6 +196,56 @@ __global__ __launch_bounds__(kAdamThreads) void table_adam_kernel(float* __restr
     }
 }
 
+// ---- loss scaling (torch.amp.GradScaler's device side: _amp_foreach_non_finite_check_and_unscale_ with inv_scale 1, amp_update_scale_) ----
+struct CheckTensors {
+    const half_t* grad[kMaxTensors];
+    uint64_t n[kMaxTensors];
+    uint32_t block_end[kMaxTensors];
+    int count;
+};
+
+// *found_inf = 1 if any fp16 gradient is inf / nan (exponent field all ones); never cleared here
+__global__ __launch_bounds__(256) void amp_check_half_kernel(const CheckTensors tens, float* __restrict__ found_inf) {
+    int t = 0;
+    while (t + 1 < tens.count && blockIdx.x >= tens.block_end[t]) t++;
+    const uint32_t first = t ? tens.block_end[t - 1] : 0u;
+    const uint32_t nblocks = tens.block_end[t] - first, block = blockIdx.x - first;
+    const uint64_t n = tens.n[t];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tens.grad[t]);
+    const uint64_t quads = n / 8;  // 16 bytes = 8 halves
+    bool bad = false;
+    for (uint64_t i = (uint64_t)block * 256 + threadIdx.x; i < quads; i += (uint64_t)nblocks * 256) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w) + i);
+        const uint32_t x[4] = {q[0], q[1], q[2], q[3]};
+#pragma unroll
+        for (int j = 0; j < 4; j++) bad |= ((x[j] & 0x7c00u) == 0x7c00u) | ((x[j] & 0x7c000000u) == 0x7c000000u);
+    }
+    const uint64_t tail = quads * 8 + threadIdx.x;
+    if (block == 0 && tail < n) bad |= (reinterpret_cast<const uint16_t*>(w)[tail] & 0x7c00u) == 0x7c00u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
+}
+
+// amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count
+__global__ void amp_update_kernel(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
+                                  const double backoff_factor, const int growth_interval) {
+    if (*found_inf != 0.0f) {
+        *scale = (float)((double)*scale * backoff_factor);
+        *growth_tracker = 0;
+    } else {
+        const int successful = *growth_tracker + 1;
+        if (successful == growth_interval) {
+            const float grown = (float)((double)*scale * growth_factor);
+            if (isfinite(grown)) *scale = grown;
+            *growth_tracker = 0;
+        } else {
+            *growth_tracker = successful;
+        }
+        if (step) *step += 1.0f;
+    }
+    *found_inf = 0.0f;
+}
+
 }  // namespace
 }  // namespace nerftex
 
@@ -176,7 +253,8 @@ using namespace nerftex;
 
 extern "C" int nerftex_render_tail_forward(const float* weights_sum, const float* depth, const float* image, const float* nears,
                                            const float* fars, const float* target, float bg, float loss_mul, uint32_t N, float* image_out,
-                                           float* depth_out, float* partial, uint32_t* ticket, float* loss, void* stream) {
+                                           float* depth_out, float* partial, uint32_t* ticket, float* loss, const float* scale,
+                                           float* scaled_loss, void* stream) {
     clear_error();
     if (N == 0) {
         set_error("render_tail: empty batch");
@@ -186,42 +264,113 @@ extern "C" int nerftex_render_tail_forward(const float* weights_sum, const float
     {
         KernelTimer kt("render_tail_forward_kernel", st);
         hipLaunchKernelGGL(render_tail_forward_kernel, dim3(div_up(N, kTailThreads)), dim3(kTailThreads), 0, st, weights_sum, depth, image, nears,
-                           fars, target, bg, loss_mul, N, image_out, depth_out, partial, ticket, loss);
+                           fars, target, bg, loss_mul, N, image_out, depth_out, partial, ticket, loss, scale, scaled_loss);
     }
     return check_launch("render_tail_forward");
 }
 
-extern "C" int nerftex_render_tail_backward(const float* grad_loss, float loss_mul, const float* image_out, const float* target, float bg,
+extern "C" int nerftex_render_tail_backward(const float* grad_loss, const float* scale, float loss_mul, const float* image_out, const float* target, float bg,
                                             uint32_t N, float* grad_image, float* grad_weights_sum, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
     hipStream_t st = as_stream(stream);
     {
         KernelTimer kt("render_tail_backward_kernel", st);
-        hipLaunchKernelGGL(render_tail_backward_kernel, dim3(div_up(N, kTailThreads)), dim3(kTailThreads), 0, st, grad_loss, loss_mul, image_out,
+        hipLaunchKernelGGL(render_tail_backward_kernel, dim3(div_up(N, kTailThreads)), dim3(kTailThreads), 0, st, grad_loss, scale, loss_mul, image_out,
                            target, bg, N, grad_image, grad_weights_sum);
     }
     return check_launch("render_tail_backward");
 }
 
+namespace {
+uint32_t blocks_for(uint64_t units, uint32_t per_block) {
+    const uint64_t want = std::max<uint64_t>(div_up(units, (uint64_t)per_block), 1);
+    return (uint32_t)std::min<uint64_t>(want, (uint64_t)device_cus() * 8);
+}
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+}  // namespace
+
+extern "C" int nerftex_adam_half_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                      const void* const* grads_half, void* const* params_half, const uint64_t* n, const float* step,
+                                      float step_offset, double lr, double beta1, double beta2, double eps, const float* grad_scale,
+                                      const float* found_inf, void* stream) {
+    clear_error();
+    if (count < 0 || count > kMaxTensors) {
+        set_error("adam_half_step: at most 8 tensors per call");
+        return NERFTEX_ERR_INVALID;
+    }
+    AdamTensors tens{};
+    uint32_t blocks = 0;
+    for (int t = 0; t < count; t++) {
+        if (n[t] == 0) continue;
+        if (misaligned(params[t]) || misaligned(exp_avgs[t]) || misaligned(exp_avg_sqs[t]) || misaligned(grads_half[t]) || misaligned(params_half[t])) {
+            set_error("adam_half_step: buffers must be 16-byte aligned");
+            return NERFTEX_ERR_INVALID;
+        }
+        const int k = tens.count++;
+        tens.param[k] = params[t];
+        tens.exp_avg[k] = exp_avgs[t];
+        tens.exp_avg_sq[k] = exp_avg_sqs[t];
+        tens.grad[k] = static_cast<const half_t*>(grads_half[t]);
+        tens.param_half[k] = static_cast<half_t*>(params_half[t]);
+        tens.n[k] = n[t];
+        blocks += blocks_for(n[t] / kAdamVec, kAdamThreads);
+        tens.block_end[k] = blocks;
+    }
+    if (tens.count == 0) return NERFTEX_OK;
+    hipStream_t st = as_stream(stream);
+    const AdamConsts k{lr, beta1, beta2, eps};
+    {
+        KernelTimer kt("adam_half_kernel", st);
+        hipLaunchKernelGGL(adam_half_kernel, dim3(blocks), dim3(kAdamThreads), 0, st, tens, step, step_offset, k, grad_scale, found_inf);
+    }
+    return check_launch("adam_half_step");
+}
+
 extern "C" int nerftex_table_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const void* grad_half, void* param_half, uint64_t n,
                                        const float* step, double lr, double beta1, double beta2, double eps, const float* grad_scale,
                                        const float* found_inf, void* stream) {
+    return nerftex_adam_half_step(1, &param, &exp_avg, &exp_avg_sq, &grad_half, &param_half, &n, step, 0.0f, lr, beta1, beta2, eps, grad_scale,
+                                  found_inf, stream);
+}
+
+extern "C" int nerftex_amp_check_half(int count, const void* const* grads_half, const uint64_t* n, float* found_inf, void* stream) {
     clear_error();
-    if (n == 0) return NERFTEX_OK;
-    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
-         reinterpret_cast<uintptr_t>(grad_half) | reinterpret_cast<uintptr_t>(param_half)) & 15) {
-        set_error("table_adam_step: buffers must be 16-byte aligned");
+    if (count < 0 || count > kMaxTensors) {
+        set_error("amp_check_half: at most 8 tensors per call");
         return NERFTEX_ERR_INVALID;
     }
-    hipStream_t st = as_stream(stream);
-    const uint64_t groups = n / kAdamVec;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(div_up(groups, (uint64_t)kAdamThreads), 1), (uint64_t)device_cus() * 8);
-    const AdamConsts k{lr, beta1, beta2, eps};
-    {
-        KernelTimer kt("table_adam_kernel", st);
-        hipLaunchKernelGGL(table_adam_kernel, dim3(blocks), dim3(kAdamThreads), 0, st, param, exp_avg, exp_avg_sq, static_cast<const half_t*>(grad_half),
-                           static_cast<half_t*>(param_half), n, step, k, grad_scale, found_inf);
+    CheckTensors tens{};
+    uint32_t blocks = 0;
+    for (int t = 0; t < count; t++) {
+        if (n[t] == 0) continue;
+        if (misaligned(grads_half[t])) {
+            set_error("amp_check_half: buffers must be 16-byte aligned");
+            return NERFTEX_ERR_INVALID;
+        }
+        const int k = tens.count++;
+        tens.grad[k] = static_cast<const half_t*>(grads_half[t]);
+        tens.n[k] = n[t];
+        blocks += blocks_for(n[t] / 8, 256 * 4);
+        tens.block_end[k] = blocks;
     }
-    return check_launch("table_adam_step");
+    if (tens.count == 0) return NERFTEX_OK;
+    hipStream_t st = as_stream(stream);
+    {
+        KernelTimer kt("amp_check_half_kernel", st);
+        hipLaunchKernelGGL(amp_check_half_kernel, dim3(blocks), dim3(256), 0, st, tens, found_inf);
+    }
+    return check_launch("amp_check_half");
+}
+
+extern "C" int nerftex_amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, double growth_factor,
+                                  double backoff_factor, int growth_interval, void* stream) {
+    clear_error();
+    hipStream_t st = as_stream(stream);
+    {
+        KernelTimer kt("amp_update_kernel", st);
+        hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, st, scale, growth_tracker, found_inf, step, growth_factor, backoff_factor,
+                           growth_interval);
+    }
+    return check_launch("amp_update");
 }

@@ -71,7 +71,7 @@ class _ffmlp_forward(Function):
         inputs, weights, outputs = saved[:3]
         forward_buffer = saved[3] if len(saved) > 3 else None  # None: the library rebuilds the activations from the inputs
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
-        grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
+        grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.empty(1, device=grad.device, dtype=grad.dtype)  # placeholder
         # the reference zero-fills both (ffmlp.py:72-73) because its kernels accumulate / skip rows; the HIP kernels
         # overwrite every element of both, so the fills (2 x num_layers x B x hidden x 2 B per call) are dropped
         grad_weights = torch.empty_like(weights)
@@ -127,12 +127,18 @@ class FFMLP(nn.Module):
         bound = math.sqrt(3 / self.hidden_dim)
         self.weights.data.uniform_(-bound, bound)
 
+    def _weights(self):
+        """The weight vector handed to the kernels: the fp32 parameter (narrowed by custom_fwd), or -- under autocast -- the fp16 leaf an
+        optimizer that keeps fp16 copies itself has installed (ngp_harness/optim.py): no cast, fp16 gradient."""
+        leaf = getattr(self, "half_leaf", None)
+        return leaf if leaf is not None and torch.is_autocast_enabled() else self.weights
+
     def forward(self, inputs, force_grad=False):
         B, C = inputs.shape
         pad = 128 - (B % 128)  # always >= 1 block of padding, like the reference
         if pad > 0:
             inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
-        outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+        outputs = ffmlp_forward(inputs, self._weights(), self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
                                 self.activation, self.output_activation, (not self.training) and (not force_grad), inputs.requires_grad)
         if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
             outputs = outputs[:B, : self.output_dim]

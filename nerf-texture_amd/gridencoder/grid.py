@@ -81,7 +81,7 @@ class _grid_encode(Function):
         if ctx.calc_grad_inputs:
             grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
         else:
-            grad_inputs = torch.zeros(1, device=inputs.device, dtype=embeddings.dtype)
+            grad_inputs = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)  # placeholder pointer, never written
 
         tok = timer.start("grid_encode_backward")
         check(lib.nerftex_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L,

@@ -83,7 +83,8 @@ class FlatGradAllReduce:
             off += n
 
     def zero_grad(self):
-        self.flat.zero_()
+        if self.small:
+            self.flat.zero_()
         for p in self.big:
             p.grad = None
 
@@ -108,9 +109,10 @@ class FlatGradAllReduce:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                 if self.average:
                     p.grad.div_(w)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        if self.average:
-            self.flat.div_(w)
+        if self.small:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.average:
+                self.flat.div_(w)
         if extra is not None:
             dist.all_reduce(extra, op=dist.ReduceOp.SUM)
         return extra

@@ -22,6 +22,7 @@ class _sigma_geo_dir(Function):
         cin = torch.empty(B, 32, dtype=torch.float16, device=h.device)
         check(lib.nerftex_field_mid_forward(ptr(h), ptr(dirs), B, ptr(sigma), ptr(cin), stream()))
         ctx.save_for_backward(h)
+        ctx.set_materialize_grads(False)
         return sigma, cin
 
     @staticmethod
@@ -62,38 +63,44 @@ color_out = _color_out.apply
 
 class _render_tail(Function):
     """image + (1 - weights_sum) * bg, depth normalisation and mean squared error against `target` in one launch
-    (nerf/renderer.py:417-425 + the MSE of nerf/utils.py:602-640); returns (image_out, depth_out, loss * loss_mul).
-    Only `loss` carries a gradient (to `image` and `weights_sum`); image_out / depth_out are outputs for display."""
+    (nerf/renderer.py:417-425 + the MSE of nerf/utils.py:602-640); returns (image_out, depth_out, loss * loss_mul, scaled loss).
+    scale: device scalar of a loss scaler or None; the last output is loss * scale (GradScaler.scale(loss)) and is the one to call
+    backward on -- it carries the gradient to `image` and `weights_sum`; the first three are plain outputs."""
 
     @staticmethod
-    def forward(ctx, weights_sum, depth, image, nears, fars, target, bg, loss_mul):
+    def forward(ctx, weights_sum, depth, image, nears, fars, target, bg, loss_mul, scale):
         args = [t.contiguous().float() for t in (weights_sum, depth, image, nears, fars, target)]
         weights_sum, depth, image, nears, fars, target = args
         N, dev = weights_sum.shape[0], weights_sum.device
         assert image.shape == (N, 3) and target.shape == (N, 3) and depth.shape == (N,)
+        assert scale is None or (scale.dtype == torch.float32 and scale.numel() == 1 and scale.device == dev)
         image_out = torch.empty_like(image)
         depth_out = torch.empty_like(depth)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
         scratch = _tail_scratch(dev, (N + 255) // 256)
         check(lib.nerftex_render_tail_forward(ptr(weights_sum), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(target), float(bg),
-                                              float(loss_mul), N, ptr(image_out), ptr(depth_out), ptr(scratch[1]), ptr(scratch[0]), ptr(loss),
-                                              stream()))
-        ctx.save_for_backward(image_out, target)
+                                              float(loss_mul), N, ptr(image_out), ptr(depth_out), ptr(scratch[1]), ptr(scratch[0]), ptr(losses),
+                                              ptr(scale), losses.data_ptr() + 4, stream()))
+        ctx.save_for_backward(image_out, target, scale)
         ctx.consts = (float(bg), float(loss_mul))
-        ctx.mark_non_differentiable(image_out, depth_out)
-        return image_out, depth_out, loss
+        loss, scaled = losses[0], losses[1]
+        ctx.mark_non_differentiable(image_out, depth_out, loss)
+        ctx.set_materialize_grads(False)
+        return image_out, depth_out, loss, scaled
 
     @staticmethod
-    def backward(ctx, _gi, _gd, grad_loss):
-        image_out, target = ctx.saved_tensors
+    def backward(ctx, _gi, _gd, _gl, grad_scaled):
+        image_out, target, scale = ctx.saved_tensors
+        if grad_scaled is None:
+            return (None,) * 9
         bg, loss_mul = ctx.consts
         N = image_out.shape[0]
-        grad_loss = grad_loss.contiguous().float()
+        grad_scaled = grad_scaled.contiguous().float()
         grad_image = torch.empty_like(image_out)
         grad_ws = torch.empty(N, dtype=torch.float32, device=image_out.device)
-        check(lib.nerftex_render_tail_backward(ptr(grad_loss), loss_mul, ptr(image_out), ptr(target), bg, N, ptr(grad_image), ptr(grad_ws),
-                                               stream()))
-        return grad_ws, None, grad_image, None, None, None, None, None
+        check(lib.nerftex_render_tail_backward(ptr(grad_scaled), ptr(scale), loss_mul, ptr(image_out), ptr(target), bg, N, ptr(grad_image),
+                                               ptr(grad_ws), stream()))
+        return grad_ws, None, grad_image, None, None, None, None, None, None
 
 
 _SCRATCH = {}
@@ -108,5 +115,6 @@ def _tail_scratch(dev, blocks):
     return s
 
 
-def render_tail(weights_sum, depth, image, nears, fars, target, bg=1.0, loss_mul=1.0):
-    return _render_tail.apply(weights_sum, depth, image, nears, fars, target, bg, loss_mul)
+def render_tail(weights_sum, depth, image, nears, fars, target, bg=1.0, loss_mul=1.0, scale=None):
+    """-> (image_out, depth_out, loss, scaled_loss); call backward on scaled_loss (== loss when scale is None)."""
+    return _render_tail.apply(weights_sum, depth, image, nears, fars, target, bg, loss_mul, scale)

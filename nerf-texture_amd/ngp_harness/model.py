@@ -83,10 +83,10 @@ class NGPField(nn.Module):
         feats = self.encoder(x, bound=self.bound)
         infer = not self.training
         s, c = self.sigma_net, self.color_net
-        h = ffmlp_forward(feats, s.weights, s.input_dim, s.padded_output_dim, s.hidden_dim, s.num_layers, s.activation, s.output_activation,
+        h = ffmlp_forward(feats, s._weights(), s.input_dim, s.padded_output_dim, s.hidden_dim, s.num_layers, s.activation, s.output_activation,
                           infer, True)
         sigma, cin = fused.sigma_geo_dir(h, d)
-        hc = ffmlp_forward(cin, c.weights, c.input_dim, c.padded_output_dim, c.hidden_dim, c.num_layers, c.activation, c.output_activation,
+        hc = ffmlp_forward(cin, c._weights(), c.input_dim, c.padded_output_dim, c.hidden_dim, c.num_layers, c.activation, c.output_activation,
                            infer, True)
         return sigma, fused.color_out(hc), {}
 
@@ -155,14 +155,14 @@ class Renderer(nn.Module):
         self.local_step = 0
 
     def render_train(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=True, force_all_rays=False, max_steps=1024, counter=None,
-                     mean_count=None, target=None, loss_mul=1.0):
+                     mean_count=None, target=None, loss_mul=1.0, scale=None):
         """Training branch of run_cuda (:361-425). Returns image [N,3], depth [N], and the sample count tensor.
 
         counter / mean_count: for graph replay the caller supplies a fixed counter tensor and a fixed buffer size and does the
         step-counter ring bookkeeping itself (`commit_counter`); by default both come from the ring like in the reference."""
         marched, counter = self.march_train(rays_o, rays_d, dt_gamma, perturb, force_all_rays, max_steps, counter, mean_count)
-        if target is not None:  # fused tail: (image, depth, loss, counter)
-            return (*self.shade_train(marched, bg_color, target, loss_mul), counter)
+        if target is not None:  # fused tail: (image, depth, loss, scaled loss, counter)
+            return (*self.shade_train(marched, bg_color, target, loss_mul, scale), counter)
         image, depth = self.shade_train(marched, bg_color)
         return image, depth, counter
 
@@ -180,11 +180,12 @@ class Renderer(nn.Module):
                                                                 128, force_all_rays, dt_gamma, max_steps)
         return (nears, fars, xyzs, dirs, deltas, rays), counter
 
-    def shade_train(self, marched, bg_color=1, target=None, loss_mul=1.0):
+    def shade_train(self, marched, bg_color=1, target=None, loss_mul=1.0, scale=None):
         """Second half (:389-425): field evaluation, compositing, background.
 
         target [N,3] (with a scalar bg_color): the blend, the depth normalisation and the MSE against the target pixels run as one
-        kernel (ngp_harness/fused.py render_tail); returns (image, depth, loss * loss_mul) instead of (image, depth)."""
+        kernel (ngp_harness/fused.py render_tail); returns (image, depth, loss * loss_mul, that times the loss scaler's `scale`)
+        instead of (image, depth); backward goes through the last one."""
         nears, fars, xyzs, dirs, deltas, rays = marched
         sigmas, rgbs, _ = self.field(xyzs, dirs)
         if self.density_scale != 1:  # x * 1.0 is x: not launched
@@ -193,7 +194,7 @@ class Renderer(nn.Module):
         if target is not None:
             from . import fused
 
-            return fused.render_tail(weights_sum, depth, image, nears, fars, target, float(bg_color), loss_mul)
+            return fused.render_tail(weights_sum, depth, image, nears, fars, target, float(bg_color), loss_mul, scale)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth

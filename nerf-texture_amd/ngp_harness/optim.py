@@ -1,62 +1,112 @@
-"""Optimizer of the ngp field for fp16 (autocast) training: `TableAdam`.
+"""Optimizer + loss scaling of the ngp field for fp16 (autocast) training: `HalfLeafAdam`, `FusedAmp`.
 
 main_nerf.py:128 trains everything with `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` under a GradScaler
 (nerf/utils.py:360, :1003-1009).  For the hash table that costs, per step, a widening copy of the fp16 gradient the encoder backward
 produced, a non-finite scan, the fused Adam kernel and a narrowing copy of the fp32 table for the next forward: ~650 MB of traffic
-for a 12.6 M-parameter table.  `TableAdam` keeps the same update (arithmetic restated from torch's fused kernel, see
-csrc/trainstep.hip) but makes the fp16 table the autograd leaf: the encoder reads it, the backward's fp16 gradient lands in its
-`.grad` as is, and one kernel updates the fp32 master + moments and rewrites the fp16 leaf (353 MB).  The MLP weights (18 K
-parameters) go through `torch._fused_adam_` unchanged.  GradScaler sees an optimizer that unscales and skips by itself
-(`_step_supports_amp_scaling`), exactly like `Adam(fused=True)`; its non-finite scan runs over the fp16 gradient (25 MB).
+for a 12.6 M-parameter table, plus ~20 small launches of scaler bookkeeping.
+
+`HalfLeafAdam` keeps the same update (arithmetic restated from torch's fused kernel, bit-identical: csrc/trainstep.hip,
+tests/test_gpu_trainstep.py) but makes the fp16 copy of every parameter the autograd leaf: the kernels read it, the backward's fp16
+gradient lands in its `.grad` as is, and one launch updates the fp32 masters + moments and rewrites the fp16 leaves (28 B per
+parameter).  It is a `torch.optim.Optimizer` a GradScaler can drive (`_step_supports_amp_scaling`, like `Adam(fused=True)`).
+
+`FusedAmp` is GradScaler's device side (non-finite check, skip, scale back-off / growth: same constants, same formulas) as three
+launches per step: check, Adam, update.
 """
+import ctypes
+
 import torch
 
 from nerftex_hip import check, lib, ptr, stream
 
 
-class TableAdam(torch.optim.Optimizer):
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class HalfLeafAdam(torch.optim.Optimizer):
     _step_supports_amp_scaling = True
 
-    def __init__(self, encoder, small_params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
-        master = encoder.embeddings
-        assert master.is_cuda and master.dtype == torch.float32 and master.is_contiguous() and encoder.level_dim % 2 == 0
-        leaf = master.detach().to(torch.half).requires_grad_(True)
-        encoder.half_leaf = leaf  # GridEncoder._table hands this to grid_encode under autocast
-        small = [p for p in small_params if p.requires_grad]
-        super().__init__([{"params": [leaf]}, {"params": small}], dict(lr=lr, betas=betas, eps=eps))
-        self.master = master
-        self.leaf = leaf
-        self.exp_avg = torch.zeros_like(master.data)
-        self.exp_avg_sq = torch.zeros_like(master.data)
-        self.small_avg = [torch.zeros_like(p.data) for p in small]
-        self.small_avg_sq = [torch.zeros_like(p.data) for p in small]
-        self.step_count = torch.zeros((), dtype=torch.float32, device=master.device)  # device-side: graph replay advances it
+    def __init__(self, owners, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
+        """owners: [(module, attribute name)] of fp32 parameters, e.g. (encoder, "embeddings"), (sigma_net, "weights"); each module gets
+        a `half_leaf` attribute that GridEncoder._table / FFMLP._weights hand to the kernels under autocast."""
+        assert 1 <= len(owners) <= 8
+        self.masters, self.leaves = [], []
+        for mod, name in owners:
+            master = getattr(mod, name)
+            assert master.is_cuda and master.dtype == torch.float32 and master.is_contiguous()
+            leaf = master.detach().to(torch.half).requires_grad_(True)
+            mod.half_leaf = leaf
+            self.masters.append(master)
+            self.leaves.append(leaf)
+        super().__init__([{"params": list(self.leaves)}], dict(lr=lr, betas=betas, eps=eps))
+        self.exp_avg = [torch.zeros_like(m.data) for m in self.masters]
+        self.exp_avg_sq = [torch.zeros_like(m.data) for m in self.masters]
+        self.step_count = torch.zeros((), dtype=torch.float32, device=self.masters[0].device)  # completed steps; device-side for graph replay
 
     def trainable(self):
         """The tensors whose `.grad` the backward pass fills (what a gradient all-reduce has to cover)."""
-        return [self.leaf] + list(self.param_groups[1]["params"])
+        return list(self.leaves)
+
+    def _launch(self, step_offset, grad_scale, found_inf):
+        idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None]
+        if not idx:
+            return
+        grads = [self.leaves[i].grad for i in idx]
+        for i, g in zip(idx, grads):
+            assert g.dtype == torch.half and g.is_contiguous() and g.shape == self.masters[i].shape
+        grp = self.param_groups[0]
+        n = (ctypes.c_uint64 * len(idx))(*[self.masters[i].numel() for i in idx])
+        check(lib.nerftex_adam_half_step(len(idx), _ptr_array([self.masters[i] for i in idx]), _ptr_array([self.exp_avg[i] for i in idx]),
+                                         _ptr_array([self.exp_avg_sq[i] for i in idx]), _ptr_array(grads),
+                                         _ptr_array([self.leaves[i] for i in idx]), n, ptr(self.step_count), float(step_offset),
+                                         float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], ptr(grad_scale), ptr(found_inf),
+                                         stream()))
+        for i in idx:
+            torch.autograd.graph.increment_version(self.masters[i])
 
     @torch.no_grad()
     def step(self, closure=None):
+        """torch.optim protocol (plain, or driven by torch.amp.GradScaler through grad_scale / found_inf)."""
         assert closure is None
         grad_scale = getattr(self, "grad_scale", None)
         found_inf = getattr(self, "found_inf", None)
         self.step_count += 1
-        g = self.leaf.grad
-        if g is not None:
-            grp = self.param_groups[0]
-            assert g.dtype == torch.half and g.is_contiguous() and g.shape == self.master.shape
-            check(lib.nerftex_table_adam_step(ptr(self.master), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(g), ptr(self.leaf),
-                                              self.master.numel(), ptr(self.step_count), float(grp["lr"]), grp["betas"][0], grp["betas"][1],
-                                              grp["eps"], ptr(grad_scale), ptr(found_inf), stream()))
-            torch.autograd.graph.increment_version(self.master)
-        grp = self.param_groups[1]
-        idx = [i for i, p in enumerate(grp["params"]) if p.grad is not None]
-        if idx:
-            torch._fused_adam_([grp["params"][i] for i in idx], [grp["params"][i].grad for i in idx], [self.small_avg[i] for i in idx],
-                               [self.small_avg_sq[i] for i in idx], [], [self.step_count] * len(idx), lr=float(grp["lr"]),
-                               beta1=grp["betas"][0], beta2=grp["betas"][1], weight_decay=0.0, eps=grp["eps"], amsgrad=False,
-                               maximize=False, grad_scale=grad_scale, found_inf=found_inf)
+        self._launch(0.0, grad_scale, found_inf)
         if found_inf is not None:  # a skipped step does not count (torch's _fused_adam does the same)
             self.step_count -= found_inf.reshape(())
         return None
+
+
+TableAdam = HalfLeafAdam
+
+
+class FusedAmp:
+    """Loss scaling with torch.amp.GradScaler's rules (init 65536, x2 after 2000 clean steps, x0.5 on overflow, overflowing steps
+    skipped) around a HalfLeafAdam, all on the device: `scale` multiplies the loss (or is handed to fused.render_tail), `step()` =
+    GradScaler.step(optimizer) + GradScaler.update()."""
+
+    def __init__(self, optimizer, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        assert isinstance(optimizer, HalfLeafAdam)
+        dev = optimizer.masters[0].device
+        self.opt = optimizer
+        self.scale = torch.full((), float(init_scale), dtype=torch.float32, device=dev)
+        self.growth_tracker = torch.zeros((), dtype=torch.int32, device=dev)
+        self.found_inf = torch.zeros((), dtype=torch.float32, device=dev)
+        self.consts = (float(growth_factor), float(backoff_factor), int(growth_interval))
+
+    def scale_loss(self, loss):
+        return loss * self.scale
+
+    def get_scale(self):
+        return float(self.scale.item())
+
+    @torch.no_grad()
+    def step(self):
+        grads = [leaf.grad for leaf in self.opt.leaves if leaf.grad is not None]
+        if grads:
+            n = (ctypes.c_uint64 * len(grads))(*[g.numel() for g in grads])
+            check(lib.nerftex_amp_check_half(len(grads), _ptr_array(grads), n, ptr(self.found_inf), stream()))
+        self.opt._launch(1.0, self.scale, self.found_inf)
+        g, b, i = self.consts
+        check(lib.nerftex_amp_update(ptr(self.scale), ptr(self.growth_tracker), ptr(self.found_inf), ptr(self.opt.step_count), g, b, i, stream()))

@@ -136,9 +136,13 @@ def _march_train(differentiable, rays_o, rays_d, bound, density_bitfield, C, H, 
     N = rays_o.shape[0]
     M = _point_budget(N, max_steps, mean_count, align, force_all_rays)
 
-    xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-    dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-    deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+    if M % 4 == 0:  # the three zero-filled sample buffers (raymarching.py:184-186) carved out of one fill; each stays 16-byte aligned
+        flat = torch.zeros(M * 8, dtype=dt, device=dev)
+        xyzs, dirs, deltas = flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
+    else:
+        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)  # (ray id, point offset, num_steps)
     if step_counter is None:
         step_counter = torch.zeros(2, dtype=torch.int32, device=dev)  # (points, rays)
@@ -225,17 +229,21 @@ class _composite_rays_train(Function):
         timer.stop(tok)
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
         ctx.dims = (M, N)
+        ctx.set_materialize_grads(False)  # depth carries no gradient (below): do not have autograd fill a zero tensor for it
         return weights_sum, depth, image
 
     @staticmethod
     @_bwd
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         # grad_depth is ignored, exactly as in the reference (raymarching.py:330).
-        grad_weights_sum, grad_image = _f32(grad_weights_sum), _f32(grad_image)
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N = ctx.dims
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
+        if grad_weights_sum is None and grad_image is None:
+            return None, None, None, None
+        grad_weights_sum = torch.zeros_like(weights_sum) if grad_weights_sum is None else _f32(grad_weights_sum)
+        grad_image = torch.zeros_like(image) if grad_image is None else _f32(grad_image)
+        flat = torch.zeros(M * 4, dtype=sigmas.dtype, device=sigmas.device)  # both zero-initialised outputs (raymarching.py:333-334), one fill
+        grad_sigmas, grad_rgbs = flat[:M], flat[M:].view(M, 3)
         tok = timer.start("composite_rays_train_backward")
         check(lib.nerftex_composite_rays_train_backward(ptr(grad_weights_sum), ptr(grad_image), ptr(sigmas), ptr(rgbs), ptr(deltas),
                                                         ptr(rays), ptr(weights_sum), ptr(image), M, N, ptr(grad_sigmas),

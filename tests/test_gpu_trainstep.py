@@ -94,55 +94,117 @@ def test_render_tail_matches_framework_ops(dev, N):
     loss_ref.backward(gl)
 
     ws2, im2 = ws.clone().requires_grad_(True), image.clone().requires_grad_(True)
-    img, dep, loss = fused.render_tail(ws2, depth, im2, nears, fars, target, bg, mul)
-    loss.backward(gl)
+    img, dep, loss, scaled = fused.render_tail(ws2, depth, im2, nears, fars, target, bg, mul)
+    assert scaled.item() == loss.item()
+    scaled.backward(gl)
     assert torch.equal(img, img_ref.detach()) and torch.equal(dep, depth_ref)
     assert abs(loss.item() - loss_ref.item()) <= 2e-6 * abs(loss_ref.item())  # a mean: summation order
     assert torch.equal(im2.grad, im1.grad)
     torch.testing.assert_close(ws2.grad, ws1.grad, rtol=1e-5, atol=1e-7)  # 3-term sum with cancellation: order of the adds
     # the ticket is back at zero: a second call gives the same loss
-    _, _, loss2 = fused.render_tail(ws, depth, image, nears, fars, target, bg, mul)
+    _, _, loss2, _ = fused.render_tail(ws, depth, image, nears, fars, target, bg, mul)
     assert loss2.item() == loss.item()
+    # with a loss scaler's device scalar: the scaled loss and the gradient both carry it
+    ws3, im3 = ws.clone().requires_grad_(True), image.clone().requires_grad_(True)
+    scale = torch.full((), 128.0, device=dev)
+    _, _, loss3, scaled3 = fused.render_tail(ws3, depth, im3, nears, fars, target, bg, mul, scale)
+    assert loss3.item() == loss.item() and scaled3.item() == loss.item() * 128.0
+    scaled3.backward(torch.ones((), device=dev))
+    assert torch.equal(im3.grad, im2.grad) and torch.equal(ws3.grad, ws2.grad)
 
 
-def test_table_adam_optimizer_trains_like_torch_adam(dev, monkeypatch):
-    """A small hash grid trained for a few steps under autocast + GradScaler: TableAdam (fp16 leaf, fp16 gradient consumed as produced)
-    against torch.optim.Adam(fused=True) on the fp32 parameter.  With the encoder backward on its order-independent path (the
-    large-batch one, forced here for 4096 points) both see identical gradients and the tables stay identical."""
-    monkeypatch.setenv("NERFTEX_GRID_BWD", "owner")
+@pytest.mark.parametrize("amp", ["gradscaler", "fused"])
+def test_half_leaf_adam_trains_like_torch_adam(dev, monkeypatch, amp):
+    """A small hash grid + FFMLP trained for a few steps under autocast with loss scaling: HalfLeafAdam (fp16 leaves, fp16 gradients
+    consumed as produced; driven by torch's GradScaler or by FusedAmp) against torch.optim.Adam(fused=True) + GradScaler on the fp32
+    parameters.  With the encoder backward on its order-independent path (the large-batch one, forced here for 4096 points) all see
+    identical gradients, so the tables, the weights and the loss scale stay identical -- through an overflowing first step, the
+    skips and the scale growth (growth interval 3 here)."""
+    from ffmlp import FFMLP
     from gridencoder import GridEncoder
-    from ngp_harness.optim import TableAdam
+    from ngp_harness.optim import FusedAmp, HalfLeafAdam
 
-    def run(fused):
+    monkeypatch.setenv("NERFTEX_GRID_BWD", "owner")
+    gs = dict(init_scale=2.0 ** 30, growth_interval=3)
+
+    def run(mode):
         torch.manual_seed(3)
-        enc = GridEncoder(input_dim=3, num_levels=4, level_dim=2, base_resolution=16, log2_hashmap_size=12, desired_resolution=128).to(dev)
-        lin = torch.nn.Linear(8, 3, bias=False).to(dev)
-        if fused:
-            opt = TableAdam(enc, lin.parameters(), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=12, desired_resolution=128).to(dev)
+        net = FFMLP(input_dim=16, output_dim=3, hidden_dim=64, num_layers=2).to(dev)
+        enc.train(), net.train()
+        fused_amp = None
+        if mode == "torch":
+            opt = torch.optim.Adam(list(enc.parameters()) + list(net.parameters()), lr=1e-2, betas=(0.9, 0.99), eps=1e-15, fused=True)
         else:
-            opt = torch.optim.Adam(list(enc.parameters()) + list(lin.parameters()), lr=1e-2, betas=(0.9, 0.99), eps=1e-15, fused=True)
-        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 30)  # the first step overflows: the skip path is exercised too
+            opt = HalfLeafAdam([(enc, "embeddings"), (net, "weights")], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+            if mode == "fused":
+                fused_amp = FusedAmp(opt, **gs)
+        scaler = None if fused_amp else torch.amp.GradScaler("cuda", **gs)
         x = torch.rand(4096, 3, device=dev) * 2 - 1
         y = torch.rand(4096, 3, device=dev)
-        losses = []
-        for _ in range(8):
-            if fused:
+        losses, scales = [], []
+        for _ in range(10):
+            if mode == "torch":
+                opt.zero_grad(set_to_none=True)
+            else:
                 for t in opt.trainable():
                     t.grad = None
-            else:
-                opt.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.float16):
-                loss = torch.nn.functional.mse_loss(lin(enc(x, bound=1)).float(), y)
-            scaler.scale(loss).backward()
-            scaler.step(opt)
-            scaler.update()
+                loss = torch.nn.functional.mse_loss(net(enc(x, bound=1)).float(), y)
+            if fused_amp:
+                fused_amp.scale_loss(loss).backward()
+                fused_amp.step()
+                scales.append(fused_amp.get_scale())
+            else:
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+                scales.append(scaler.get_scale())
             losses.append(loss.item())
-        return enc.embeddings.detach().clone(), lin.weight.detach().clone(), losses, scaler.get_scale()
+        return enc.embeddings.detach().clone(), net.weights.detach().clone(), losses, scales
 
-    e1, w1, l1, s1 = run(False)
-    e2, w2, l2, s2 = run(True)
-    assert s1 == s2 and s1 < 2.0 ** 30
-    assert (e1 != 0).any() and not torch.equal(e1, torch.zeros_like(e1))
-    assert torch.equal(e1, e2)
-    torch.testing.assert_close(w1, w2, rtol=1e-5, atol=1e-7)
-    assert l1 == pytest.approx(l2, rel=1e-5)
+    e1, w1, l1, s1 = run("torch")
+    e2, w2, l2, s2 = run(amp)
+    assert s1 == s2 and s1[0] < 2.0 ** 30 and max(s1[1:]) > min(s1)  # backed off first, grew later
+    assert torch.equal(e1, e2) and torch.equal(w1, w2)
+    assert l1 == l2
+
+
+def test_amp_check_and_update_follow_gradscaler_rules(dev):
+    import ctypes
+
+    from nerftex_hip import check, lib, ptr, stream
+
+    g = [torch.randn(4096 * 8 + 3, device=dev).half(), torch.randn(64, device=dev).half()]
+    found = torch.zeros((), device=dev)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    n = lambda ts: (ctypes.c_uint64 * len(ts))(*[t.numel() for t in ts])  # noqa: E731
+    check(lib.nerftex_amp_check_half(2, arr(g), n(g), ptr(found), stream()))
+    assert found.item() == 0.0
+    for bad, where in ((float("inf"), (0, 4096 * 8 + 2)), (float("nan"), (1, 5)), (-float("inf"), (0, 777))):
+        found.zero_()
+        g2 = [t.clone() for t in g]
+        g2[where[0]][where[1]] = bad
+        check(lib.nerftex_amp_check_half(2, arr(g2), n(g2), ptr(found), stream()))
+        assert found.item() == 1.0, (bad, where)
+    g2 = [t.clone() for t in g]
+    g2[0][11] = 65504.0  # the largest finite half is not an overflow
+    found.zero_()
+    check(lib.nerftex_amp_check_half(2, arr(g2), n(g2), ptr(found), stream()))
+    assert found.item() == 0.0
+
+    scale = torch.full((), 65536.0, device=dev)
+    tracker = torch.zeros((), dtype=torch.int32, device=dev)
+    step = torch.zeros((), device=dev)
+    ref = torch.amp.GradScaler("cuda", init_scale=65536.0, growth_interval=4)
+    ref._lazy_init_scale_growth_tracker(dev)
+    pattern = [0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0]
+    good = 0
+    for f in pattern:
+        found.fill_(float(f))
+        check(lib.nerftex_amp_update(ptr(scale), ptr(tracker), ptr(found), ptr(step), 2.0, 0.5, 4, stream()))
+        torch._amp_update_scale_(ref._scale, ref._growth_tracker, torch.full((), float(f), device=dev), 2.0, 0.5, 4)
+        good += 1 - f
+        assert found.item() == 0.0
+        assert scale.item() == ref._scale.item() and tracker.item() == ref._growth_tracker.item()
+        assert step.item() == good
