@@ -86,21 +86,50 @@ __device__ __forceinline__ int kmap(bool permuted, int ks, int g, int j) {
 // Stage the A-operand fragments of a matrix view A[m][k] (M x K, M % 16 == 0) into LDS.
 //   element (m,k) = transposed ? W[k*ldw + m] : W[m*ldw + k];  k >= K pads with zero.
 // Layout: fragment (mt, ks) at ((mt*KS + ks)*64 + lane) * 16 bytes -> one ds_read_b128 per lane, no conflicts.
+// Loads are 8- or 16-byte pieces of the row-major weights (rows start 32-byte aligned: ldw % 16 == 0, checked at the entry points):
+// element-wise 2-byte gathers go through the texture-address path at about one LANE per clock -- 7-14 k of them per workgroup, four
+// workgroups per CU, were 12 us of a 24 us inference launch.
+//   as stored  : a lane's 8 values are one 16-byte run of row m (natural k order) or two 8-byte runs (permuted)
+//   transposed : a thread takes 8 consecutive m of one k (one 16-byte load) and scatters them into the table with 2-byte LDS stores
 __device__ void stage_fragments(half8_t* __restrict__ dst, const half_t* __restrict__ W, int ldw, bool transposed, int M, int K,
                                 bool permuted) {
     const int KS = (K + 31) / 32;
-    const int total = (M / 16) * KS * 64;
-    for (int s = threadIdx.x; s < total; s += kBlockThreads) {
-        const int frag = s >> 6, lane = s & 63;
-        const int mt = frag / KS, ks = frag - mt * KS;
-        const int m = 16 * mt + (lane & 15), g = lane >> 4;
-        half8_t v;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = kmap(permuted, ks, g, j);
-            v[j] = k < K ? (transposed ? W[(size_t)k * ldw + m] : W[(size_t)m * ldw + k]) : (half_t)0.0f;
+    const half8_t zero8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (!transposed) {
+        const int total = (M / 16) * KS * 64;
+        for (int s = threadIdx.x; s < total; s += kBlockThreads) {
+            const int frag = s >> 6, lane = s & 63;
+            const int mt = frag / KS, ks = frag - mt * KS;
+            const int m = 16 * mt + (lane & 15), g = lane >> 4;
+            const half_t* row = W + (size_t)m * ldw;
+            half8_t v;
+            if (!permuted) {
+                const int k0 = 32 * ks + 8 * g;
+                v = k0 < K ? *reinterpret_cast<const half8_t*>(row + k0) : zero8;
+            } else {
+                const int ka = 32 * ks + 4 * g, kb = ka + 16;
+                const half4_t z4{0, 0, 0, 0};
+                const half4_t lo = ka < K ? *reinterpret_cast<const half4_t*>(row + ka) : z4;
+                const half4_t hi = kb < K ? *reinterpret_cast<const half4_t*>(row + kb) : z4;
+                v = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            dst[s] = v;
         }
-        dst[s] = v;
+    } else {
+        half_t* d = reinterpret_cast<half_t*>(dst);
+        const int MP = M / 8;
+        for (int s = threadIdx.x; s < KS * 32 * MP; s += kBlockThreads) {
+            const int k = s / MP, m0 = 8 * (s - k * MP);
+            const half8_t v = k < K ? *reinterpret_cast<const half8_t*>(W + (size_t)k * ldw + m0) : zero8;
+            const int ks = k >> 5, kk = k & 31;
+            const int g = permuted ? (kk & 15) >> 2 : kk >> 3;        // inverse of kmap
+            const int j = permuted ? 4 * (kk >> 4) + (kk & 3) : kk & 7;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int m = m0 + i;
+                d[((size_t)((m >> 4) * KS + ks) * 64 + (m & 15) + 16 * g) * 8 + j] = v[i];
+            }
+        }
     }
 }
 
@@ -954,12 +983,24 @@ int launch_backward_fused(const void* grad, const void* inputs, const void* weig
 
 using namespace nerftex;
 
+namespace {
+// the weight fragments are staged with 16-byte loads of the row-major layers (every layer starts a multiple of 256 halfs into the vector)
+int weights_aligned(const void* weights) {
+    if (reinterpret_cast<uintptr_t>(weights) & 15) {
+        set_error("FFMLP: the weight vector must be 16-byte aligned");
+        return NERFTEX_ERR_INVALID;
+    }
+    return NERFTEX_OK;
+}
+}  // namespace
+
 extern "C" int nerftex_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                                      void* forward_buffer, void* outputs, void* stream) {
     clear_error();
     int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NERFTEX_OK || B == 0) return rc;
+    if ((rc = weights_aligned(weights)) != NERFTEX_OK) return rc;
     if (!forward_buffer) {
         set_error("ffmlp_forward: forward_buffer must not be NULL (use ffmlp_inference)");
         return NERFTEX_ERR_INVALID;
@@ -975,6 +1016,7 @@ extern "C" int nerftex_ffmlp_inference(const void* inputs, const void* weights, 
     clear_error();
     int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NERFTEX_OK || B == 0) return rc;
+    if ((rc = weights_aligned(weights)) != NERFTEX_OK) return rc;
     return dispatch_forward<true>(inputs, weights, B, input_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs,
                                   as_stream(stream));
 }
@@ -986,6 +1028,7 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     clear_error();
     int rc = validate(B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc != NERFTEX_OK || B == 0) return rc;
+    if ((rc = weights_aligned(weights)) != NERFTEX_OK) return rc;
 
     hipStream_t st = as_stream(stream);
     const uint32_t H = hidden_dim, IN = input_dim, NL = num_layers;
