@@ -38,7 +38,9 @@ enum Act : uint32_t { kRelu = 0, kExp = 1, kSine = 2, kSigmoid = 3, kSquareplus 
 
 __device__ __forceinline__ float act_forward(uint32_t a, float x) {
     switch (a) {
-        case kRelu: return x > 0.0f ? x : 0.0f;
+        // integer max on the bit pattern: negative floats (sign bit set, -0 included) are negative ints -> +0, positive ones pass through.
+        // One v_max_i32; the float compare-select form comes out as v_max_f32 plus a canonicalising v_max_f32 x, x per element
+        case kRelu: return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
         case kExp: return expf(x);
         case kSine: return sinf(x);
         case kSigmoid: return 1.0f / (1.0f + expf(-x));
@@ -485,6 +487,34 @@ __global__ __launch_bounds__(kBlockThreads) void ffmlp_wgrad_kernel(const WgradA
 
 // per-workgroup combine of one weight-gradient matrix held as NA x NB result tiles per wave: LDS sum over the 4 waves, one fp32
 // write per element.  Everything is indexed at compile time so the accumulators stay in registers.
+// One layer's products for NB 16-row batch tiles: out[t][ot] = sum_ks A(ot, ks) . b[t][ks], the A fragments read from LDS (fr = table
+// base + lane).  The fragments of tile ot+1 are requested BEFORE the MFMAs of tile ot and the order is pinned: left alone, the
+// scheduler (at the register limit) reloads the same registers right after their last use and waits out the full LDS latency in
+// front of every tile -- ~30 exposed round trips per 32-row step of the fused backward.
+template <int NTILES, int KS, int NB>
+__device__ __forceinline__ void layer_products(const half8_t* __restrict__ fr, const half8_t (&b)[NB][KS], float4_t (&out)[NB][NTILES]) {
+    half8_t a[2][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) a[0][ks] = fr[(size_t)ks * 64];
+#pragma unroll
+    for (int ot = 0; ot < NTILES; ot++) {
+        if (ot + 1 < NTILES) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) a[(ot + 1) & 1][ks] = fr[(size_t)((ot + 1) * KS + ks) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float4_t c[NB];
+#pragma unroll
+        for (int t = 0; t < NB; t++) c[t] = float4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int t = 0; t < NB; t++) c[t] = mfma16(a[ot & 1][ks], b[t][ks], c[t]);
+#pragma unroll
+        for (int t = 0; t < NB; t++) out[t][ot] = c[t];
+    }
+}
+
 template <int NA, int NB>
 __device__ __forceinline__ void flush_tiles(const float4_t (&tiles)[NA][NB], float* __restrict__ red, float* __restrict__ out, uint32_t K, int wave,
                                             int lane) {
@@ -589,24 +619,69 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
 #pragma unroll
         for (int b = 0; b < IT; b++) gw_in[a][b] = zero;
 
-    // (requesting the NEXT step's operands before computing the current one was tried: +64 live registers push the 3-layer
-    //  instantiation to 256 + 256 registers with spills, 130 -> 160 us.  The four waves of a CU overlap each other instead.)
-    for (uint32_t row0 = blockIdx.x * kRowsPerBlock + wave * 16 * NT; row0 < B; row0 += gridDim.x * kRowsPerBlock) {
-        // ---- all loads of this step first: output gradient, inputs, saved activations of every layer
-        half8_t bg[NT];
+    // One wave per SIMD: nobody hides the latency of a step's loads, and asking for the NEXT step's operands in registers costs 64
+    // of them (tried: the 3-layer instantiation spills, 130 -> 160 us).  With the activations recomputed a step needs only its
+    // gradient and input rows -- 4 KiB per wave -- and those are prefetched one step ahead straight into LDS (global_load_lds: no
+    // registers, the wave's own counted vmcnt orders its later ds_read), two slots per wave.
+    constexpr int kPieces = NT + NT * KS0;  // 1-KiB pieces per step: grad tiles, then input tiles
+    constexpr size_t kRingOffset = ((size_t)(base_fh + (NL - 1) * per_hidden) * 1024 > 64 * 1024) ? (size_t)(base_fh + (NL - 1) * per_hidden) * 1024 : 64 * 1024;
+    half8_t* ring = reinterpret_cast<half8_t*>(smem + kRingOffset) + (size_t)wave * 2 * kPieces * 64;
+    const uint32_t row_step = gridDim.x * kRowsPerBlock;
+    auto prefetch = [&](uint32_t rw, int slot) {
+        half8_t* dst = ring + (size_t)slot * kPieces * 64;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if (g < 2) bg[t] = *reinterpret_cast<const half8_t*>(grad + (size_t)(row0 + 16 * t + r) * 16 + 8 * g);
-            else bg[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-        half8_t xin[NT][KS0];
+        for (int t = 0; t < NT; t++)  // lane groups 2, 3 have no gradient columns: they fetch a copy of groups 0, 1 and drop it
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grad + (size_t)(rw + 16 * t + r) * 16 + 8 * (g & 1)),
+                                             (__attribute__((address_space(3))) void*)(dst + t * 64), 16, 0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS0; ks++)
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                if (32 * ks + 8 * g < IN) xin[t][ks] = *reinterpret_cast<const half8_t*>(X + (size_t)(row0 + 16 * t + r) * IN + 32 * ks + 8 * g);
-                else xin[t][ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                const int k0 = 32 * ks + 8 * g;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)(rw + 16 * t + r) * IN + (k0 < IN ? k0 : 0)),
+                                                 (__attribute__((address_space(3))) void*)(dst + (NT + ks * NT + t) * 64), 16, 0, 0);
             }
+    };
+    uint32_t step = 0;
+    if constexpr (RECOMPUTE) {
+        const uint32_t first = blockIdx.x * kRowsPerBlock + wave * 16 * NT;
+        if (first < B) prefetch(first, 0);
+    }
+    for (uint32_t row0 = blockIdx.x * kRowsPerBlock + wave * 16 * NT; row0 < B; row0 += row_step, step++) {
+        // ---- all loads of this step first: output gradient, inputs, saved activations of every layer
+        half8_t bg[NT];
+        half8_t xin[NT][KS0];
+        if constexpr (RECOMPUTE) {
+            const uint32_t next = row0 + row_step;
+            prefetch(next < B ? next : row0, (step + 1) & 1);  // past the end: a harmless re-fetch keeps the count below uniform
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");  // everything but the pieces just requested has landed
+            const half8_t* src = ring + (size_t)(step & 1) * kPieces * 64;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const half8_t v = src[t * 64 + lane];
+                bg[t] = g < 2 ? v : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS0; ks++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const half8_t v = src[(NT + ks * NT + t) * 64 + lane];
+                    xin[t][ks] = (32 * ks + 8 * g < IN) ? v : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (g < 2) bg[t] = *reinterpret_cast<const half8_t*>(grad + (size_t)(row0 + 16 * t + r) * 16 + 8 * g);
+                else bg[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS0; ks++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (32 * ks + 8 * g < IN) xin[t][ks] = *reinterpret_cast<const half8_t*>(X + (size_t)(row0 + 16 * t + r) * IN + 32 * ks + 8 * g);
+                    else xin[t][ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+        }
         // yop[j][t][s] = post-activations of hidden layer NL-1-j for 16 rows x 32 features, already in the packed-operand form
         // (slot q < 4: feature 16(2s) + 4g + q, slot 4 + q: feature 16(2s+1) + 4g + q of row r): what the recomputation produces anyway,
         // what the transposing MFMAs consume, and what the activation derivative reads element by element
@@ -618,35 +693,24 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 asm volatile("" ::: "memory");  // re-read the weight fragments from LDS per tile instead of keeping 20 of them in registers
-                float4_t fa[OT];
+                float4_t fa[1][OT];
+                half8_t x1[1][KS0];
 #pragma unroll
-                for (int ot = 0; ot < OT; ot++) fa[ot] = zero;
-#pragma unroll
-                for (int ks = 0; ks < KS0; ks++)
-#pragma unroll
-                    for (int ot = 0; ot < OT; ot++) fa[ot] = mfma16(frags[(size_t)(base_f0 + ot * KS0 + ks) * 64 + lane], xin[t][ks], fa[ot]);
+                for (int ks = 0; ks < KS0; ks++) x1[0][ks] = xin[t][ks];
+                layer_products<OT, KS0, 1>(frags + (size_t)base_f0 * 64 + lane, x1, fa);
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
-                    half8_t fop[KSH];
+                    half8_t fop[1][KSH];
 #pragma unroll
                     for (int ot = 0; ot < OT; ot++)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) fa[ot][q] = act_fwd<ACT>(act, fa[ot][q]);
+                        for (int q = 0; q < 4; q++) fa[0][ot][q] = act_fwd<ACT>(act, fa[0][ot][q]);
 #pragma unroll
                     for (int s = 0; s < KSH; s++) {
-                        fop[s] = pack_operand(fa[2 * s], fa[2 * s + 1]);
-                        yop[NL - 1 - l][t][s] = fop[s];
+                        fop[0][s] = pack_operand(fa[0][2 * s], fa[0][2 * s + 1]);
+                        yop[NL - 1 - l][t][s] = fop[0][s];
                     }
-                    if (l + 1 < NL) {
-                        const half8_t* fl = frags + (size_t)(base_fh + l * per_hidden) * 64;
-#pragma unroll
-                        for (int ot = 0; ot < OT; ot++) {
-                            float4_t c = zero;
-#pragma unroll
-                            for (int ks = 0; ks < KSH; ks++) c = mfma16(fl[(size_t)(ot * KSH + ks) * 64 + lane], fop[ks], c);
-                            fa[ot] = c;
-                        }
-                    }
+                    if (l + 1 < NL) layer_products<OT, KSH, 1>(frags + (size_t)(base_fh + l * per_hidden) * 64 + lane, fop, fa);
                 }
             }
         } else {
@@ -717,23 +781,7 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
                 Aprev[2 * s] = pack_operand(mfma16(bop[0][s], selP0, zero), mfma16(bop[1][s], selP0, zero));
                 Aprev[2 * s + 1] = pack_operand(mfma16(bop[0][s], selP1, zero), mfma16(bop[1][s], selP1, zero));
             }
-            if (j + 1 < NL) {
-                const half8_t* fl = frags + (size_t)(base_hidden + j * per_hidden) * 64;  // W_{NL-1-j}^T
-#pragma unroll
-                for (int ot = 0; ot < OT; ot++) {
-                    float4_t c[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; t++) c[t] = zero;
-#pragma unroll
-                    for (int ks = 0; ks < KSH; ks++) {
-                        const half8_t a = fl[(size_t)(ot * KSH + ks) * 64 + lane];
-#pragma unroll
-                        for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; t++) acc[t][ot] = c[t];
-                }
-            }
+            if (j + 1 < NL) layer_products<OT, KSH, NT>(frags + (size_t)(base_hidden + j * per_hidden) * 64 + lane, bop, acc);  // W_{NL-1-j}^T
         }
 
         // ---- first matrix: dW_0 += dPre_0^T . X
@@ -751,24 +799,16 @@ __global__ __launch_bounds__(kBlockThreads, 1) void ffmlp_backward_fused_kernel(
         }
 
         if (grad_inputs) {  // dL/dX = W_0^T . dPre_0, no activation (ffmlp.cu:880-887)
-            const half8_t* fi = frags + (size_t)base_in * 64;
+            float4_t gi[NT][IT];
+            layer_products<IT, KSH, NT>(frags + (size_t)base_in * 64 + lane, bop, gi);
 #pragma unroll
-            for (int it = 0; it < IT; it++) {
-                float4_t c[NT];
+            for (int it = 0; it < IT; it++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) c[t] = zero;
-#pragma unroll
-                for (int ks = 0; ks < KSH; ks++) {
-                    const half8_t a = fi[(size_t)(it * KSH + ks) * 64 + lane];
-#pragma unroll
-                    for (int t = 0; t < NT; t++) c[t] = mfma16(a, bop[t][ks], c[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < NT; t++) store4(grad_inputs + (size_t)(row0 + 16 * t + r) * IN + 16 * it + 4 * g, c[t]);
-            }
+                for (int t = 0; t < NT; t++) store4(grad_inputs + (size_t)(row0 + 16 * t + r) * IN + 16 * it + 4 * g, gi[t][it]);
         }
     }
 
+    if constexpr (RECOMPUTE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's spare prefetch
     // ---- combine the 4 waves in LDS (one matrix at a time, <= 16 tiles = 64 KiB), one fp32 partial row per workgroup
     float* red = reinterpret_cast<float*>(smem);
     float* out = partials + (size_t)blockIdx.x * n_params;
@@ -939,6 +979,7 @@ int launch_fused(const void* grad, const void* inputs, const void* weights, cons
     const bool recompute = fwd == nullptr;
     size_t lds = lds_bytes_dgrad(H, 16 * IT, NL, true) + (recompute ? (size_t)(frag_count(H, 16 * IT) + (NL - 1) * frag_count(H, H)) * 1024 : 0);
     if (lds < 64 * 1024) lds = 64 * 1024;  // the end-of-kernel combine reuses the fragment area
+    if (recompute) lds += (size_t)4 * 2 * (2 + 2 * ((16 * IT + 31) / 32)) * 1024;  // prefetch ring: 4 waves x 2 slots x (grad + input pieces) KiB
     int rc = lds_check(lds);
     if (rc != NERFTEX_OK) return rc;
     auto kernel = recompute ? ffmlp_backward_fused_kernel<H, NL, IT, true, ACT> : ffmlp_backward_fused_kernel<H, NL, IT, false, ACT>;
