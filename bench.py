@@ -237,29 +237,22 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             renderer.update_mean_count()
             renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
 
-    # ---- the same step as ONE replayed HIP graph: ~100 launches per 1.6 ms step put the eager loop at the edge of being bound by
-    # the host's launch rate (the same kernels took 1.60 or 1.83 ms per step depending on the box's host); a graph takes the
-    # host out of it.  Static inputs: the batch is picked on the device by an index tensor, the sample buffers are sized by a
-    # fixed count (the ring's mean rounded up to 4096 + 4096), the counter is a fixed tensor committed to the ring after replay.
-    pool_o = torch.stack([p[0] for p in pool])
-    pool_d = torch.stack([p[1] for p in pool])
-    batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
-    graph_counter = torch.zeros(2, dtype=torch.int32, device=dev)
-    gstate = {"graph": None, "M": 0}
+    # ---- the same step as ONE replayed HIP graph: the eager loop is bound by the host's launch rate (the same kernels took 1.60 or
+    # 1.83 ms per step depending on the box's host); a graph takes the host out of it.  Sixteen graphs, one per slot of the
+    # step-counter ring, each with its ray batch and its counter slot baked in; the sample buffers are sized by a fixed count (the
+    # ring's mean rounded up to 4096 + 4096); all graphs share one memory pool (they never run concurrently).
+    RING = 16  # = the renderer's step-counter ring: graph g is step g of a 16-step cycle
+    gstate = {"graphs": None, "M": 0}
 
-    def body_fb():
-        ro, rd, tgt = pool_o.index_select(0, batch_idx)[0], pool_d.index_select(0, batch_idx)[0], gt.index_select(0, batch_idx)[0]
+    def body_fb(g):
+        ro, rd = pool[g % n_pool]
         reducer.zero_grad()
-        forward_backward(ro, rd, tgt, counter=graph_counter, mean_count=gstate["M"])
-        total_samples.add_(graph_counter[0])
+        renderer.local_step = g  # the step's counter is ring slot g, exactly as in the eager loop
+        counter = forward_backward(ro, rd, gt[g % n_pool], mean_count=gstate["M"])
+        total_samples.add_(counter[0])
 
     def body_opt():
         optimizer_step()
-
-    def step_body():
-        body_fb()
-        reducer.all_reduce()
-        body_opt()
 
     def capture():
         gstate["M"] = (renderer.mean_count + 4095) // 4096 * 4096 + 4096
@@ -267,33 +260,39 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):  # allocator / library workspaces at this size, outside the capture
-                step_body()
-        torch.cuda.current_stream().wait_stream(side)
-        if split_graph:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                body_fb()
-            reducer.all_reduce()
-            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            for g in range(3):  # allocator / library workspaces at this size, outside the capture
+                body_fb(g)
+                reducer.all_reduce()
                 body_opt()
-            gstate["graph"] = (ga, gb)
-        else:
-            g = torch.cuda.CUDAGraph()
+        torch.cuda.current_stream().wait_stream(side)
+        graphs, mem = [], None
+        for g in range(RING):  # one graph per ring slot: static ray batch, static counter slot -> nothing to select or copy per step
             # thread_local: only this thread's calls can invalidate the capture (an RCCL watchdog thread may query events meanwhile)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                step_body()
-            gstate["graph"] = (g,)
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
+                body_fb(g)
+                if not split_graph:
+                    body_opt()
+            mem = ga.pool()
+            gb = None
+            if split_graph:
+                reducer.all_reduce()
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=mem, capture_error_mode="thread_local"):
+                    body_opt()
+            graphs.append((ga, gb))
+        gstate["graphs"] = graphs
+        renderer.local_step = 0
         total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
 
     def graph_step(k):
-        batch_idx.fill_(k % n_pool)
-        gstate["graph"][0].replay()
-        if split_graph:
+        ga, gb = gstate["graphs"][renderer.local_step]
+        ga.replay()
+        if gb is not None:
             reducer.all_reduce()
-            gstate["graph"][1].replay()
-        renderer.commit_counter(graph_counter)
-        if renderer.local_step == 16:
+            gb.replay()
+        renderer.local_step += 1
+        if renderer.local_step == RING:
             renderer.update_mean_count()
             renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
             if renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]:
