@@ -83,6 +83,19 @@ int nerftex_grid_encode_backward(const void* grad, const float* inputs, const vo
                                  uint32_t gridtype, int align_corners, int dtype, int layout,
                                  void* stream);
 
+/* The same two calls with the caller's coordinate normalisation folded in: every kernel reads x = (inputs + in_add) * in_mul
+ * (two fp32 roundings, as the framework's add and multiply before the call: gridencoder/grid.py:141 with in_add = bound,
+ * in_mul = 1 / (2 bound)).  dy_dx / grad_inputs stay derivatives with respect to the NORMALISED x; in_mul > 0.             */
+int nerftex_grid_encode_forward_affine(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                       int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                                       int layout, float in_add, float in_mul, void* stream);
+int nerftex_grid_encode_backward_affine(const void* grad, const float* inputs, const void* embeddings,
+                                        const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
+                                        void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, int layout,
+                                        float in_add, float in_mul, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * shencoder  (reference: shencoder/src/bindings.cpp, shencoder.h:10,13,
  *             shencoder.cu:386-440).  float32 only (the wrapper forces it,

@@ -17,11 +17,24 @@ constexpr uint32_t kLevelFwdMinBatch = 8192;  // from here on the XCD-pinned (po
 struct LevelConsts {
     float scale[kMaxLevels];
     uint32_t resolution[kMaxLevels];
+    // optional normalisation of the coordinates on load, x = (raw + in_add) * in_mul: what GridEncoder.forward does with two framework
+    // ops over the [B, D] inputs before calling the kernel (gridencoder/grid.py:141, (x + bound) / (2 bound)); same two roundings
+    float in_add, in_mul;
+    bool in_affine;
 };
 
+// coordinate d of point b as the kernels see it (identity unless the caller folded its normalisation in)
+__device__ __forceinline__ float load_coord(const LevelConsts& lc, const float* __restrict__ inputs, size_t idx) {
+    const float raw = inputs[idx];
+    return lc.in_affine ? (raw + lc.in_add) * lc.in_mul : raw;
+}
+
 // host: gridencoder.cu:125-127, evaluated once per call instead of per thread
-inline LevelConsts make_level_consts(uint32_t L, float S, uint32_t H) {
+inline LevelConsts make_level_consts(uint32_t L, float S, uint32_t H, bool affine = false, float in_add = 0.0f, float in_mul = 1.0f) {
     LevelConsts lc{};
+    lc.in_affine = affine;
+    lc.in_add = in_add;
+    lc.in_mul = in_mul;
     for (uint32_t l = 0; l < L && l < (uint32_t)kMaxLevels; l++) {
         const float p = exp2f((float)l * S) * (float)H;
         const float scale = p - 1.0f;

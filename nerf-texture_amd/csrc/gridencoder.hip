@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(const float* __restri
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
+        x[d] = load_coord(lc, inputs, (size_t)b * D + d);
         if (x[d] < 0 || x[d] > 1) oob = true;
     }
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
+        x[d] = load_coord(lc, inputs, (size_t)b * D + d);
         if (x[d] < 0 || x[d] > 1) oob = true;
     }
     T* out = out_lbc + ((size_t)level * B + b) * C;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
     float x[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        x[d] = valid ? inputs[(size_t)b * D + d] : 0.0f;
+        x[d] = valid ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
         if (x[d] < 0 || x[d] > 1) valid = false;  // gridencoder.cu:248-253: out-of-range points add nothing
     }
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kOwnerThreads) void grid_backward_owner_kernel(cons
         auto fetch = [&](uint32_t b) {
             if (b < hi) {
 #pragma unroll
-                for (int d = 0; d < D; d++) xn[d] = inputs[(size_t)b * D + d];
+                for (int d = 0; d < D; d++) xn[d] = load_coord(lc, inputs, (size_t)b * D + d);
                 load_row<T, C>(g_level + (size_t)b * C, gn);
             } else {
 #pragma unroll
@@ -927,14 +927,60 @@ int check_common(uint32_t L, int dtype, int layout) {
 
 using namespace nerftex;
 
+namespace {
+int affine_ok(float in_mul) {
+    if (!(in_mul > 0.0f) || !std::isfinite(in_mul)) {
+        set_error("grid_encode: the input scale must be positive and finite");
+        return NERFTEX_ERR_INVALID;
+    }
+    return NERFTEX_OK;
+}
+int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
+                       uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                       int layout, bool affine, float in_add, float in_mul, void* stream);
+int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream);
+}  // namespace
+
 extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                            int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
                                            int layout, void* stream) {
+    return grid_forward_entry(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype, align_corners, dtype,
+                              layout, false, 0.0f, 1.0f, stream);
+}
+
+extern "C" int nerftex_grid_encode_forward_affine(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                                  uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                                  int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                                                  int layout, float in_add, float in_mul, void* stream) {
     clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    return grid_forward_entry(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype, align_corners, dtype,
+                              layout, true, in_add, in_mul, stream);
+}
+
+extern "C" int nerftex_grid_encode_backward_affine(const void* grad, const float* inputs, const void* embeddings,
+                                                   const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                                   uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
+                                                   void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, int layout,
+                                                   float in_add, float in_mul, void* stream) {
+    (void)embeddings;
+    clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs, gridtype,
+                               align_corners, dtype, layout, true, in_add, in_mul, stream);
+}
+
+namespace {
+int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
+                       uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                       int layout, bool affine, float in_add, float in_mul, void* stream) {
+    if (!affine) clear_error();
     int rc = check_common(L, dtype, layout);
     if (rc != NERFTEX_OK) return rc;
-    const LevelConsts lc = make_level_consts(L, S, H);
+    const LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
     if (dtype == NERFTEX_F32)
         return dispatch_forward<float>(inputs, embeddings, offsets, outputs, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
                                        gridtype, align_corners != 0, layout, as_stream(stream));
@@ -942,19 +988,27 @@ extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embe
                                     align_corners != 0, layout, as_stream(stream));
 }
 
+int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream) {
+    if (!affine) clear_error();
+    int rc = check_common(L, dtype, layout);
+    if (rc != NERFTEX_OK) return rc;
+    const LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
+    if (dtype == NERFTEX_F32)
+        return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
+                                        grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+    return dispatch_backward<half_t>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
+                                     grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+}
+}  // namespace
+
 extern "C" int nerftex_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
                                             const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                                             uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
                                             void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, int layout,
                                             void* stream) {
     (void)embeddings;  // the reference passes it but never reads it in backward
-    clear_error();
-    int rc = check_common(L, dtype, layout);
-    if (rc != NERFTEX_OK) return rc;
-    const LevelConsts lc = make_level_consts(L, S, H);
-    if (dtype == NERFTEX_F32)
-        return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
-                                        grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
-    return dispatch_backward<half_t>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
-                                     grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs, gridtype,
+                               align_corners, dtype, layout, false, 0.0f, 1.0f, stream);
 }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const float* __r
             const uint32_t b = b0 + lane;
             float xs[D];
 #pragma unroll
-            for (int d = 0; d < D; d++) xs[d] = b < B ? inputs[(size_t)b * D + d] : 0.0f;
+            for (int d = 0; d < D; d++) xs[d] = b < B ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
             Sample<T, D> sm;
             make_sample<T, D, false>(sm, xs, b < B, g, scale, align_corners, index_of, hashmap_size, merge_runs);
             if (sm.valid) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(const T* __restri
     // path of the first barrier: table latency + scan + its own samples)
     float xs[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
+    for (int d = 0; d < D; d++) xs[d] = in_batch ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
     float g[2] = {0.0f, 0.0f};
     if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
     if (threadIdx.x < kWave) {  // wave 0: this workgroup's run lengths -> LDS offsets, and the runs' global starts (2 tiles per lane)
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_dir_kernel(const T* __re
     if (threadIdx.x < kMaxTilesPerLevel) hist[threadIdx.x] = 0;
     float xs[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) xs[d] = in_batch ? inputs[(size_t)b * D + d] : 0.0f;
+    for (int d = 0; d < D; d++) xs[d] = in_batch ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
     float g[2] = {0.0f, 0.0f};
     if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
     const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);

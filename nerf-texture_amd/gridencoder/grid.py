@@ -35,8 +35,9 @@ class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
-                align_corners=False):
+                align_corners=False, affine=None):
         # inputs [B,D] float32 in [0,1]; embeddings [rows,C]; offsets [L+1] int32 -> [B, L*C]
+        # affine = (add, mul) (not in the reference): the kernels read (inputs + add) * mul -- the caller's normalisation, folded in
         if not inputs.is_cuda:
             raise RuntimeError("inputs must be a CUDA tensor")
         inputs = inputs.contiguous().float()
@@ -58,10 +59,16 @@ class _grid_encode(Function):
             dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)
 
         tok = timer.start("grid_encode_forward")
-        check(lib.nerftex_grid_encode_forward(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, S, H,
-                                              int(bool(calc_grad_inputs)), ptr(dy_dx), int(gridtype), int(bool(align_corners)), tag,
-                                              LAYOUT_BLC, stream()))
+        if affine is None:
+            check(lib.nerftex_grid_encode_forward(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, S, H,
+                                                  int(bool(calc_grad_inputs)), ptr(dy_dx), int(gridtype), int(bool(align_corners)), tag,
+                                                  LAYOUT_BLC, stream()))
+        else:
+            check(lib.nerftex_grid_encode_forward_affine(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, S, H,
+                                                         int(bool(calc_grad_inputs)), ptr(dy_dx), int(gridtype), int(bool(align_corners)),
+                                                         tag, LAYOUT_BLC, float(affine[0]), float(affine[1]), stream()))
         timer.stop(tok)
+        ctx.affine = affine
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = (B, D, C, L, S, H, gridtype)
@@ -84,14 +91,23 @@ class _grid_encode(Function):
             grad_inputs = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)  # placeholder pointer, never written
 
         tok = timer.start("grid_encode_backward")
-        check(lib.nerftex_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L,
-                                               S, H, int(bool(ctx.calc_grad_inputs)), ptr(dy_dx), ptr(grad_inputs), int(gridtype),
-                                               int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC, stream()))
+        if ctx.affine is None:
+            check(lib.nerftex_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L,
+                                                   S, H, int(bool(ctx.calc_grad_inputs)), ptr(dy_dx), ptr(grad_inputs), int(gridtype),
+                                                   int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC, stream()))
+        else:
+            check(lib.nerftex_grid_encode_backward_affine(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C,
+                                                          L, S, H, int(bool(ctx.calc_grad_inputs)), ptr(dy_dx), ptr(grad_inputs), int(gridtype),
+                                                          int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC,
+                                                          float(ctx.affine[0]), float(ctx.affine[1]), stream()))
         timer.stop(tok)
 
         if ctx.calc_grad_inputs:
-            return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
-        return None, grad_embeddings, None, None, None, None, None, None
+            grad_inputs = grad_inputs.to(inputs.dtype)
+            if ctx.affine is not None:  # chain rule through the folded (x + add) * mul, as autograd does for the framework's multiply
+                grad_inputs = grad_inputs * ctx.affine[1]
+            return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+        return None, grad_embeddings, None, None, None, None, None, None, None
 
 
 grid_encode = _grid_encode.apply
@@ -162,10 +178,20 @@ class GridEncoder(nn.Module):
             self._half_cache = cache
         return cache[2]
 
+    fold_normalisation = True  # False: the reference's two framework ops (x + bound) / (2 bound) in front of the kernel
+
     def forward(self, inputs, bound=1):
         # inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
-        inputs = (inputs + bound) / (2 * bound)
         prefix = list(inputs.shape[:-1])
+        if self.fold_normalisation and inputs.dtype == torch.float32:
+            # the same (x + bound) * (1 / (2 bound)) -- that is what the framework's division by a Python scalar computes -- applied
+            # by the kernels as they read each coordinate: no [B, D] intermediates, two launches fewer
+            inputs = inputs.reshape(-1, self.input_dim)
+            outputs = grid_encode(inputs, self._table(), self.offsets, self.per_level_scale, self.base_resolution,
+                                  inputs.requires_grad, self.gridtype_id, self.align_corners,
+                                  (float(bound), float(np.float32(1.0) / np.float32(2 * bound))))
+            return outputs.view(prefix + [self.output_dim])
+        inputs = (inputs + bound) / (2 * bound)
         inputs = inputs.view(-1, self.input_dim)
         outputs = grid_encode(inputs, self._table(), self.offsets, self.per_level_scale, self.base_resolution,
                               inputs.requires_grad, self.gridtype_id, self.align_corners)
