@@ -83,6 +83,12 @@ int nerftex_grid_encode_backward(const void* grad, const float* inputs, const vo
                                  uint32_t gridtype, int align_corners, int dtype, int layout,
                                  void* stream);
 
+/* Install the host copy of a level table (offsets_host [L+1]) for the device table at offsets_dev.  The large-batch backward
+ * plans its launch from a host copy, which it otherwise reads back once per (pointer, L, device) and keeps: a caller that may
+ * pass a NEW table at a recycled address must register it (the kernels trap on a host/device mismatch).  The Python wrapper
+ * registers every offsets tensor it sees for the first time.                                                             */
+int nerftex_grid_register_offsets(const int32_t* offsets_dev, uint32_t L, const int32_t* offsets_host);
+
 /* The same two calls with the caller's coordinate normalisation folded in: every kernel reads x = (inputs + in_add) * in_mul
  * (two fp32 roundings, as the framework's add and multiply before the call: gridencoder/grid.py:141 with in_add = bound,
  * in_mul = 1 / (2 bound)).  dy_dx / grad_inputs stay derivatives with respect to the NORMALISED x; in_mul > 0.             */

@@ -862,3 +862,21 @@ template int grid_backward_binned<half_t, 3>(const half_t*, bool, const float*, 
 
 }  // namespace gridenc
 }  // namespace nerftex
+
+// The host copy of a level table is cached per (device pointer, L, device): a caller that knows the table can install it up front --
+// and must, when it may hand over a NEW table at an address the allocator has recycled from an old one (the kernels compare the
+// device table with the host copy and trap on a mismatch rather than scatter out of bounds).
+extern "C" int nerftex_grid_register_offsets(const int32_t* offsets_dev, uint32_t L, const int32_t* offsets_host) {
+    using namespace nerftex;
+    using namespace nerftex::gridenc;
+    clear_error();
+    if (!offsets_dev || !offsets_host || L == 0 || L > (uint32_t)kMaxLevels) {
+        set_error("grid_register_offsets: need a device table, its host copy and 1 <= L <= %d", kMaxLevels);
+        return NERFTEX_ERR_INVALID;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    g_tables[TableKey{offsets_dev, L, dev}] = std::vector<int32_t>(offsets_host, offsets_host + L + 1);
+    return NERFTEX_OK;
+}

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "nerftex_profile_report": [C.c_char_p, _sz],
     "nerftex_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _u32, _i, _i, _i, _vp],
     "nerftex_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _vp],
+    "nerftex_grid_register_offsets": [_vp, _u32, _vp],
     "nerftex_grid_encode_forward_affine": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _u32, _i, _i, _i, _f32, _f32, _vp],
     "nerftex_grid_encode_backward_affine": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _f32, _f32, _vp],
     "nerftex_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _i, _vp, _vp],

@@ -660,3 +660,51 @@ def test_grid_folded_normalisation_matches_framework_ops(bound, B):
     # table gradient: fp16 sums whose order of partial sums is not fixed in either configuration (per-sample atomics below 16 k points,
     # several partial tiles per LDS tile above): equal up to that rounding noise
     torch.testing.assert_close(ge0.float(), ge1.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_grid_level_table_at_recycled_address():
+    """Encoders with the same number of levels but different tables whose offsets live at the SAME device address (what the caching
+    allocator does when one encoder replaces another; forced here by reusing the buffer).  The large-batch backward plans from a
+    host copy of the table cached per pointer -- the wrapper registers every offsets tensor / contents it sees, so each encoder
+    gets its own plan (a stale one trips the kernels' trap and takes the process down)."""
+    import gc
+
+    import torch
+    from gridencoder import GridEncoder
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    x = torch.rand(20000, 3, device=dev) * 2 - 1
+    g = torch.randn(20000, 16, device=dev)
+    ptrs, buf = [], None
+    for log2_t, res in ((15, 512), (12, 128), (14, 300)):
+        enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=log2_t, desired_resolution=res).to(dev)
+        enc.embeddings.data.uniform_(-1.0, 1.0)
+        if buf is None:
+            buf = enc.offsets
+        else:
+            buf.copy_(enc.offsets)
+            enc.offsets = buf
+        ptrs.append(enc.offsets.data_ptr())
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(x, bound=1)
+        y.backward(g.to(y.dtype))
+        torch.cuda.synchronize()
+        big = enc.embeddings.grad.clone()
+        enc.embeddings.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):  # the per-sample path (small batch) as the check: no plan involved
+            y = enc(x[:8192], bound=1)
+        y.backward(g[:8192].to(y.dtype))
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(x[8192:16384], bound=1)
+        y.backward(g[8192:16384].to(y.dtype))
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(x[16384:], bound=1)
+        y.backward(g[16384:].to(y.dtype))
+        torch.testing.assert_close(big.float(), enc.embeddings.grad.float(), rtol=3e-2, atol=3e-2)
+        del enc, y
+        gc.collect()
+    assert len(set(ptrs)) == 1
