@@ -110,6 +110,9 @@ def main():
             g = (torch.randn(Bp, 16, device=dev) * 1e-3).half()
             bb = torch.zeros_like(fb)
             gw = torch.zeros_like(w)
+            gx = torch.empty_like(x)
+            res[f"ffmlp_bwd_recompute_{nm}"] = {"ms": timeit(lambda: check(lib.nerftex_ffmlp_backward(ptr(g), ptr(x), ptr(w), None, Bp, 32, 16, 64, net.num_layers, 0, 6, 1, None,
+                                                                                                      ptr(gx), ptr(gw), stream())))}  # what training runs: activations rebuilt, dL/dX written
             res[f"ffmlp_bwd_{nm}"] = {"ms": timeit(lambda: check(lib.nerftex_ffmlp_backward(ptr(g), ptr(x), ptr(w), ptr(fb), Bp, 32, 16, 64, net.num_layers, 0, 6, 0, ptr(bb),
                                                                                             None, ptr(gw), stream())))}
 
