@@ -39,6 +39,10 @@ extern "C" {
 /* layout of the per-level feature tensor handed across the boundary */
 #define NERFTEX_LAYOUT_LBC 0    /* [L, B, C]  (reference native layout)          */
 #define NERFTEX_LAYOUT_BLC 1    /* [B, L*C]   (what grid.py returns to callers)  */
+/* OR-ed into `layout` of nerftex_grid_encode_backward(_affine): grad_embeddings arrives UNINITIALISED and is overwritten (the
+ * reference's contract, and the default here, is a zero-filled buffer the kernels add into -- gridencoder/grid.py:74).  Saves
+ * the caller's fill pass over the table; the large-batch path then writes every row itself.                               */
+#define NERFTEX_LAYOUT_GRAD_OVERWRITE 0x100
 
 /* thread-local text of the last error on this thread ("" if none) */
 const char* nerftex_last_error(void);

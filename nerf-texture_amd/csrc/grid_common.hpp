@@ -174,7 +174,7 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]
 // grad is [B, L*2] (blc) or level-major [L,B,2].
 template <typename T, int D>
 int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
-                         const LevelConsts& lc, uint32_t gridtype, bool align_corners, hipStream_t st);
+                         const LevelConsts& lc, uint32_t gridtype, bool align_corners, bool overwrite, hipStream_t st);
 
 }  // namespace gridenc
 }  // namespace nerftex

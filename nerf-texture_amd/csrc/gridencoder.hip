@@ -796,11 +796,24 @@ int launch_forward(const float* inputs, const T* emb, const int* offsets, T* out
     return check_launch("grid_encode_forward");
 }
 
+// grad table <- 0 for all offsets[L] rows (the caller said it is uninitialised and this path accumulates into it)
+template <typename T, int C>
+__global__ __launch_bounds__(256) void zero_table_rows_kernel(T* __restrict__ table, const int* __restrict__ offsets, uint32_t L) {
+    const size_t n = (size_t)(uint32_t)offsets[L] * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) table[i] = (T)0.0f;
+}
+
 template <typename T, int D, int C>
 int launch_backward(const T* grad, const float* inputs, const int* offsets, T* grad_emb, uint32_t B, uint32_t L,
                     const LevelConsts& lc, bool calc_grad, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool align,
-                    int layout, hipStream_t st) {
-    if (B == 0) return NERFTEX_OK;
+                    int layout, bool overwrite, hipStream_t st) {
+    // overwrite (NERFTEX_LAYOUT_GRAD_OVERWRITE): grad_emb arrives uninitialised.  The single-pass binned path writes every row itself;
+    // every other path adds into the table, so it is cleared first (its size is offsets[L] rows: read on the device)
+    auto clear_table = [&]() {
+        hipLaunchKernelGGL((zero_table_rows_kernel<T, C>), dim3(1024), dim3(256), 0, st, grad_emb, offsets, L);
+        return check_launch("grid_encode_backward(clear)");
+    };
+    if (B == 0) return overwrite ? clear_table() : NERFTEX_OK;
     const uint32_t nchunks = div_up(B, 256u);
     const dim3 grid(kXcds * nchunks * div_up(L, kXcds)), block(256);
     const bool blc = layout == NERFTEX_LAYOUT_BLC;
@@ -811,10 +824,11 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
         if (owner) {  // every level through the LDS tile owners, no per-sample global atomics at all
             const char* algo = getenv("NERFTEX_GRID_BWD_ALGO");  // "sweep" keeps the tile-owner sweep; default = binning
             if (!(algo && algo[0] == 's')) {
-                rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, st);
+                rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, overwrite, st);
                 if (rc == NERFTEX_OK) goto table_done;
                 if (rc > 0) return rc;  // rc < 0: shape outside the binned path's limits -> sweep below
             }
+            if (overwrite && (rc = clear_table()) != NERFTEX_OK) return rc;
             const T* g = grad;
             if (blc) {  // the sweep reads level-major gradients
                 T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
@@ -844,6 +858,7 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
     }
 table_done:
     if (!owner) {  // per-sample atomics with wave64 run compression
+        if (overwrite && (rc = clear_table()) != NERFTEX_OK) return rc;
         {
             KernelTimer kt("grid_backward_kernel", st, kTimeGrid);
             if (blc)
@@ -892,10 +907,10 @@ int dispatch_forward(const float* inputs, const void* emb, const int* offsets, v
 template <typename T>
 int dispatch_backward(const void* grad, const float* inputs, const int* offsets, void* grad_emb, uint32_t B, uint32_t D,
                       uint32_t C, uint32_t L, const LevelConsts& lc, bool calc_grad, const void* dy_dx, void* grad_inputs,
-                      uint32_t gridtype, bool align, int layout, hipStream_t st) {
+                      uint32_t gridtype, bool align, int layout, bool overwrite, hipStream_t st) {
 #define BWD(DD, CC)                                                                                                      \
     return launch_backward<T, DD, CC>((const T*)grad, inputs, offsets, (T*)grad_emb, B, L, lc, calc_grad, (const T*)dy_dx, \
-                                      (T*)grad_inputs, gridtype, align, layout, st)
+                                      (T*)grad_inputs, gridtype, align, layout, overwrite, st)
     if (D == 2) {
         switch (C) { case 1: BWD(2, 1); case 2: BWD(2, 2); case 4: BWD(2, 4); case 8: BWD(2, 8); default: break; }
     } else if (D == 3) {
@@ -992,14 +1007,16 @@ int grid_backward_entry(const void* grad, const float* inputs, const int32_t* of
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                         int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream) {
     if (!affine) clear_error();
+    const bool overwrite = (layout & NERFTEX_LAYOUT_GRAD_OVERWRITE) != 0;
+    layout &= ~NERFTEX_LAYOUT_GRAD_OVERWRITE;
     int rc = check_common(L, dtype, layout);
     if (rc != NERFTEX_OK) return rc;
     const LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
     if (dtype == NERFTEX_F32)
         return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
-                                        grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+                                        grad_inputs, gridtype, align_corners != 0, layout, overwrite, as_stream(stream));
     return dispatch_backward<half_t>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
-                                     grad_inputs, gridtype, align_corners != 0, layout, as_stream(stream));
+                                     grad_inputs, gridtype, align_corners != 0, layout, overwrite, as_stream(stream));
 }
 }  // namespace
 

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_dir_kernel(const T* __re
                                                                   const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
                                                                   uint32_t gridtype, bool align_corners, const DirTable tab,
                                                                   uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, bool merge_runs,
-                                                                  uint32_t nchunks) {
+                                                                  uint32_t nchunks, T* __restrict__ zero_grid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel];
     constexpr int NP = Sample<T, D>::NP;
@@ -535,6 +535,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_dir_kernel(const T* __re
     const uint32_t b = chunk * kBinSamples + threadIdx.x;
     const bool in_batch = b < B;
     const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
+    // caller handed over an uninitialised gradient table: the tiles of this level that several K4d work items will add into
+    // (coarse levels only) start from zero -- this level's workgroups clear one slice of its rows each; sole-owner tiles are
+    // written whole by K4d
+    if (zero_grid != nullptr && tab.slices[level] > 1) {
+        const uint32_t units = hashmap_size * 2, per = div_up(units, nchunks);  // elements (2 per row)
+        T* base = zero_grid + (size_t)(uint32_t)tab.offsets[level] * 2;
+        for (uint32_t i = chunk * per + threadIdx.x; i < min(units, (chunk + 1) * per); i += kBinThreads) base[i] = (T)0.0f;
+    }
     const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
     Rec<T>* region = records + ((size_t)level * nchunks + chunk) * kRegionRecords;
 
@@ -605,7 +613,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_dir_kernel(const T* __re
 
 template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
-                                                                   const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid) {
+                                                                   const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
+                                                                   const bool overwrite) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t kRows = rows_per_tile<T>();
     constexpr bool kFixed = sizeof(T) == 2;
@@ -692,21 +701,33 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
     if constexpr (kFixed) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kSumThreads) {
             const long long s0 = (long long)acc64[(size_t)i * 2], s1 = (long long)acc64[(size_t)i * 2 + 1];
+            half2_t* p = reinterpret_cast<half2_t*>(dst) + i;
+            if (sole && overwrite) {  // the caller's buffer is uninitialised: this work item owns the tile and writes all of it
+                *p = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
+                continue;
+            }
             if ((s0 | s1) == 0) continue;
             const half2_t v = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
-            half2_t* p = reinterpret_cast<half2_t*>(dst) + i;
             if (sole) *p = *p + v;
             else unsafeAtomicAdd(reinterpret_cast<__half2*>(p), __builtin_bit_cast(__half2, v));
         }
     } else {
         for (uint32_t i = threadIdx.x; i < nrows * 2; i += kSumThreads) {
             const float v = acc32[i];
-            if (v == 0.0f) continue;
             float* p = reinterpret_cast<float*>(dst) + i;
+            if (sole && overwrite) {
+                *p = v;
+                continue;
+            }
+            if (v == 0.0f) continue;
             if (sole) *p = *p + v;
             else unsafeAtomicAdd(p, v);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void zero_table_kernel(uint32_t* __restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
 
 // ---- host: cached copy of the level table -----------------------------------------------------------------------------
@@ -737,7 +758,7 @@ int host_offsets(const int* offsets_dev, uint32_t L, hipStream_t st, std::vector
 
 template <typename T, int D>
 int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
-                         const LevelConsts& lc, uint32_t gridtype, bool align_corners, hipStream_t st) {
+                         const LevelConsts& lc, uint32_t gridtype, bool align_corners, bool overwrite, hipStream_t st) {
     std::vector<int32_t> off;
     int rc = host_offsets(offsets_dev, L, st, off);
     if (rc != NERFTEX_OK) return rc;
@@ -788,17 +809,22 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
                 NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
                 KernelTimer kt("bin_fill_dir_kernel", st, kTimeGrid);
                 hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), dim3(kBinThreads), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype,
-                                   align_corners, dt, dir, recs, merge, nchunks);
+                                   align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr);
             }
             if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
             {
                 auto kernel = sum_tiles_dir_kernel<T>;
                 NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
                 KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-                hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid);
+                hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite);
             }
             return check_launch("grid_encode_backward(sum)");
         }
+    }
+    if (overwrite) {  // the count / scan / fill / sum pipeline adds into the table: clear it first
+        const size_t words = (size_t)off[L] * 2 * sizeof(T) / 4;
+        hipLaunchKernelGGL(zero_table_kernel, dim3((uint32_t)std::min<size_t>(div_up(words, (size_t)1024), 4096)), dim3(256), 0, st,
+                           reinterpret_cast<uint32_t*>(grad_grid), words);
     }
     const size_t n_counts = (size_t)L * nchunks * kMaxTilesPerLevel;
     const size_t max_records = (size_t)B * L * NP * 2;  // worst case: every pair straddles a tile edge
@@ -855,10 +881,10 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     return check_launch("grid_encode_backward(sum)");
 }
 
-template int grid_backward_binned<float, 2>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
-template int grid_backward_binned<float, 3>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
-template int grid_backward_binned<half_t, 2>(const half_t*, bool, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
-template int grid_backward_binned<half_t, 3>(const half_t*, bool, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, hipStream_t);
+template int grid_backward_binned<float, 2>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, bool, hipStream_t);
+template int grid_backward_binned<float, 3>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, bool, hipStream_t);
+template int grid_backward_binned<half_t, 2>(const half_t*, bool, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, bool, hipStream_t);
+template int grid_backward_binned<half_t, 3>(const half_t*, bool, const float*, const int*, half_t*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, bool, hipStream_t);
 
 }  // namespace gridenc
 }  // namespace nerftex

@@ -18,7 +18,7 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
-from nerftex_hip import F16, F32, LAYOUT_BLC, check, lib, ptr, stream, timer
+from nerftex_hip import F16, F32, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, check, lib, ptr, stream, timer
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 
@@ -94,7 +94,8 @@ class _grid_encode(Function):
         grad = grad.contiguous()  # [B, L*C], consumed as is
         if grad.dtype != embeddings.dtype:
             grad = grad.to(embeddings.dtype)
-        grad_embeddings = torch.zeros_like(embeddings)
+        # the reference zero-fills the table gradient for its atomics (grid.py:74); here the library overwrites it (clearing what it must)
+        grad_embeddings = torch.empty_like(embeddings)
         if ctx.calc_grad_inputs:
             grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
         else:
@@ -104,11 +105,11 @@ class _grid_encode(Function):
         if ctx.affine is None:
             check(lib.nerftex_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L,
                                                    S, H, int(bool(ctx.calc_grad_inputs)), ptr(dy_dx), ptr(grad_inputs), int(gridtype),
-                                                   int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC, stream()))
+                                                   int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, stream()))
         else:
             check(lib.nerftex_grid_encode_backward_affine(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C,
                                                           L, S, H, int(bool(ctx.calc_grad_inputs)), ptr(dy_dx), ptr(grad_inputs), int(gridtype),
-                                                          int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC,
+                                                          int(bool(ctx.align_corners)), _dtype_tag(embeddings), LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE,
                                                           float(ctx.affine[0]), float(ctx.affine[1]), stream()))
         timer.stop(tok)
 

@@ -14,6 +14,7 @@ from ._build import CSRC, LIB_PATH, PKG_ROOT  # noqa: F401
 
 F32, F16 = 0, 1
 LAYOUT_LBC, LAYOUT_BLC = 0, 1
+LAYOUT_GRAD_OVERWRITE = 0x100  # backward: grad_embeddings is uninitialised and gets overwritten
 
 
 from ._build import build  # noqa: E402,F401

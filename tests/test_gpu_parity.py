@@ -177,6 +177,46 @@ def test_grid_backward_large_batch_owner_path(oracle, dev, case, dtype):
         assert np.count_nonzero(got) > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("path", ["directory", "sweep", "atomic", "small"])
+def test_grid_backward_overwrites_uninitialised_table(oracle, dev, dtype, path, monkeypatch):
+    """NERFTEX_LAYOUT_GRAD_OVERWRITE: grad_embeddings arrives as garbage (NaN here) and must come back exactly as from a
+    zero-filled buffer under the reference's contract, on every internal path (single-pass binning writes every row itself,
+    the others clear the table first)."""
+    from nerftex_hip import F16, F32, LAYOUT_GRAD_OVERWRITE, check, lib, ptr, stream
+
+    n = 3000 if path == "small" else 20011
+    s = _grid_setup(oracle, GRID_CASES[0], n, 23, dtype)
+    if path == "sweep":
+        monkeypatch.setenv("NERFTEX_GRID_BWD_ALGO", "sweep")
+    if path == "atomic":
+        monkeypatch.setenv("NERFTEX_GRID_BWD", "atomic")
+    rng = np.random.default_rng(24)
+    B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
+    g = (rng.standard_normal((B, L * C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)
+    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    tag = F16 if dtype == np.float16 else F32
+    tdt = torch.float16 if dtype == np.float16 else torch.float32
+    dummy = torch.zeros(1, dtype=tdt, device=dev)
+    outs = []
+    for flag, init in ((0, 0.0), (LAYOUT_GRAD_OVERWRITE, float("nan"))):
+        ge = torch.full((s["rows"] + 64, C), init, dtype=tdt, device=dev)  # 64 guard rows past the table
+        ge[s["rows"]:] = 7.0
+        check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), B, D, C, L, s["S"], s["base"], 0, ptr(dummy),
+                                               ptr(dummy), s["gridtype"], int(s["align"]), tag, 1 | flag, stream()))
+        torch.cuda.synchronize()
+        assert torch.all(ge[s["rows"]:] == 7.0), "wrote past the table"
+        outs.append(ge[: s["rows"]].float().cpu().numpy())
+    assert np.isfinite(outs[1]).all() and np.count_nonzero(outs[1]) > 0
+    # the order of the partial sums is not fixed between two launches on most paths: equal up to that rounding
+    np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=(2e-2 if dtype == np.float16 else 2e-5) * np.abs(outs[0]).max())
+    # and an empty batch leaves a cleared table behind
+    ge = torch.full((s["rows"], C), float("nan"), dtype=tdt, device=dev)
+    check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), 0, D, C, L, s["S"], s["base"], 0, ptr(dummy),
+                                           ptr(dummy), s["gridtype"], int(s["align"]), tag, 1 | LAYOUT_GRAD_OVERWRITE, stream()))
+    assert torch.count_nonzero(ge).item() == 0
+
+
 def test_grid_input_backward_fp32_bit_exact(oracle, dev):
     from nerftex_hip import F32, check, lib, ptr, stream
 
