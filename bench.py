@@ -274,22 +274,23 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 if not split_graph:
                     body_opt()
             mem = ga.pool()
-            gb = None
+            gb, grads = None, None
             if split_graph:
-                reducer.all_reduce()
+                grads = reducer.big_grads()  # this graph's gradient tensors: A writes them, the all-reduce and B read them -- kept alive
+                reducer.all_reduce(grads=grads)
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=mem, capture_error_mode="thread_local"):
                     body_opt()
-            graphs.append((ga, gb))
+            graphs.append((ga, gb, grads))
         gstate["graphs"] = graphs
         renderer.local_step = 0
         total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
 
     def graph_step(k):
-        ga, gb = gstate["graphs"][renderer.local_step]
+        ga, gb, grads = gstate["graphs"][renderer.local_step]
         ga.replay()
         if gb is not None:
-            reducer.all_reduce()
+            reducer.all_reduce(grads=grads)
             gb.replay()
         renderer.local_step += 1
         if renderer.local_step == RING:

@@ -93,22 +93,27 @@ class FlatGradAllReduce:
             for p in self.params:
                 dist.broadcast(p.data, src)
 
-    def all_reduce(self, extra=None):
+    def big_grads(self):
+        """The gradient tensors of the big parameters as they stand (a graph capture keeps them: their addresses are baked into it)."""
+        return [p.grad for p in self.big]
+
+    def all_reduce(self, extra=None, grads=None):
         """Sum (then average) the gradients: biggest tensors first, then the flat buffer of the small ones; `extra` (e.g. a
-        loss or found-inf flag) is a further tiny all-reduce."""
+        loss or found-inf flag) is a further tiny all-reduce.  grads: the big parameters' gradient tensors to use instead of the
+        current `.grad` (replayed graphs write to the tensors that existed when they were captured)."""
         w = world_size()
         if w == 1:
             return extra
-        for p in self.big:
-            if p.grad is not None:
-                if self.big_comm_dtype is not None and p.grad.dtype != self.big_comm_dtype:
-                    wire = p.grad.to(self.big_comm_dtype)
+        for p, g in zip(self.big, grads if grads is not None else self.big_grads()):
+            if g is not None:
+                if self.big_comm_dtype is not None and g.dtype != self.big_comm_dtype:
+                    wire = g.to(self.big_comm_dtype)
                     dist.all_reduce(wire, op=dist.ReduceOp.SUM)
-                    p.grad.copy_(wire)
+                    g.copy_(wire)
                 else:
-                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
                 if self.average:
-                    p.grad.div_(w)
+                    g.div_(w)
         if self.small:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             if self.average:

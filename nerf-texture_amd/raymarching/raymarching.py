@@ -268,9 +268,13 @@ class _march_rays(Function):
         if align > 0:
             M += align - (M % align)
         dev, dt = rays_o.device, rays_o.dtype
-        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        if M % 4 == 0:  # one fill for the three zero-initialised buffers (raymarching.py:379-381), each still 16-byte aligned
+            flat = torch.zeros(M * 8, dtype=dt, device=dev)
+            xyzs, dirs, deltas = flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
+        else:
+            xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+            dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+            deltas = torch.zeros(M, 2, dtype=dt, device=dev)
         check(lib.nerftex_march_rays(int(n_alive), int(n_step), ptr(rays_alive), ptr(rays_t), ptr(rays_o), ptr(rays_d), float(bound),
                                      float(dt_gamma), int(max_steps), int(C), int(H), ptr(density_bitfield), ptr(near), ptr(far),
                                      ptr(xyzs), ptr(dirs), ptr(deltas), int(perturb), stream()))
