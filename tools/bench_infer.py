@@ -26,3 +26,12 @@ with torch.autocast("cuda", dtype=torch.float16):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
 print(json.dumps({"ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n), "iters": getattr(r, "last_iters", None)}))
+if len(sys.argv) > 2:  # per-kernel device time of one more frame (library kernels only)
+    import nerftex_hip
+    nerftex_hip.kernel_profile(1, reset=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        r.render_infer(ro, rd, dt_gamma=1 / 128)
+    torch.cuda.synchronize()
+    nerftex_hip.kernel_profile(0)
+    k = nerftex_hip.kernel_profile()
+    print(json.dumps(k))
