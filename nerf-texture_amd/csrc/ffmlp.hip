@@ -917,7 +917,8 @@ int set_lds(K kernel, size_t bytes) {
 uint32_t persistent_grid(uint32_t B, size_t lds) {
     const uint32_t blocks_needed = B / kRowsPerBlock;
     uint32_t per_cu = lds > 0 ? (uint32_t)(kLdsLimit / lds) : 8;
-    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    static const uint32_t wg_cap = getenv("NERFTEX_FFMLP_WG_PER_CU") ? (uint32_t)atoi(getenv("NERFTEX_FFMLP_WG_PER_CU")) : 4u;
+    per_cu = per_cu < 1 ? 1 : (per_cu > wg_cap ? wg_cap : per_cu);
     const uint32_t cap = (uint32_t)num_cus() * per_cu;
     return blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap;
 }
