@@ -351,7 +351,17 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         dist.all_reduce(samples, op=dist.ReduceOp.SUM)
     elapsed = float(elapsed.item())
     samples = int(samples.item())
-    res = dict(value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
+    replicas_identical = None
+    if world > 1:  # data parallelism keeps full replicas: after the run every rank must hold the same bits (cheap: one checksum vector)
+        torch.cuda.synchronize()
+        sums = torch.stack([p.detach().double().sum() for p in field.parameters()] + [p.detach().double().abs().sum() for p in field.parameters()])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+        if not replicas_identical:
+            print(f"[bench] rank {rank}: parameter replicas differ across ranks after training", file=sys.stderr)
+    res = dict(replicas_identical=replicas_identical, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt,
                graph=("two replayed HIP graphs per step (forward+backward | optimizer), eager all-reduce between" if split_graph else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
@@ -474,6 +484,7 @@ def main():
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
                 "optimizer": ("Adam(eps=1e-15) + GradScaler rules, as HIP kernels on the fp16 gradients (fp32 masters + fp16 copies; bit-identical to torch fused Adam)"
                               if res.get("fused_opt") else "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)"),
+                "replicas_identical_after_run": res.get("replicas_identical"),
                 "launch": res["graph"] if res["graph"] else "eager launches",
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
             },

@@ -21,6 +21,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test rig for boxes with ONE GPU: NERFTEX_DP_SHARE_GPU=1 puts every rank on cuda:0 and exchanges through gloo (RCCL refuses
+    # two ranks on one device), so the multi-process step -- two graphs per step, eager all-reduce of fp16 gradients, mean_count
+    # agreement -- runs end to end; not a performance configuration
+    if os.environ.get("NERFTEX_DP_SHARE_GPU") == "1":
+        local, backend = 0, "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
