@@ -197,13 +197,18 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=use_amp)
     one = torch.ones((), dtype=torch.float32, device=dev)  # root gradient, so that autograd does not fill one per step
 
-    def forward_backward(ro, rd, tgt, **kw):
+    def march(ro, rd, **kw):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+            return renderer.march_train(ro, rd, dt_gamma=dt_gamma, perturb=True, max_steps=1024, **kw)
+
+    def forward_backward(ro, rd, tgt, marched=None, **kw):
+        """One training render + loss + backward; marched = (sample tensors, counter) of an earlier `march` of the same rays, or None."""
+        marched, counter = march(ro, rd, **kw) if marched is None else marched
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
             if fused_tail:
-                image, depth, loss, scaled, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024,
-                                                                            target=tgt, loss_mul=inv_world, scale=amp.scale if amp else None, **kw)
+                image, depth, loss, scaled = renderer.shade_train(marched, 1, target=tgt, loss_mul=inv_world, scale=amp.scale if amp else None)
             else:
-                image, depth, counter = renderer.render_train(ro, rd, dt_gamma=dt_gamma, bg_color=1, perturb=True, max_steps=1024, **kw)
+                image, depth = renderer.shade_train(marched, 1)
                 scaled = torch.nn.functional.mse_loss(image, tgt)
                 if world > 1:
                     scaled = scaled * inv_world
@@ -242,13 +247,15 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # step-counter ring, each with its ray batch and its counter slot baked in; the sample buffers are sized by a fixed count (the
     # ring's mean rounded up to 4096 + 4096); all graphs share one memory pool (they never run concurrently).
     RING = 16  # = the renderer's step-counter ring: graph g is step g of a 16-step cycle
-    gstate = {"graphs": None, "M": 0}
+    gstate = {"graphs": None, "M": 0, "marched": -1}
 
-    def body_fb(g):
-        ro, rd = pool[g % n_pool]
-        reducer.zero_grad()
+    def body_march(g):
         renderer.local_step = g  # the step's counter is ring slot g, exactly as in the eager loop
-        counter = forward_backward(ro, rd, gt[g % n_pool], mean_count=gstate["M"])
+        return march(*pool[g % n_pool], mean_count=gstate["M"])
+
+    def body_fb(g, marched=None):
+        reducer.zero_grad()
+        counter = forward_backward(*pool[g % n_pool], gt[g % n_pool], marched=body_march(g) if marched is None else marched)
         total_samples.add_(counter[0])
 
     def body_opt():
@@ -265,34 +272,52 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 reducer.all_reduce()
                 body_opt()
         torch.cuda.current_stream().wait_stream(side)
-        graphs, mem = [], None
+        graphs, mem, marches = [], None, [None] * RING
+        # thread_local: only this thread's calls can invalidate a capture (an RCCL watchdog thread may query events meanwhile)
+        if split_graph:  # N > 1: the march of a step is its own graph, replayed while the PREVIOUS step's gradients are on the wire
+            for g in range(RING):
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm, pool=mem, capture_error_mode="thread_local"):
+                    out = body_march(g)
+                mem = gm.pool()
+                marches[g] = (gm, out)  # the sample tensors stay alive: graph A of the slot reads them
         for g in range(RING):  # one graph per ring slot: static ray batch, static counter slot -> nothing to select or copy per step
-            # thread_local: only this thread's calls can invalidate the capture (an RCCL watchdog thread may query events meanwhile)
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
-                body_fb(g)
+                body_fb(g, marches[g][1] if split_graph else None)
                 if not split_graph:
                     body_opt()
             mem = ga.pool()
-            gb, grads = None, None
+            gm, gb, grads = None, None, None
             if split_graph:
+                gm = marches[g][0]
                 grads = reducer.big_grads()  # this graph's gradient tensors: A writes them, the all-reduce and B read them -- kept alive
                 reducer.all_reduce(grads=grads)
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=mem, capture_error_mode="thread_local"):
                     body_opt()
-            graphs.append((ga, gb, grads))
+            graphs.append((gm, ga, gb, grads))
         gstate["graphs"] = graphs
+        gstate["marched"] = -1
         renderer.local_step = 0
         total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
 
     def graph_step(k):
-        ga, gb, grads = gstate["graphs"][renderer.local_step]
-        ga.replay()
-        if gb is not None:
-            reducer.all_reduce(grads=grads)
+        g = renderer.local_step
+        gm, ga, gb, grads = gstate["graphs"][g]
+        if gb is None:
+            ga.replay()
+        else:  # march(g) | shade + backward(g) | all-reduce(g) overlapped with march(g + 1) | optimizer(g)
+            if gstate["marched"] != g:
+                gm.replay()
+            ga.replay()
+            handle = reducer.all_reduce_start(grads)
+            if g + 1 < RING:  # not across the ring's end: the mean_count read-back (and a possible re-capture) comes first there
+                gstate["graphs"][g + 1][0].replay()
+                gstate["marched"] = g + 1
+            reducer.all_reduce_finish(handle)
             gb.replay()
-        renderer.local_step += 1
+        renderer.local_step = g + 1
         if renderer.local_step == RING:
             renderer.update_mean_count()
             renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
@@ -363,7 +388,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             print(f"[bench] rank {rank}: parameter replicas differ across ranks after training", file=sys.stderr)
     res = dict(replicas_identical=replicas_identical, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt,
-               graph=("two replayed HIP graphs per step (forward+backward | optimizer), eager all-reduce between" if split_graph else
+               graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
 

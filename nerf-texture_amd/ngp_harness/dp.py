@@ -102,27 +102,49 @@ class FlatGradAllReduce:
         """The gradient tensors of the big parameters as they stand (a graph capture keeps them: their addresses are baked into it)."""
         return [p.grad for p in self.big]
 
+    def all_reduce_start(self, grads=None):
+        """Launch the gradient exchange without waiting for it (the collectives run on the backend's own stream / thread): whatever
+        the caller enqueues next on the current stream overlaps with it.  Returns a handle for `all_reduce_finish`."""
+        if world_size() == 1:
+            return None
+        works, post = [], []
+        for p, g in zip(self.big, grads if grads is not None else self.big_grads()):
+            if g is None:
+                continue
+            if self.big_comm_dtype is not None and g.dtype != self.big_comm_dtype:
+                wire = g.to(self.big_comm_dtype)
+                works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True))
+                post.append((g, wire))
+            else:
+                works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+                post.append((g, None))
+        if self.small:
+            works.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True))
+        return works, post
+
+    def all_reduce_finish(self, handle):
+        """Make the current stream wait for the exchange started by `all_reduce_start`, then the local epilogue (widen / average)."""
+        if handle is None:
+            return
+        works, post = handle
+        for wk in works:
+            wk.wait()
+        w = world_size()
+        for g, wire in post:
+            if wire is not None:
+                g.copy_(wire)
+            if self.average:
+                g.div_(w)
+        if self.small and self.average:
+            self.flat.div_(w)
+
     def all_reduce(self, extra=None, grads=None):
         """Sum (then average) the gradients: biggest tensors first, then the flat buffer of the small ones; `extra` (e.g. a
         loss or found-inf flag) is a further tiny all-reduce.  grads: the big parameters' gradient tensors to use instead of the
         current `.grad` (replayed graphs write to the tensors that existed when they were captured)."""
-        w = world_size()
-        if w == 1:
+        if world_size() == 1:
             return extra
-        for p, g in zip(self.big, grads if grads is not None else self.big_grads()):
-            if g is not None:
-                if self.big_comm_dtype is not None and g.dtype != self.big_comm_dtype:
-                    wire = g.to(self.big_comm_dtype)
-                    dist.all_reduce(wire, op=dist.ReduceOp.SUM)
-                    g.copy_(wire)
-                else:
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
-                if self.average:
-                    g.div_(w)
-        if self.small:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if self.average:
-                self.flat.div_(w)
+        self.all_reduce_finish(self.all_reduce_start(grads))
         if extra is not None:
             dist.all_reduce(extra, op=dist.ReduceOp.SUM)
         return extra
