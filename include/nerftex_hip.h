@@ -309,6 +309,14 @@ int nerftex_adam_half_step(int count, float* const* params, float* const* exp_av
  * else tracker += 1, at growth_interval scale *= growth_factor (if finite) and tracker = 0, and *step += 1 (step may be
  * NULL); found_inf is cleared for the next step.                                                                   */
 int nerftex_amp_check_half(int count, const void* const* grads_half, const uint64_t* n, float* found_inf, void* stream);
+/* nerftex_adam_half_step (step number *step + 1, gradients divided by *scale, skipped when *found_inf == 1) followed, in the same
+ * launch, by nerftex_amp_update on the same scale / found_inf / step words: the block that finishes last does it (ticket: one
+ * uint32 that is 0 on entry and left 0).                                                                                  */
+int nerftex_adam_half_step_amp(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                               const void* const* grads_half, void* const* params_half, const uint64_t* n, float* step,
+                               double lr, double beta1, double beta2, double eps, float* scale, int32_t* growth_tracker,
+                               float* found_inf, uint32_t* ticket, double growth_factor, double backoff_factor,
+                               int growth_interval, void* stream);
 int nerftex_amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, double growth_factor,
                        double backoff_factor, int growth_interval, void* stream);
 

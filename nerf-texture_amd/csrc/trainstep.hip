@@ -134,11 +134,44 @@ struct AdamTensors {
     int count;
 };
 
+// amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count
+__device__ __forceinline__ void amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
+                                           const double backoff_factor, const int growth_interval) {
+    if (*found_inf != 0.0f) {
+        *scale = (float)((double)*scale * backoff_factor);
+        *growth_tracker = 0;
+    } else {
+        const int successful = *growth_tracker + 1;
+        if (successful == growth_interval) {
+            const float grown = (float)((double)*scale * growth_factor);
+            if (isfinite(grown)) *scale = grown;
+            *growth_tracker = 0;
+        } else {
+            *growth_tracker = successful;
+        }
+        if (step) *step += 1.0f;
+    }
+    *found_inf = 0.0f;
+}
+
+// optional tail of the Adam launch: the loss scaler's update, done by whichever block finishes last (ticket) -- every block has read
+// scale / found_inf / step by then, so the three words can be rewritten in place; scale == nullptr: no tail
+struct AmpTail {
+    float* scale;
+    int32_t* growth_tracker;
+    float* found_inf;
+    float* step;
+    uint32_t* ticket;  // zero on entry, left zero
+    double growth_factor, backoff_factor;
+    int growth_interval;
+};
+
 // up to 8 tensors per launch (the table and the MLP weight vectors): a block finds its tensor, then grid-strides inside it
-__global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTensors tens, const float* __restrict__ step, const float step_offset,
-                                                                 const AdamConsts k, const float* __restrict__ grad_scale,
-                                                                 const float* __restrict__ found_inf) {
-    if (found_inf && *found_inf == 1.0f) return;  // GradScaler: skip the step, every buffer stays as it is
+__global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTensors tens, const float* step, const float step_offset,
+                                                                 const AdamConsts k, const float* grad_scale, const float* found_inf,
+                                                                 const AmpTail tail) {
+    const bool skip = found_inf && *found_inf == 1.0f;  // GradScaler: skip the step, every buffer stays as it is
+    if (!skip) {
     int t = 0;
     while (t + 1 < tens.count && blockIdx.x >= tens.block_end[t]) t++;
     const uint32_t first = t ? tens.block_end[t - 1] : 0u;
@@ -185,14 +218,27 @@ __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTenso
         reinterpret_cast<half8_t*>(param_half)[i] = h;
     }
     // ragged end (n not a multiple of 8): the tensor's first block, first lanes
-    const uint64_t tail = groups * kAdamVec + threadIdx.x;
-    if (block == 0 && tail < n) {
-        float p = param[tail], m = exp_avg[tail], v = exp_avg_sq[tail];
-        adam_one(p, m, v, (float)grad[tail], k, unscale, scale, step_size, bc2_sqrt);
-        param[tail] = p;
-        exp_avg[tail] = m;
-        exp_avg_sq[tail] = v;
-        param_half[tail] = (half_t)p;
+    const uint64_t rest = groups * kAdamVec + threadIdx.x;
+    if (block == 0 && rest < n) {
+        float p = param[rest], m = exp_avg[rest], v = exp_avg_sq[rest];
+        adam_one(p, m, v, (float)grad[rest], k, unscale, scale, step_size, bc2_sqrt);
+        param[rest] = p;
+        exp_avg[rest] = m;
+        exp_avg_sq[rest] = v;
+        param_half[rest] = (half_t)p;
+    }
+    }
+    if (tail.scale != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // no fence: the last block consumes nothing the others wrote -- it only needs them to be past their reads of the three words,
+            // which the ticket (a device-scope atomic, performed memory-side) says.  A device-scope release here would have every one
+            // of the 2048 blocks write its XCD's L2 back: measured +125 us on a 60 us kernel
+            if (atomicAdd(tail.ticket, 1u) == gridDim.x - 1) {
+                amp_update(tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor, tail.backoff_factor, tail.growth_interval);
+                *tail.ticket = 0u;
+            }
+        }
     }
 }
 
@@ -226,24 +272,9 @@ __global__ __launch_bounds__(256) void amp_check_half_kernel(const CheckTensors 
     if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
 }
 
-// amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count
 __global__ void amp_update_kernel(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
                                   const double backoff_factor, const int growth_interval) {
-    if (*found_inf != 0.0f) {
-        *scale = (float)((double)*scale * backoff_factor);
-        *growth_tracker = 0;
-    } else {
-        const int successful = *growth_tracker + 1;
-        if (successful == growth_interval) {
-            const float grown = (float)((double)*scale * growth_factor);
-            if (isfinite(grown)) *scale = grown;
-            *growth_tracker = 0;
-        } else {
-            *growth_tracker = successful;
-        }
-        if (step) *step += 1.0f;
-    }
-    *found_inf = 0.0f;
+    amp_update(scale, growth_tracker, found_inf, step, growth_factor, backoff_factor, growth_interval);
 }
 
 }  // namespace
@@ -290,10 +321,39 @@ uint32_t blocks_for(uint64_t units, uint32_t per_block) {
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 }  // namespace
 
+namespace {
+int adam_half_launch(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, const void* const* grads_half,
+                     void* const* params_half, const uint64_t* n, const float* step, float step_offset, double lr, double beta1, double beta2,
+                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream);
+}  // namespace
+
 extern "C" int nerftex_adam_half_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
                                       const void* const* grads_half, void* const* params_half, const uint64_t* n, const float* step,
                                       float step_offset, double lr, double beta1, double beta2, double eps, const float* grad_scale,
                                       const float* found_inf, void* stream) {
+    return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads_half, params_half, n, step, step_offset, lr, beta1, beta2, eps, grad_scale,
+                            found_inf, AmpTail{}, stream);
+}
+
+extern "C" int nerftex_adam_half_step_amp(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                          const void* const* grads_half, void* const* params_half, const uint64_t* n, float* step,
+                                          double lr, double beta1, double beta2, double eps, float* scale, int32_t* growth_tracker,
+                                          float* found_inf, uint32_t* ticket, double growth_factor, double backoff_factor,
+                                          int growth_interval, void* stream) {
+    if (!scale || !growth_tracker || !found_inf || !step || !ticket) {
+        clear_error();
+        set_error("adam_half_step_amp: scale, growth_tracker, found_inf, step and ticket must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval};
+    return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads_half, params_half, n, step, 1.0f, lr, beta1, beta2, eps, scale, found_inf,
+                            tail, stream);
+}
+
+namespace {
+int adam_half_launch(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, const void* const* grads_half,
+                     void* const* params_half, const uint64_t* n, const float* step, float step_offset, double lr, double beta1, double beta2,
+                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream) {
     clear_error();
     if (count < 0 || count > kMaxTensors) {
         set_error("adam_half_step: at most 8 tensors per call");
@@ -317,15 +377,23 @@ extern "C" int nerftex_adam_half_step(int count, float* const* params, float* co
         blocks += blocks_for(n[t] / kAdamVec, kAdamThreads);
         tens.block_end[k] = blocks;
     }
-    if (tens.count == 0) return NERFTEX_OK;
     hipStream_t st = as_stream(stream);
+    if (tens.count == 0) {  // nothing to update: the scaler's bookkeeping still happens
+        if (tail.scale) {
+            hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, st, tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor,
+                               tail.backoff_factor, tail.growth_interval);
+            return check_launch("adam_half_step(amp)");
+        }
+        return NERFTEX_OK;
+    }
     const AdamConsts k{lr, beta1, beta2, eps};
     {
         KernelTimer kt("adam_half_kernel", st);
-        hipLaunchKernelGGL(adam_half_kernel, dim3(blocks), dim3(kAdamThreads), 0, st, tens, step, step_offset, k, grad_scale, found_inf);
+        hipLaunchKernelGGL(adam_half_kernel, dim3(blocks), dim3(kAdamThreads), 0, st, tens, step, step_offset, k, grad_scale, found_inf, tail);
     }
     return check_launch("adam_half_step");
 }
+}  // namespace
 
 extern "C" int nerftex_table_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const void* grad_half, void* param_half, uint64_t n,
                                        const float* step, double lr, double beta1, double beta2, double eps, const float* grad_scale,

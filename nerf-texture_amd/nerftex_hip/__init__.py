@@ -33,6 +33,7 @@ _SIGNATURES = {
     "nerftex_render_tail_backward": [_vp, _vp, _f32, _vp, _vp, _f32, _u32, _vp, _vp, _vp],
     "nerftex_adam_half_step": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "nerftex_amp_check_half": [_i, _vp, _vp, _vp, _vp],
+    "nerftex_adam_half_step_amp": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
     "nerftex_amp_update": [_vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
     "nerftex_table_adam_step": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "nerftex_profile_enable": [_i],

@@ -10,8 +10,8 @@ tests/test_gpu_trainstep.py) but makes the fp16 copy of every parameter the auto
 gradient lands in its `.grad` as is, and one launch updates the fp32 masters + moments and rewrites the fp16 leaves (28 B per
 parameter).  It is a `torch.optim.Optimizer` a GradScaler can drive (`_step_supports_amp_scaling`, like `Adam(fused=True)`).
 
-`FusedAmp` is GradScaler's device side (non-finite check, skip, scale back-off / growth: same constants, same formulas) as three
-launches per step: check, Adam, update.
+`FusedAmp` is GradScaler's device side (non-finite check, skip, scale back-off / growth: same constants, same formulas) as two
+launches per step: the non-finite check, then Adam with the scale update done by its last block.
 """
 import ctypes
 
@@ -48,20 +48,27 @@ class HalfLeafAdam(torch.optim.Optimizer):
         """The tensors whose `.grad` the backward pass fills (what a gradient all-reduce has to cover)."""
         return list(self.leaves)
 
-    def _launch(self, step_offset, grad_scale, found_inf):
+    def _launch(self, step_offset, grad_scale, found_inf, amp=None):
+        """One launch over every leaf that has a gradient.  amp = (scale, growth_tracker, found_inf, ticket, growth, backoff, interval):
+        the loss scaler's update rides along (step number *step_count + 1; the launch advances step_count itself)."""
         idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None]
-        if not idx:
+        if not idx and amp is None:
             return
         grads = [self.leaves[i].grad for i in idx]
         for i, g in zip(idx, grads):
             assert g.dtype == torch.half and g.is_contiguous() and g.shape == self.masters[i].shape
         grp = self.param_groups[0]
-        n = (ctypes.c_uint64 * len(idx))(*[self.masters[i].numel() for i in idx])
-        check(lib.nerftex_adam_half_step(len(idx), _ptr_array([self.masters[i] for i in idx]), _ptr_array([self.exp_avg[i] for i in idx]),
-                                         _ptr_array([self.exp_avg_sq[i] for i in idx]), _ptr_array(grads),
-                                         _ptr_array([self.leaves[i] for i in idx]), n, ptr(self.step_count), float(step_offset),
-                                         float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], ptr(grad_scale), ptr(found_inf),
-                                         stream()))
+        n = (ctypes.c_uint64 * max(len(idx), 1))(*[self.masters[i].numel() for i in idx])
+        arrays = (_ptr_array([self.masters[i] for i in idx]), _ptr_array([self.exp_avg[i] for i in idx]),
+                  _ptr_array([self.exp_avg_sq[i] for i in idx]), _ptr_array(grads), _ptr_array([self.leaves[i] for i in idx]), n)
+        hyper = (float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"])
+        if amp is None:
+            check(lib.nerftex_adam_half_step(len(idx), *arrays, ptr(self.step_count), float(step_offset), *hyper, ptr(grad_scale), ptr(found_inf),
+                                             stream()))
+        else:
+            scale, tracker, found, ticket, growth, backoff, interval = amp
+            check(lib.nerftex_adam_half_step_amp(len(idx), *arrays, ptr(self.step_count), *hyper, ptr(scale), ptr(tracker), ptr(found), ptr(ticket),
+                                                 growth, backoff, interval, stream()))
         for i in idx:
             torch.autograd.graph.increment_version(self.masters[i])
 
@@ -93,6 +100,7 @@ class FusedAmp:
         self.scale = torch.full((), float(init_scale), dtype=torch.float32, device=dev)
         self.growth_tracker = torch.zeros((), dtype=torch.int32, device=dev)
         self.found_inf = torch.zeros((), dtype=torch.float32, device=dev)
+        self.ticket = torch.zeros((), dtype=torch.int32, device=dev)  # "last block to finish" counter of the Adam launch, self-resetting
         self.consts = (float(growth_factor), float(backoff_factor), int(growth_interval))
 
     def scale_loss(self, loss):
@@ -107,6 +115,5 @@ class FusedAmp:
         if grads:
             n = (ctypes.c_uint64 * len(grads))(*[g.numel() for g in grads])
             check(lib.nerftex_amp_check_half(len(grads), _ptr_array(grads), n, ptr(self.found_inf), stream()))
-        self.opt._launch(1.0, self.scale, self.found_inf)
-        g, b, i = self.consts
-        check(lib.nerftex_amp_update(ptr(self.scale), ptr(self.growth_tracker), ptr(self.found_inf), ptr(self.opt.step_count), g, b, i, stream()))
+        # Adam (skipped on overflow) and the scale / step-counter update in one launch
+        self.opt._launch(1.0, self.scale, self.found_inf, (self.scale, self.growth_tracker, self.found_inf, self.ticket, *self.consts))
