@@ -667,9 +667,11 @@ def test_render_train_without_autocast(dev, scene_data):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 2, False, "hash"), (3, 2, True, "hash"), (2, 4, False, "tiled"), (3, 8, True, "hash"), (3, 1, False, "hash")],
+                         ids=lambda v: f"D{v[0]}C{v[1]}{'a' if v[2] else ''}{v[3]}")
 @pytest.mark.parametrize("bound", [1, 2.0, 1.5])
 @pytest.mark.parametrize("B", [4096, 70000])  # per-point kernels / level-pinned forward + binned backward
-def test_grid_folded_normalisation_matches_framework_ops(bound, B):
+def test_grid_folded_normalisation_matches_framework_ops(bound, B, shape):
     """GridEncoder.forward folds (x + bound) / (2 bound) into the kernels' coordinate load; the reference runs it as two framework ops
     in front of the kernel (gridencoder/grid.py:141).  Same roundings -> identical features, table gradients and input gradients."""
     import torch
@@ -679,12 +681,14 @@ def test_grid_folded_normalisation_matches_framework_ops(bound, B):
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
-    enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).to(dev)
+    D, C, align, gridtype = shape
+    enc = GridEncoder(input_dim=D, num_levels=8, level_dim=C, base_resolution=16, log2_hashmap_size=15, desired_resolution=512, gridtype=gridtype,
+                      align_corners=align).to(dev)
     enc.embeddings.data.uniform_(-1.0, 1.0)
-    x = (torch.rand(B, 3, device=dev) * 2 - 1) * bound
-    x[:7] = torch.tensor([bound, -bound, 0.0], device=dev)  # the faces of the box
+    x = (torch.rand(B, D, device=dev) * 2 - 1) * bound
+    x[:7] = torch.tensor([bound, -bound, 0.0][:D], device=dev)  # the faces of the box
     x[7:9] *= 1.001  # just outside: zero features either way
-    g = torch.randn(B, 16, device=dev)
+    g = torch.randn(B, 8 * C, device=dev)
     res = []
     for fold in (False, True):
         enc.fold_normalisation = fold
@@ -699,7 +703,7 @@ def test_grid_folded_normalisation_matches_framework_ops(bound, B):
     assert torch.equal(gx0, gx1)
     # table gradient: fp16 sums whose order of partial sums is not fixed in either configuration (per-sample atomics below 16 k points,
     # several partial tiles per LDS tile above): equal up to that rounding noise
-    torch.testing.assert_close(ge0.float(), ge1.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(ge0.float(), ge1.float(), rtol=2e-2, atol=2e-2 * max(1.0, ge0.float().abs().max().item()))
 
 
 @pytest.mark.gpu
