@@ -37,8 +37,12 @@ def _worker(rank, world, port, q, comm_dtype=None):
         loss.backward()
         assert model[2].weight.grad.data_ptr() == red.flat.data_ptr(), "a small .grad must stay a view of the flat buffer"
         assert model[0].weight.grad is not None and model[0].weight.grad.data_ptr() != red.flat.data_ptr()
-        if _ % 2:  # the replayed-graph form: the caller names the gradient tensors (same objects here)
+        if _ == 1:  # the replayed-graph form: the caller names the gradient tensors (same objects here)
             red.all_reduce(grads=red.big_grads())
+        elif _ == 2:  # the overlapped form: start, do unrelated work, finish
+            handle = red.all_reduce_start(red.big_grads())
+            _unrelated = torch.randn(64, 64) @ torch.randn(64, 64)
+            red.all_reduce_finish(handle)
         else:
             red.all_reduce()
         opt.step()
