@@ -49,6 +49,14 @@ const char* nerftex_last_error(void);
 /* library / build identification: "nerftex_hip <ver> gfx950" */
 const char* nerftex_version(void);
 
+/* Tuning knobs / A-B switches of the kernels (profiling aid; the defaults are what is measured and shipped).  The library
+ * reads its environment ONCE when it is loaded (NERFTEX_TUNE="name=value,..."), a launch never calls getenv().  Names:
+ * grid_fwd, grid_bwd, grid_bwd_sweep, grid_bwd_items, grid_bwd_slice, grid_bwd_nomerge, grid_bwd_fill, grid_bwd_sum,
+ * grid_bwd_probe, march, march_serial, ffmlp_wg_per_cu, ffmlp_bwd_split (csrc/common.hpp documents the values).
+ * tune_set: NERFTEX_ERR_INVALID for an unknown name; tune_get: -1 for an unknown name.                                    */
+int nerftex_tune_set(const char* name, long value);
+long nerftex_tune_get(const char* name);
+
 /* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every kernel the
  * library launches).  on = 0 off (default), 1 every kernel, 2 hash-grid kernels only; bench.py uses 2 over its timed
  * region to report the roofline kernel's average launch duration.  report() synchronises the device and writes a JSON object

@@ -51,6 +51,28 @@ inline int device_cus() {
     return cus;
 }
 
+// ---- tuning knobs (runtime.hip) ----------------------------------------------------------------------------------------
+// A/B switches and tuning parameters of the kernels.  Read ONCE when the library is loaded (NERFTEX_TUNE="name=value,..." plus
+// the older one-variable-per-switch names), changed afterwards only through nerftex_tune_set(); a launch reads a plain array.
+enum Knob {
+    kKnobGridFwd,        // 0 auto, 1 thread-per-sample kernel, 2 level-per-XCD kernel
+    kKnobGridBwd,        // 0 auto, 1 per-sample atomics, 2 tile owners (binned / sweep)
+    kKnobGridBwdSweep,   // 1: the tile-owner sweep instead of binning
+    kKnobGridBwdItems,   // sweep: work items per level (0 = auto)
+    kKnobGridBwdSlice,   // binning: records per K4 work item (0 = default)
+    kKnobGridBwdNoMerge, // binning: 1 = do not merge runs of samples that share a cell
+    kKnobGridBwdFill,    // binning K3: samples per thread (0 = default)
+    kKnobGridBwdSum,     // binning K4: 0 = default, 1 = per-wave run tables (round-1 kernel)
+    kKnobGridBwdProbe,   // phase ablation of K3 / K4 for profiling (0 = off; results are garbage when set)
+    kKnobMarch,          // 0 auto, 1 replay, 2 log
+    kKnobMarchSerial,    // 1: one-ray-per-lane DDA for the counting pass
+    kKnobFfmlpWgPerCu,   // forward: workgroups per CU (0 = default)
+    kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
+    kKnobCount
+};
+extern long g_knobs[kKnobCount];
+inline long knob(Knob k) { return g_knobs[k]; }
+
 // ---- optional per-kernel timing (runtime.hip): { KernelTimer t("name", stream); hipLaunchKernelGGL(...); } --------------
 extern int g_profile_mode;                   // 0 off, 1 every kernel, 2 hash-grid kernels only
 constexpr int kTimeAny = 1, kTimeGrid = 2;  // timer groups

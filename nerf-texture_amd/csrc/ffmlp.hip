@@ -917,7 +917,7 @@ int set_lds(K kernel, size_t bytes) {
 uint32_t persistent_grid(uint32_t B, size_t lds) {
     const uint32_t blocks_needed = B / kRowsPerBlock;
     uint32_t per_cu = lds > 0 ? (uint32_t)(kLdsLimit / lds) : 8;
-    static const uint32_t wg_cap = getenv("NERFTEX_FFMLP_WG_PER_CU") ? (uint32_t)atoi(getenv("NERFTEX_FFMLP_WG_PER_CU")) : 4u;
+    const uint32_t wg_cap = knob(kKnobFfmlpWgPerCu) > 0 ? (uint32_t)knob(kKnobFfmlpWgPerCu) : 4u;
     per_cu = per_cu < 1 ? 1 : (per_cu > wg_cap ? wg_cap : per_cu);
     const uint32_t cap = (uint32_t)num_cus() * per_cu;
     return blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap;
@@ -1078,8 +1078,7 @@ extern "C" int nerftex_ffmlp_backward(const void* grad, const void* inputs, cons
     const uint32_t n_params = H * (IN + H * (NL - 1) + 16);
 
     {   // fused activation + weight gradients (the default where instantiated): backward_buffer stays untouched
-        const char* mode = getenv("NERFTEX_FFMLP_BWD");  // "split" = dgrad kernel, then wgrad kernel through backward_buffer
-        if (!(mode && mode[0] == 's')) {
+        if (!knob(kKnobFfmlpBwdSplit)) {  // ffmlp_bwd_split = 1: dgrad kernel, then wgrad kernel through backward_buffer
             rc = launch_backward_fused(grad, inputs, weights, forward_buffer, gi, B, IN, H, NL, activation, n_params, grad_weights, st);
             if (rc >= 0) return rc;  // rc < 0: shape not instantiated -> split path below
         }

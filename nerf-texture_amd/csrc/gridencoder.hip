@@ -761,8 +761,8 @@ int launch_forward(const float* inputs, const T* emb, const int* offsets, T* out
                    const LevelConsts& lc, bool calc_grad, T* dy_dx, uint32_t gridtype, bool align, int layout,
                    hipStream_t st) {
     if (B == 0) return NERFTEX_OK;
-    const char* force = getenv("NERFTEX_GRID_FWD");  // "point" | "level": A/B switch for profiling
-    const bool by_level = force ? (force[0] == 'l') : (B >= kLevelFwdMinBatch);
+    const long force = knob(kKnobGridFwd);  // 1 point | 2 level: A/B switch for profiling
+    const bool by_level = force ? force == 2 : (B >= kLevelFwdMinBatch);
     if (by_level) {
         T* lbc = outputs;
         if (layout == NERFTEX_LAYOUT_BLC) {
@@ -817,13 +817,12 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
     const uint32_t nchunks = div_up(B, 256u);
     const dim3 grid(kXcds * nchunks * div_up(L, kXcds)), block(256);
     const bool blc = layout == NERFTEX_LAYOUT_BLC;
-    const char* force = getenv("NERFTEX_GRID_BWD");  // "atomic" | "owner": A/B switch for profiling
-    bool owner = C == 2 && (force ? (force[0] == 'o') : (B >= kOwnerMinBatch));
+    const long force = knob(kKnobGridBwd);  // 1 atomic | 2 owner: A/B switch for profiling
+    bool owner = C == 2 && (force ? force == 2 : (B >= kOwnerMinBatch));
     int rc = NERFTEX_OK;
     if constexpr (C == 2) {
         if (owner) {  // every level through the LDS tile owners, no per-sample global atomics at all
-            const char* algo = getenv("NERFTEX_GRID_BWD_ALGO");  // "sweep" keeps the tile-owner sweep; default = binning
-            if (!(algo && algo[0] == 's')) {
+            if (!knob(kKnobGridBwdSweep)) {  // grid_bwd_sweep = 1 keeps the tile-owner sweep; default = binning
                 rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, overwrite, st);
                 if (rc == NERFTEX_OK) goto table_done;
                 if (rc > 0) return rc;  // rc < 0: shape outside the binned path's limits -> sweep below
@@ -845,8 +844,7 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
             NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnerLdsBytes),
                             "hipFuncSetAttribute");
             const uint32_t cus = (uint32_t)device_cus();
-            const char* ip = getenv("NERFTEX_GRID_BWD_ITEMS");
-            const uint32_t items_per_level = ip ? (uint32_t)atoi(ip) : div_up(6u * cus, L);
+            const uint32_t items_per_level = knob(kKnobGridBwdItems) > 0 ? (uint32_t)knob(kKnobGridBwdItems) : div_up(6u * cus, L);
             {
                 KernelTimer kt("grid_backward_owner_kernel", st, kTimeGrid);
                 hipLaunchKernelGGL(kernel, dim3(cus), dim3(kOwnerThreads), kOwnerLdsBytes, st, g, inputs, offsets, grad_emb, B, L, lc, gridtype, align,

@@ -1034,15 +1034,14 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     // scratch: [0] base, [1..nblocks] workgroup totals, then (optionally) the per-ray log of accepted t's [N, max_steps]
     const size_t head = (sizeof(uint32_t) * (1 + (size_t)nblocks) + 255) / 256 * 256;
     const size_t log_bytes = sizeof(float) * (size_t)N * max_steps;
-    const char* force = getenv("NERFTEX_MARCH");  // "replay" | "log": A/B switch for profiling
-    const bool use_log = force ? (force[0] == 'l') : (log_bytes <= ((size_t)1 << 30));
+    const long force = knob(kKnobMarch);  // 1 replay | 2 log: A/B switch for profiling
+    const bool use_log = force ? force == 2 : (log_bytes <= ((size_t)1 << 30));
     char* base = static_cast<char*>(workspace(kWsMarch, head + (use_log ? log_bytes : 0)));
     if (!base) return NERFTEX_ERR_HIP;
     uint32_t* ws = reinterpret_cast<uint32_t*>(base);
     float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
     hipStream_t st = as_stream(stream);
-    const char* serial = getenv("NERFTEX_MARCH_COUNT");  // "serial": the one-ray-per-lane DDA (A/B switch)
-    if (use_log && H <= 256 && !(serial && serial[0] == 's')) {  // (the packed voxel of the parallel pass holds 8-bit coordinates)
+    if (use_log && H <= 256 && !knob(kKnobMarchSerial)) {  // march_serial = 1: the one-ray-per-lane DDA (A/B switch)  // (the packed voxel of the parallel pass holds 8-bit coordinates)
         {   // a kernel, not hipMemsetAsync: the memset node did not re-zero the buffer when the launch sequence is replayed from a
             // captured HIP graph (ROCm 7.2; the block sums then accumulate garbage on the second replay)
             KernelTimer kt("zero_words_kernel", st);

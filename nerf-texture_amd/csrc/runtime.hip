@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include "workspace.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -20,6 +21,45 @@ void set_error(const char* fmt, ...) {
 }
 
 void clear_error() { g_err[0] = 0; }
+
+// ---- tuning knobs -------------------------------------------------------------------------------
+long g_knobs[kKnobCount] = {0};
+namespace {
+const char* const kKnobNames[kKnobCount] = {"grid_fwd", "grid_bwd", "grid_bwd_sweep", "grid_bwd_items", "grid_bwd_slice", "grid_bwd_nomerge",
+                                            "grid_bwd_fill", "grid_bwd_sum", "grid_bwd_probe", "march", "march_serial", "ffmlp_wg_per_cu",
+                                            "ffmlp_bwd_split"};
+int knob_index(const char* name, size_t n) {
+    for (int k = 0; k < kKnobCount; k++)
+        if (strlen(kKnobNames[k]) == n && strncmp(kKnobNames[k], name, n) == 0) return k;
+    return -1;
+}
+// environment, read once at load: NERFTEX_TUNE="grid_bwd=1,march_serial=1" and the one-variable-per-switch names of round 1
+struct KnobInit {
+    KnobInit() {
+        auto env = [](const char* n) { const char* v = getenv(n); return v ? v : ""; };
+        const char* v;
+        v = env("NERFTEX_GRID_FWD"); g_knobs[kKnobGridFwd] = v[0] == 'p' ? 1 : v[0] == 'l' ? 2 : 0;
+        v = env("NERFTEX_GRID_BWD"); g_knobs[kKnobGridBwd] = v[0] == 'a' ? 1 : v[0] == 'o' ? 2 : 0;
+        g_knobs[kKnobGridBwdSweep] = env("NERFTEX_GRID_BWD_ALGO")[0] == 's';
+        g_knobs[kKnobGridBwdItems] = atol(env("NERFTEX_GRID_BWD_ITEMS"));
+        g_knobs[kKnobGridBwdSlice] = atol(env("NERFTEX_GRID_BWD_SLICE"));
+        g_knobs[kKnobGridBwdNoMerge] = getenv("NERFTEX_GRID_BWD_NOMERGE") != nullptr;
+        v = env("NERFTEX_MARCH"); g_knobs[kKnobMarch] = v[0] == 'r' ? 1 : v[0] == 'l' ? 2 : 0;
+        g_knobs[kKnobMarchSerial] = env("NERFTEX_MARCH_COUNT")[0] == 's';
+        g_knobs[kKnobFfmlpWgPerCu] = atol(env("NERFTEX_FFMLP_WG_PER_CU"));
+        g_knobs[kKnobFfmlpBwdSplit] = env("NERFTEX_FFMLP_BWD")[0] == 's';
+        for (const char* p = env("NERFTEX_TUNE"); *p;) {
+            const char* eq = strchr(p, '=');
+            if (!eq) break;
+            const int k = knob_index(p, (size_t)(eq - p));
+            if (k >= 0) g_knobs[k] = atol(eq + 1);
+            const char* c = strchr(eq, ',');
+            if (!c) break;
+            p = c + 1;
+        }
+    }
+} g_knob_init;
+}  // namespace
 
 // ---- device scratch ------------------------------------------------------------------------------
 namespace {
@@ -127,6 +167,22 @@ int nerftex_profile_report(char* buf, size_t n) {
     out += "}";
     snprintf(buf, n, "%s", out.c_str());
     return NERFTEX_OK;
+}
+
+int nerftex_tune_set(const char* name, long value) {
+    nerftex::clear_error();
+    const int k = name ? nerftex::knob_index(name, strlen(name)) : -1;
+    if (k < 0) {
+        nerftex::set_error("nerftex_tune_set: unknown knob '%s'", name ? name : "(null)");
+        return NERFTEX_ERR_INVALID;
+    }
+    nerftex::g_knobs[k] = value;
+    return NERFTEX_OK;
+}
+
+long nerftex_tune_get(const char* name) {
+    const int k = name ? nerftex::knob_index(name, strlen(name)) : -1;
+    return k < 0 ? -1 : nerftex::g_knobs[k];
 }
 
 const char* nerftex_last_error(void) { return nerftex::g_err; }

@@ -18,11 +18,13 @@ import os
 
 from nerftex_hip import check, lib, ptr, stream, timer
 
+_RECOMPUTE = os.environ.get("NERFTEX_FFMLP_RECOMPUTE", "1") != "0"  # read once
+
 
 def _recompute_ok(input_dim, hidden_dim, num_layers):
     """Shapes for which the library's fused backward can rebuild the activations from the inputs (forward_buffer = NULL): the
     training forward then writes no forward_buffer at all.  NERFTEX_FFMLP_RECOMPUTE=0 restores the stored-activation contract."""
-    return (os.environ.get("NERFTEX_FFMLP_RECOMPUTE", "1") != "0" and os.environ.get("NERFTEX_FFMLP_BWD", "") != "split"
+    return (_RECOMPUTE and not lib.nerftex_tune_get(b"ffmlp_bwd_split")
             and hidden_dim == 64 and 2 <= num_layers <= 4 and input_dim % 16 == 0 and input_dim <= 64)
 
 

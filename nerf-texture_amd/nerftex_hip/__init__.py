@@ -36,6 +36,7 @@ _SIGNATURES = {
     "nerftex_adam_half_step_amp": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
     "nerftex_amp_update": [_vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
     "nerftex_table_adam_step": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
+    "nerftex_tune_set": [C.c_char_p, C.c_long],
     "nerftex_profile_enable": [_i],
     "nerftex_profile_reset": [],
     "nerftex_profile_report": [C.c_char_p, _sz],
@@ -67,7 +68,7 @@ _SIGNATURES = {
     "nerftex_destroy_raytracer": [_vp],
     "nerftex_raytracer_trace": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
 }
-EXPORTS = ["nerftex_last_error", "nerftex_version"] + list(_SIGNATURES)
+EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get"] + list(_SIGNATURES)
 
 
 def _load():
@@ -79,6 +80,8 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.nerftex_last_error.restype = C.c_char_p
     lib.nerftex_version.restype = C.c_char_p
+    lib.nerftex_tune_get.argtypes = [C.c_char_p]
+    lib.nerftex_tune_get.restype = C.c_long
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == a symbol the header declares is not exported
         fn.argtypes = args
@@ -94,6 +97,24 @@ def check(rc):
     if rc != 0:
         msg = lib.nerftex_last_error().decode() or f"nerftex_hip call failed with status {rc}"
         raise RuntimeError(msg)
+
+
+class tune:
+    """Set tuning knobs / A-B switches of the kernels (include/nerftex_hip.h: nerftex_tune_set); usable as a context manager:
+    `with tune(grid_bwd=1): ...` restores the previous values on exit."""
+
+    def __init__(self, **knobs):
+        self._old = {k: lib.nerftex_tune_get(k.encode()) for k in knobs}
+        for k, v in knobs.items():
+            check(lib.nerftex_tune_set(k.encode(), int(v)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._old.items():
+            check(lib.nerftex_tune_set(k.encode(), v))
+        return False
 
 
 def ptr(t):

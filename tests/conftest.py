@@ -32,3 +32,18 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def knobs():
+    """Set kernel A/B switches for one test (nerftex_tune_set); every knob touched is restored afterwards."""
+    import nerftex_hip
+
+    stack = []
+
+    def set_knobs(**kw):
+        stack.append(nerftex_hip.tune(**kw))
+
+    yield set_knobs
+    for t in reversed(stack):
+        t.__exit__(None, None, None)

@@ -88,12 +88,12 @@ def test_ffmlp_forward_and_inference(oracle, dev, case):
 
 @pytest.mark.parametrize("mode", ["fused", "split"])
 @pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4], CASES[5]], ids=lambda c: f"in{c[0]}_h{c[1]}_L{c[2]}_act{c[3]}")
-def test_ffmlp_backward(oracle, dev, case, mode, monkeypatch):
+def test_ffmlp_backward(oracle, dev, case, mode, knobs):
     """mode "fused" (default): activation + weight gradients in one kernel, backward_buffer untouched (hidden 64, 2-4 layers,
     input <= 64; other shapes fall through to the split kernels).  mode "split": dgrad kernel -> backward_buffer -> wgrad kernel."""
     from nerftex_hip import check, lib, ptr, stream
 
-    monkeypatch.setenv("NERFTEX_FFMLP_BWD", mode)
+    knobs(ffmlp_bwd_split=int(mode == "split"))
     IN, H, NL, act, B, w, x = _setup(case, 32)
     fused = mode == "fused" and H == 64 and 2 <= NL <= 4 and IN <= 64
     _, fb = oracle.ffmlp_forward(x, w, IN, 16, H, NL, act, 6)  # same forward activations on both sides

@@ -177,9 +177,41 @@ def test_grid_backward_large_batch_owner_path(oracle, dev, case, dtype):
         assert np.count_nonzero(got) > 0
 
 
+@pytest.mark.parametrize("form", [dict(grid_bwd_fill=2), dict(grid_bwd_fill=4), dict(grid_bwd_sum=1), dict(grid_bwd_sum=4), dict(grid_bwd_sum=16)],
+                         ids=lambda f: "_".join(f"{k[9:]}{v}" for k, v in f.items()))
+def test_grid_backward_binned_forms_agree(oracle, dev, form, knobs):
+    """Every form of the binning kernels (samples per thread in the fill pass, run-table form / loads in flight in the sum pass)
+    produces the same fp16 table: bit for bit on tiles with one owner (exact fixed-point sums, order-independent), and within
+    one half-precision atomic rounding per partial sum on the coarse tiles that several work items add into."""
+    from nerftex_hip import F16, check, lib, ptr, stream
+
+    s = _grid_setup(oracle, GRID_CASES[0], 40009, 31, np.float16)
+    rng = np.random.default_rng(32)
+    B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
+    s["x"][9000:29000] = np.clip(np.repeat(s["x"][9000:9200], 100, axis=0) + np.tile(np.linspace(0, 0.03, 100, dtype=np.float32)[:, None], (200, D)), 0, 1)
+    g = (rng.standard_normal((B, L * C)) * 1e-2).astype(np.float16)
+    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    dummy = torch.zeros(1, dtype=torch.float16, device=dev)
+
+    def run():
+        ge = torch.zeros(s["rows"], C, dtype=torch.float16, device=dev)
+        check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), B, D, C, L, s["S"], s["base"], 0, ptr(dummy), ptr(dummy),
+                                               s["gridtype"], int(s["align"]), F16, 1, stream()))
+        torch.cuda.synchronize()
+        return ge.cpu().numpy().astype(np.float64)
+
+    want = run()
+    knobs(**form)
+    got = run()
+    assert np.count_nonzero(want) > 0
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-3 * np.abs(want).max())
+    fine = int(s["offsets"][5])  # levels >= 5 are hashed, 128 tiles each, one work item per tile
+    assert np.array_equal(got[fine:], want[fine:])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float16], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("path", ["directory", "sweep", "atomic", "small"])
-def test_grid_backward_overwrites_uninitialised_table(oracle, dev, dtype, path, monkeypatch):
+def test_grid_backward_overwrites_uninitialised_table(oracle, dev, dtype, path, knobs):
     """NERFTEX_LAYOUT_GRAD_OVERWRITE: grad_embeddings arrives as garbage (NaN here) and must come back exactly as from a
     zero-filled buffer under the reference's contract, on every internal path (single-pass binning writes every row itself,
     the others clear the table first)."""
@@ -188,9 +220,9 @@ def test_grid_backward_overwrites_uninitialised_table(oracle, dev, dtype, path, 
     n = 3000 if path == "small" else 20011
     s = _grid_setup(oracle, GRID_CASES[0], n, 23, dtype)
     if path == "sweep":
-        monkeypatch.setenv("NERFTEX_GRID_BWD_ALGO", "sweep")
+        knobs(grid_bwd_sweep=1)
     if path == "atomic":
-        monkeypatch.setenv("NERFTEX_GRID_BWD", "atomic")
+        knobs(grid_bwd=1)
     rng = np.random.default_rng(24)
     B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
     g = (rng.standard_normal((B, L * C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)

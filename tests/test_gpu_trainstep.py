@@ -114,7 +114,7 @@ def test_render_tail_matches_framework_ops(dev, N):
 
 
 @pytest.mark.parametrize("amp", ["gradscaler", "fused"])
-def test_half_leaf_adam_trains_like_torch_adam(dev, monkeypatch, amp):
+def test_half_leaf_adam_trains_like_torch_adam(dev, knobs, amp):
     """A small hash grid + FFMLP trained for a few steps under autocast with loss scaling: HalfLeafAdam (fp16 leaves, fp16 gradients
     consumed as produced; driven by torch's GradScaler or by FusedAmp) against torch.optim.Adam(fused=True) + GradScaler on the fp32
     parameters.  With the encoder backward on its order-independent path (the large-batch one, forced here for 4096 points) all see
@@ -124,7 +124,7 @@ def test_half_leaf_adam_trains_like_torch_adam(dev, monkeypatch, amp):
     from gridencoder import GridEncoder
     from ngp_harness.optim import FusedAmp, HalfLeafAdam
 
-    monkeypatch.setenv("NERFTEX_GRID_BWD", "owner")
+    knobs(grid_bwd=2)
     gs = dict(init_scale=2.0 ** 30, growth_interval=3)
 
     def run(mode):

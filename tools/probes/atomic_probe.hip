@@ -13,6 +13,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb3
 // mode 2: plain 4-byte stores to the same addresses (no atomic)
 // mode 3: f32 atomics (8-byte rows: 2 atomics)
 // mode 4: packed-half atomics, region chosen by the real XCC id (s_getreg)
+// mode 6 / 7 / 8: INTEGER atomics (u32, u64, u32 relaxed agent scope) to random rows -- is the L2 atomic rate a float-unit limit?
 // mode 5: packed-half atomics, lanes in groups of ADJ share one random base row and hit ADJ adjacent rows (same 64/128 B line)
 template <int ADJ>
 __global__ void scatter_adj(uint32_t* table, uint32_t rows, uint32_t per_thread) {
@@ -46,10 +47,13 @@ __global__ void scatter(uint32_t* table, uint32_t rows, uint32_t per_thread, uin
     uint32_t region = 0;
     if (MODE == 1) region = blockIdx.x % 8;
     if (MODE == 4) { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); region = x & 7; }
-    uint32_t* base = table + (size_t)(region % n_regions) * rows * (MODE == 3 ? 2 : 1);
+    uint32_t* base = table + (size_t)(region % n_regions) * rows * (MODE == 3 || MODE == 7 ? 2 : 1);
     for (uint32_t k = 0; k < per_thread; k++) {
         const uint32_t r = mix(tid * 131u + k * 2654435761u) % rows;
         if (MODE == 2) { base[r] = tid; }
+        else if (MODE == 6) { atomicAdd(base + r, 3u); }                                                          // integer, 4 B
+        else if (MODE == 7) { atomicAdd(reinterpret_cast<unsigned long long*>(base) + r, 0x100000001ull); }      // integer, 8 B
+        else if (MODE == 8) { __hip_atomic_fetch_add(base + r, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else if (MODE == 3) { unsafeAtomicAdd(reinterpret_cast<float*>(base) + 2 * r, 1.0f); unsafeAtomicAdd(reinterpret_cast<float*>(base) + 2 * r + 1, 1.0f); }
         else { __half2 v = __floats2half2_rn(1.0f, 1.0f); unsafeAtomicAdd(reinterpret_cast<__half2*>(base) + r, v); }
     }
@@ -79,6 +83,9 @@ int main() {
         run<4>("pk_add_f16, region = XCC_ID", table, rows, 8);
         run<3>("add_f32 x2, one region", table, rows, 1);
         run<2>("plain store, one region", table, rows, 1);
+        run<6>("atomic add u32, one region", table, rows, 1);
+        run<7>("atomic add u64, one region", table, rows, 1);
+        run<8>("atomic add u32 relaxed/agent, one region", table, rows, 1);
         run_adj<2>(table, rows); run_adj<4>(table, rows); run_adj<16>(table, rows); run_adj<64>(table, rows);
     }
     return 0;
