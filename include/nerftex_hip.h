@@ -51,8 +51,8 @@ const char* nerftex_version(void);
 
 /* Tuning knobs / A-B switches of the kernels (profiling aid; the defaults are what is measured and shipped).  The library
  * reads its environment ONCE when it is loaded (NERFTEX_TUNE="name=value,..."), a launch never calls getenv().  Names:
- * grid_fwd, grid_bwd, grid_bwd_sweep, grid_bwd_items, grid_bwd_slice, grid_bwd_nomerge, grid_bwd_fill, grid_bwd_sum,
- * grid_bwd_probe, march, march_serial, ffmlp_wg_per_cu, ffmlp_bwd_split (csrc/common.hpp documents the values).
+ * grid_fwd, grid_bwd, grid_bwd_sweep, grid_bwd_items, grid_bwd_slice, grid_bwd_nomerge, grid_bwd_probe,
+ * march, march_serial, ffmlp_wg_per_cu, ffmlp_bwd_split (csrc/common.hpp documents the values).
  * tune_set: NERFTEX_ERR_INVALID for an unknown name; tune_get: -1 for an unknown name.                                    */
 int nerftex_tune_set(const char* name, long value);
 long nerftex_tune_get(const char* name);

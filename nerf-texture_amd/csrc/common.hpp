@@ -61,8 +61,6 @@ enum Knob {
     kKnobGridBwdItems,   // sweep: work items per level (0 = auto)
     kKnobGridBwdSlice,   // binning: records per K4 work item (0 = default)
     kKnobGridBwdNoMerge, // binning: 1 = do not merge runs of samples that share a cell
-    kKnobGridBwdFill,    // binning K3: samples per thread (0 = default)
-    kKnobGridBwdSum,     // binning K4: 0 = default, 1 = per-wave run tables (round-1 kernel)
     kKnobGridBwdProbe,   // phase ablation of K3 / K4 for profiling (0 = off; results are garbage when set)
     kKnobMarch,          // 0 auto, 1 replay, 2 log
     kKnobMarchSerial,    // 1: one-ray-per-lane DDA for the counting pass

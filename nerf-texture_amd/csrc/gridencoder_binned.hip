@@ -38,18 +38,23 @@ constexpr uint32_t kTileBytes = 64 * 1024;              // LDS accumulator tile 
 constexpr uint32_t kMaxTilesPerLevel = 128;             // 2^19 rows of an fp16 level
 constexpr uint32_t kSliceRecords = 32 * 1024;           // records per K4 work item
 constexpr uint32_t kSumThreads = 1024;
-constexpr uint32_t kRowBits = 14, kRowMask = (1u << kRowBits) - 1u, kHasB = 1u << (2 * kRowBits);
-
-// a record: tile-local rows a | b << 14 | has_b << 28, then the two weighted gradients (C = 2)
+// A record is ONE x-neighbour pair of corners of a sample on a level (rows a and b = a ^ (2^(k+1) - 1) inside one tile: adjacent
+// rows on dense levels, one aligned block on hashed levels because prime[0] == 1) together with the pair's share of the gradient
+// g' = w_yz * grad and the x fraction p: row a receives (1 - p) g', row b receives p g'.  Or, kcode 15, a single row that receives g'
+// whole (pairs that straddle a tile edge, and runs of samples merged before emission, whose two sums no longer share one p).
+//   fp16:  word = local row a | kcode << 12 | p16 << 16 (p in 2^-16 units), g' as half2                      ->  8 bytes
+//   fp32:  word = local row a | kcode << 14, p and g' as floats                                                -> 16 bytes
 template <typename T> struct Rec;
-template <> struct Rec<half_t> { uint32_t rows; half2_t va, vb; };              // 12 B
-template <> struct Rec<float> { uint32_t rows; float va0, va1, vb0, vb1; };     // 20 B
+template <> struct Rec<half_t> { uint32_t word; half2_t g; };
+template <> struct Rec<float> { uint32_t word; float p, g0, g1; };
+constexpr uint32_t kSingle = 15;
+template <typename T> constexpr uint32_t row_bits() { return sizeof(T) == 2 ? 12u : 14u; }
 
-// accumulator bytes per table row in K4: fp16 -> 2 x int64 fixed point, fp32 -> 2 x float
+// accumulator bytes per table row in K4d: fp16 -> 2 x int64 fixed point, fp32 -> 2 x float
 template <typename T>
 constexpr uint32_t rows_per_tile() { return sizeof(T) == 2 ? kTileBytes / 16u : kTileBytes / 8u; }
 static_assert(kMaxTilesPerLevel == 2 * kWave, "K3d scans one level's tiles with one wave, two tiles per lane");
-static_assert(rows_per_tile<half_t>() <= (1u << kRowBits) && rows_per_tile<float>() <= (1u << kRowBits), "local row field");
+static_assert(rows_per_tile<half_t>() == (1u << row_bits<half_t>()) && rows_per_tile<float>() <= (1u << row_bits<float>()), "local row field");
 
 // ---- fp16 <-> 2^-24 fixed point ------------------------------------------------------------------------------------
 // every finite half is m * 2^-24 with |m| < 2^40; inf / nan map to >= 2^40 and come back as inf
@@ -58,6 +63,13 @@ __device__ __forceinline__ long long half_to_fixed(half_t h) {
     const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
     const unsigned long long mag = e ? (unsigned long long)(f | 1024u) << (e - 1u) : (unsigned long long)f;
     return (b & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+// the share p16 / 65536 of a fixed-point value, rounded to nearest; an overflowed value (>= 2^40) is handed on whole so that both
+// rows of the pair come back as inf
+__device__ __forceinline__ long long fixed_share(long long v, uint32_t p16) {
+    const unsigned long long m = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+    const unsigned long long r = (m >> 40) ? m : (m * p16 + 32768ull) >> 16;
+    return v < 0 ? -(long long)r : (long long)r;
 }
 // round-to-nearest-even of s * 2^-24 to half, overflow -> inf
 __device__ __forceinline__ half_t fixed_to_half(long long s) {
@@ -77,21 +89,54 @@ __device__ __forceinline__ half_t fixed_to_half(long long s) {
     return __builtin_bit_cast(half_t, (uint16_t)(bits | sign));
 }
 
-// ---- per-sample record construction, shared by K1 (count only) and K3 (fill) ---------------------------------------
+// lane i <- lane i + N of the same 16-lane row (0 past the row's end): one VALU move with a DPP row shift, no LDS crossbar
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 | N, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_shr_u32(uint32_t v, uint32_t fill) {  // lane i <- lane i - N of the row, `fill` at the row's start
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 | N, 0xf, 0xf, false);
+}
+
+// ---- the records of one (sample, level) --------------------------------------------------------------------------------
+// NP pairs; pair q is emitted as ONE record (row a, block code, p, g') or, when split, as two single-row records
+// (row a <- va, row b <- vb).
 template <typename T, int D>
 struct Sample {
     static constexpr int NP = 1 << (D - 1);  // x-pairs per sample
-    bool valid;       // in range AND head of its run (contributions of merged lanes are already folded in)
-    uint32_t row_a[NP], row_b[NP];
-    float va[NP][2], vb[NP][2];
+    bool live;             // this lane emits records (valid sample, first lane of its run)
+    uint32_t split;        // bit q: pair q goes out as two single-row records
+    uint32_t row_a[NP], row_b[NP];  // rows inside the level
+    float ga[NP][2];       // pair: g' = w_yz * grad; split: row a's sum
+    float gb[NP][2];       // split: row b's sum
+    float p;               // x fraction of the pairs
 };
 
-// xs: the sample's coordinates, in_batch: b < B, g: this (sample, level)'s two gradient values (FILL only).
-// Must be called by whole waves (shuffles); consecutive lanes = consecutive samples.
-template <typename T, int D, bool FILL>
+template <int N, int NP>
+__device__ __forceinline__ void merge_step(float (&va)[NP][2], float (&vb)[NP][2], int lane_in_row, int run_end) {
+    const bool take = lane_in_row + N < run_end;
+    if (__ballot(take) == 0ull) return;
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float oa = row_shl<N>(va[q][c]), ob = row_shl<N>(vb[q][c]);
+            va[q][c] += take ? oa : 0.0f;
+            vb[q][c] += take ? ob : 0.0f;
+        }
+}
+
+// xs: the sample's coordinates, in_batch: b < B, g: this (sample, level)'s two gradient values.
+// Must be called by whole waves (cross-lane moves); consecutive lanes = consecutive samples.
+// Runs of consecutive samples in one cell (coarse levels; samples are ray-ordered) are merged onto the run's first lane before
+// anything is emitted -- inside 16-lane rows, so that the moves are DPP row shifts (a run that crosses a row boundary continues as a
+// second run): the same-row pile-ups of the coarse levels never reach the LDS atomics of K4d.
+template <typename T, int D>
 __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[D], bool in_batch, const float (&g)[2], float scale,
-                                            bool align_corners, const IndexFn<D>& index_of, uint32_t hashmap_size, bool merge_runs) {
+                                            bool align_corners, const IndexFn<D>& index_of, bool merge_runs) {
     constexpr int NP = Sample<T, D>::NP;
+    constexpr uint32_t kRows = rows_per_tile<T>();
     const int lane = threadIdx.x & (kWave - 1);
     bool valid = in_batch;
     float pos[D];
@@ -104,89 +149,104 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
     }
+    sm.p = pos[0];
 
     uint32_t term[D][2];
     index_of.terms(pg, term);
+    float wyz[NP];
+    uint32_t unpairable = 0;
 #pragma unroll
     for (int q = 0; q < NP; q++) {  // q enumerates the corner bits of dimensions 1..D-1
-        float wyz = 1;
+        float w = 1;
         uint32_t yz = 0;
 #pragma unroll
         for (int d = 1; d < D; d++) {
             const int bit = (q >> (d - 1)) & 1;
-            wyz *= bit ? pos[d] : 1 - pos[d];
+            w *= bit ? pos[d] : 1 - pos[d];
             yz = index_of.combine(yz, term[d][bit]);
         }
+        wyz[q] = w;
         sm.row_a[q] = index_of.wrap(index_of.combine(term[0][0], yz));
         sm.row_b[q] = index_of.wrap(index_of.combine(term[0][1], yz));
-        if (FILL) {
-            const float wa = (1 - pos[0]) * wyz, wb = pos[0] * wyz;  // products commute: same value as the dimension-ordered weight
-            sm.va[q][0] = wa * g[0]; sm.va[q][1] = wa * g[1];
-            sm.vb[q][0] = wb * g[0]; sm.vb[q][1] = wb * g[1];
-        }
+        const uint32_t m = sm.row_a[q] ^ sm.row_b[q];  // a pair: b = a ^ (2^k - 1) inside one tile
+        if (m == 0u || (m & (m + 1u)) != 0u || m >= kRows) unpairable |= 1u << q;
     }
 
-    // wave64 run merge: consecutive samples in the same cell (coarse levels) collapse onto the first lane of the run
-    // every lane must execute every shuffle (no short-circuit): the lane above reads this lane's registers
-    bool same = valid && lane > 0;
+    // head of a run: the previous lane (same 16-lane row) is not a valid sample of the same cell
+    bool same = valid && (lane & 15) != 0 && merge_runs;
     {
-        const int prev_valid = __shfl_up((int)valid, 1, kWave);
-        bool eq = prev_valid != 0;
+        bool eq = row_shr_u32<1>((uint32_t)valid, 0u) != 0u;
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const uint32_t prev = __shfl_up(pg[d], 1, kWave);
-            eq = eq & (prev == pg[d]);
-        }
+        for (int d = 0; d < D; d++) eq = eq & (row_shr_u32<1>(pg[d], 0xffffffffu) == pg[d]);
         same = same & eq;
     }
-    const bool head = !same || !merge_runs;
-    const uint64_t heads = __ballot(head);
-    if (FILL && heads != ~0ull) {
-        const uint64_t above = lane == kWave - 1 ? 0ull : (heads & ~((2ull << lane) - 1ull));
-        const int run_end = above ? __builtin_ctzll(above) : kWave;
+    sm.live = valid && !same;
+    const uint64_t heads = __ballot(!same);
+    const bool merging = heads != ~0ull;                                   // some lane of this wave has followers
+    const bool splitting = merging || __ballot(sm.live && unpairable) != 0ull;  // wave-uniform: the two rows' sums are needed
+    float va[NP][2], vb[NP][2];
 #pragma unroll
-        for (int step = 1; step < kWave; step <<= 1) {
-            const bool take = lane + step < run_end;
-            if (__ballot(take) == 0ull) break;
-#pragma unroll
-            for (int q = 0; q < NP; q++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const float oa = __shfl_down(sm.va[q][c], step, kWave);
-                    const float ob = __shfl_down(sm.vb[q][c], step, kWave);
-                    if (take) { sm.va[q][c] += oa; sm.vb[q][c] += ob; }
-                }
-        }
+    for (int q = 0; q < NP; q++) {
+        sm.ga[q][0] = wyz[q] * g[0];
+        sm.ga[q][1] = wyz[q] * g[1];
+        va[q][0] = va[q][1] = vb[q][0] = vb[q][1] = 0.0f;
     }
-    sm.valid = valid && head;
+    sm.split = 0;
+    if (splitting) {
+        const float wa0 = 1 - pos[0];
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const float wa = wa0 * wyz[q], wb = pos[0] * wyz[q];  // products commute: same value as the dimension-ordered weight
+            va[q][0] = wa * g[0]; va[q][1] = wa * g[1];
+            vb[q][0] = wb * g[0]; vb[q][1] = wb * g[1];
+        }
+        bool merged = false;  // this lane is a head that absorbed followers
+        if (merging) {
+            const uint32_t row_heads = (uint32_t)(heads >> (lane & 48)) & 0xffffu;
+            const uint32_t above = row_heads & ~((2u << (lane & 15)) - 1u);
+            const int run_end = above ? __builtin_ctz(above) : 16;  // lane-in-row of the next head
+            merged = run_end > (lane & 15) + 1;
+            merge_step<1, NP>(va, vb, lane & 15, run_end);
+            merge_step<2, NP>(va, vb, lane & 15, run_end);
+            merge_step<4, NP>(va, vb, lane & 15, run_end);
+            merge_step<8, NP>(va, vb, lane & 15, run_end);
+        }
+        sm.split = merged ? (1u << NP) - 1u : unpairable;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const bool sp = (sm.split >> q) & 1u;
+        sm.ga[q][0] = sp ? va[q][0] : sm.ga[q][0];
+        sm.ga[q][1] = sp ? va[q][1] : sm.ga[q][1];
+        sm.gb[q][0] = vb[q][0];
+        sm.gb[q][1] = vb[q][1];
+    }
 }
 
 template <typename T>
-__device__ __forceinline__ void put_record(Rec<T>* __restrict__ dst, uint32_t rows, const float (&va)[2], const float (&vb)[2]) {
+__device__ __forceinline__ Rec<T> make_record(uint32_t local_row, uint32_t code, float p, const float (&v)[2]) {
     Rec<T> r;
-    r.rows = rows;
     if constexpr (sizeof(T) == 2) {
-        r.va = half2_t{(half_t)va[0], (half_t)va[1]};
-        r.vb = half2_t{(half_t)vb[0], (half_t)vb[1]};
+        const uint32_t p16 = min(65535u, (uint32_t)(p * 65536.0f + 0.5f));
+        r.word = local_row | (code << row_bits<T>()) | (code == kSingle ? 0u : p16 << 16);
+        r.g = half2_t{(half_t)v[0], (half_t)v[1]};
     } else {
-        r.va0 = va[0]; r.va1 = va[1]; r.vb0 = vb[0]; r.vb1 = vb[1];
+        r.word = local_row | (code << row_bits<T>());
+        r.p = p; r.g0 = v[0]; r.g1 = v[1];
     }
-    *dst = r;
+    return r;
 }
 
 // =====================================================================================================================
-// K3d  one workgroup per (1024 samples, level): the samples' records are counted per tile in LDS, laid out grouped by tile and
-//      copied, as ONE contiguous block, into the workgroup's own fixed-capacity region of the record buffer; a directory
-//      entry (offset << 16 | count) per (level, tile, chunk) says where each tile's run sits inside that block.
-//      THREADS x SPT = 1024: a thread carries SPT samples (sample s of thread t = chunk * 1024 + s * THREADS + t, so that
-//      consecutive lanes are consecutive samples for the run merge).
+// K3d  one workgroup per (1024 samples, level), thread = sample: the samples' records are counted per tile in LDS, laid out
+//      grouped by tile and copied, as ONE contiguous block, into the workgroup's own fixed-capacity region of the record buffer;
+//      a directory entry (offset << 16 | count) per (level, tile, chunk) says where each tile's run sits inside that block.
 // K4d  one workgroup per (tile, range of chunks): reads its directory entries, then streams the runs.
-// The record buffer is addressed, not packed (capacity 8192 records per region, the worst case of every pair straddling a
-// tile edge), which is what 288 GB of HBM is for.
+// The record buffer is addressed, not packed (capacity 8192 records per region, the worst case of every pair split),
+// which is what 288 GB of HBM is for.
 constexpr uint32_t kStageRecords = 4096 + 256;            // LDS slots per K3d workgroup; rarer overflow goes straight to memory
 constexpr uint32_t kRegionRecords = 2 * 4 * kBinSamples;  // capacity of one (chunk, level) region
-constexpr uint32_t kDirLdsBytes = (kSumThreads / kWave) * 2 * kWave * 4;  // K4d (per-wave form): run tables
-constexpr uint32_t kRunTableBytes = (2 * kSumThreads + kWave) * 4;        // K4d (workgroup form): exclusive prefix + record index per run
+constexpr uint32_t kDirLdsBytes = (kSumThreads / kWave) * 2 * kWave * 4;  // K4d: per-wave run tables
 
 struct DirTable {
     int32_t offsets[kMaxLevels + 1];
@@ -195,13 +255,12 @@ struct DirTable {
     uint32_t slices[kMaxLevels];         // work items per tile of the level (each takes a range of chunks)
 };
 
-template <typename T, int D, bool BLC, int THREADS, int SPT>
-__global__ __launch_bounds__(THREADS) void bin_fill_dir_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                               const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
-                                                               uint32_t gridtype, bool align_corners, const DirTable tab,
-                                                               uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, bool merge_runs,
-                                                               uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe) {
-    static_assert(THREADS * SPT == (int)kBinSamples && THREADS >= (int)kMaxTilesPerLevel, "chunk shape");
+template <typename T, int D, bool BLC>
+__global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                  const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
+                                                                  uint32_t gridtype, bool align_corners, const DirTable tab,
+                                                                  uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, bool merge_runs,
+                                                                  uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel];
     constexpr int NP = Sample<T, D>::NP;
@@ -219,44 +278,35 @@ __global__ __launch_bounds__(THREADS) void bin_fill_dir_kernel(const T* __restri
     if (zero_grid != nullptr && tab.slices[level] > 1) {
         const uint32_t units = hashmap_size * 2, per = div_up(units, nchunks);  // elements (2 per row)
         T* base = zero_grid + (size_t)(uint32_t)tab.offsets[level] * 2;
-        for (uint32_t i = chunk * per + threadIdx.x; i < min(units, (chunk + 1) * per); i += THREADS) base[i] = (T)0.0f;
+        for (uint32_t i = chunk * per + threadIdx.x; i < min(units, (chunk + 1) * per); i += kBinSamples) base[i] = (T)0.0f;
     }
     const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
     Rec<T>* region = records + ((size_t)level * nchunks + chunk) * kRegionRecords;
 
     if (threadIdx.x < kMaxTilesPerLevel) hist[threadIdx.x] = 0;
-    float xs[SPT][D], g[SPT][2];
-    bool in_batch[SPT];
+    const uint32_t b = chunk * kBinSamples + threadIdx.x;
+    const bool in_batch = b < B;
+    float xs[D], g[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int s = 0; s < SPT; s++) {
-        const uint32_t b = chunk * kBinSamples + s * THREADS + threadIdx.x;
-        in_batch[s] = b < B;
-#pragma unroll
-        for (int d = 0; d < D; d++) xs[s][d] = in_batch[s] ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
-        g[s][0] = g[s][1] = 0.0f;
-        if (in_batch[s]) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g[s]);
-    }
+    for (int d = 0; d < D; d++) xs[d] = in_batch ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
+    if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
     const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
-    Sample<T, D> sm[SPT];
-#pragma unroll
-    for (int s = 0; s < SPT; s++) make_sample<T, D, true>(sm[s], xs[s], in_batch[s], g[s], lc.scale[level], align_corners, index_of, hashmap_size, merge_runs);
+    Sample<T, D> sm;
+    make_sample<T, D>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, merge_runs);
     if (probe == 1) {  // ablation: loads + record construction only
-        if (sm[0].va[0][0] == 1234.5f && sm[SPT - 1].row_b[NP - 1] == 77u) dir[0] = 1;
+        if (sm.ga[0][0] == 1234.5f && sm.row_b[NP - 1] == 77u && sm.gb[0][1] == 3.0f) dir[0] = 1;
         return;
     }
     __syncthreads();
 
     // ---- count per tile
+    if (sm.live) {
 #pragma unroll
-    for (int s = 0; s < SPT; s++)
-        if (sm[s].valid) {
-#pragma unroll
-            for (int q = 0; q < NP; q++) {
-                const uint32_t ta = sm[s].row_a[q] / kRows, tb = sm[s].row_b[q] / kRows;
-                atomicAdd(&hist[ta], 1u);
-                if (ta != tb) atomicAdd(&hist[tb], 1u);
-            }
+        for (int q = 0; q < NP; q++) {
+            atomicAdd(&hist[sm.row_a[q] / kRows], 1u);
+            if ((sm.split >> q) & 1u) atomicAdd(&hist[sm.row_b[q] / kRows], 1u);
         }
+    }
     __syncthreads();
     if (threadIdx.x < kWave) {  // wave 0: exclusive prefix over the level's tiles (two per lane) + the directory entries
         uint32_t cnt[2] = {hist[lane], hist[lane + kWave]};
@@ -281,51 +331,63 @@ __global__ __launch_bounds__(THREADS) void bin_fill_dir_kernel(const T* __restri
     if (probe == 2) return;  // ablation: + count + scan + directory
 
     // ---- place: LDS for the first kStageRecords slots of the block, the rest straight to the region
+    auto place = [&](uint32_t row, uint32_t code, const float (&v)[2]) {
+        const uint32_t t = row / kRows;
+        const uint32_t at = lbase[t] + atomicAdd(&lcount[t], 1u);
+        const Rec<T> r = make_record<T>(row - t * kRows, code, sm.p, v);
+        if (at < kStageRecords) stage[at] = r;
+        else region[at] = r;
+    };
+    if (sm.live) {
 #pragma unroll
-    for (int s = 0; s < SPT; s++)
-        if (sm[s].valid) {
-#pragma unroll
-            for (int q = 0; q < NP; q++) {
-                const uint32_t ta = sm[s].row_a[q] / kRows, tb = sm[s].row_b[q] / kRows;
-                const uint32_t la = sm[s].row_a[q] - ta * kRows, lb = sm[s].row_b[q] - tb * kRows;
-                const uint32_t sa = lbase[ta] + atomicAdd(&lcount[ta], 1u);
-                Rec<T>* da = sa < kStageRecords ? stage + sa : region + sa;
-                if (ta == tb) {
-                    put_record<T>(da, la | (lb << kRowBits) | kHasB, sm[s].va[q], sm[s].vb[q]);
-                } else {
-                    const uint32_t sb = lbase[tb] + atomicAdd(&lcount[tb], 1u);
-                    put_record<T>(da, la, sm[s].va[q], sm[s].vb[q]);
-                    put_record<T>(sb < kStageRecords ? stage + sb : region + sb, lb, sm[s].vb[q], sm[s].va[q]);
-                }
-            }
+        for (int q = 0; q < NP; q++) {
+            const uint32_t m = sm.row_a[q] ^ sm.row_b[q];
+            const bool sp = (sm.split >> q) & 1u;
+            place(sm.row_a[q], sp ? kSingle : 30u - (uint32_t)__builtin_clz(m + 1u), sm.ga[q]);  // m = 2^(k+1) - 1 -> code k
+            if (sp) place(sm.row_b[q], kSingle, sm.gb[q]);
         }
+    }
     __syncthreads();
     if (probe == 3) return;  // ablation: + placement in LDS
     const uint32_t total = min(lbase[kMaxTilesPerLevel], kStageRecords);
 #pragma unroll 5
-    for (uint32_t i = threadIdx.x; i < total; i += THREADS) region[i] = stage[i];  // one contiguous block, tile order preserved
+    for (uint32_t i = threadIdx.x; i < total; i += kBinSamples) region[i] = stage[i];  // one contiguous block, tile order preserved
 }
 
-// fp16: value * 2^24 into the 64-bit accumulators; fp32: float LDS atomics
+// K4d: one record into the tile's accumulators.  fp16: value * 2^24 in 64-bit integers -- every half is an integer multiple of
+// 2^-24 below 2^16 -- split between the pair's rows as fixed(g') * p16 / 2^16 and the exact remainder, so the two shares always add
+// up to g'; ds_add_u64 sums are exact and order-independent.  fp32: float LDS atomics.
 template <typename T>
 __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
-    const uint32_t ra = r.rows & kRowMask, rb = (r.rows >> kRowBits) & kRowMask;
-    const bool has_b = (r.rows & kHasB) != 0;
+    constexpr uint32_t kBits = row_bits<T>();
+    const uint32_t ra = r.word & ((1u << kBits) - 1u), code = (r.word >> kBits) & 15u;
+    const uint32_t rb = ra ^ ((2u << code) - 1u);
     if constexpr (sizeof(T) == 2) {
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
-        atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)half_to_fixed(r.va[0]));
-        atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)half_to_fixed(r.va[1]));
-        if (has_b) {
-            atomicAdd(acc64 + (size_t)rb * 2, (unsigned long long)half_to_fixed(r.vb[0]));
-            atomicAdd(acc64 + (size_t)rb * 2 + 1, (unsigned long long)half_to_fixed(r.vb[1]));
+        const long long f0 = half_to_fixed(r.g[0]), f1 = half_to_fixed(r.g[1]);
+        if (code == kSingle) {
+            atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)f0);
+            atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)f1);
+        } else {
+            const uint32_t p16 = r.word >> 16;
+            const long long b0 = fixed_share(f0, p16), b1 = fixed_share(f1, p16);
+            const bool ovf0 = ((f0 < 0 ? -f0 : f0) >> 40) != 0, ovf1 = ((f1 < 0 ? -f1 : f1) >> 40) != 0;
+            atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)(ovf0 ? f0 : f0 - b0));
+            atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)(ovf1 ? f1 : f1 - b1));
+            atomicAdd(acc64 + (size_t)rb * 2, (unsigned long long)b0);
+            atomicAdd(acc64 + (size_t)rb * 2 + 1, (unsigned long long)b1);
         }
     } else {
         float* acc32 = reinterpret_cast<float*>(smem);
-        atomicAdd(acc32 + (size_t)ra * 2, r.va0);
-        atomicAdd(acc32 + (size_t)ra * 2 + 1, r.va1);
-        if (has_b) {
-            atomicAdd(acc32 + (size_t)rb * 2, r.vb0);
-            atomicAdd(acc32 + (size_t)rb * 2 + 1, r.vb1);
+        if (code == kSingle) {
+            atomicAdd(acc32 + (size_t)ra * 2, r.g0);
+            atomicAdd(acc32 + (size_t)ra * 2 + 1, r.g1);
+        } else {
+            const float wa = 1 - r.p;
+            atomicAdd(acc32 + (size_t)ra * 2, wa * r.g0);
+            atomicAdd(acc32 + (size_t)ra * 2 + 1, wa * r.g1);
+            atomicAdd(acc32 + (size_t)rb * 2, r.p * r.g0);
+            atomicAdd(acc32 + (size_t)rb * 2 + 1, r.p * r.g1);
         }
     }
 }
@@ -390,83 +452,15 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
     }
 }
 
-// K4d, workgroup form: the workgroup prefix-sums the lengths of up to 1024 runs into ONE LDS table and walks their concatenation
-// as a flat list, U records per lane in flight (the loads of a lane are independent: each finds its run with a 10-step search).
-template <typename T, int U>
+// K4d: a wave takes 64 runs at a time (chunks c_lo + wave + 16 k): their lengths are prefix-summed into a per-wave LDS table and
+// the wave walks the concatenation as ONE flat list -- every lane busy, loads independent -- finding the run of an element with a
+// 6-step search in that table.  (Measured alternatives: a wave per run leaves half the lanes idle, 159 us against 95; a lane per
+// run makes every load divergent, 410; one run table for the whole workgroup with 4-16 loads in flight per lane puts two
+// barriers in front of every pass: 137-161.)
+template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
-                                                                   const bool overwrite, uint32_t probe) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    SumItem it;
-    if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it)) return;
-    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-    constexpr uint32_t kWaves = kSumThreads / kWave;
-    zero_tile<T>(smem, it.nrows);
-
-    uint32_t* s_excl = reinterpret_cast<uint32_t*>(smem + kTileBytes);  // [1024] exclusive prefix of the run lengths
-    uint32_t* s_base = s_excl + kSumThreads;                            // [1024] first record of the run
-    uint32_t* s_wsum = s_base + kSumThreads;                            // [16] wave totals
-    const uint32_t* drow = dir + ((size_t)it.level * kMaxTilesPerLevel + it.t) * nchunks;
-    for (uint32_t cb = it.c_lo; cb < it.c_hi; cb += kSumThreads) {
-        const uint32_t c = cb + threadIdx.x;
-        const uint32_t entry = c < it.c_hi ? drow[c] : 0u;
-        const uint32_t cnt = entry & 0xffffu;
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, kWave);
-            if ((int)lane >= off) incl += o;
-        }
-        if (lane == kWave - 1) s_wsum[wave] = incl;
-        __syncthreads();  // (first pass: also orders the zero fill before the atomics)
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kWaves; w++) {
-            const uint32_t v = s_wsum[w];
-            before += w < wave ? v : 0u;
-            total += v;
-        }
-        s_excl[threadIdx.x] = before + incl - cnt;
-        s_base[threadIdx.x] = (uint32_t)(((size_t)it.level * nchunks + (c < it.c_hi ? c : it.c_lo)) * kRegionRecords) + (entry >> 16);  // < 2^32 records
-        __syncthreads();
-        if (probe == 1) continue;  // ablation: zero fill + directory + scan only
-        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += kSumThreads * U) {
-            Rec<T> r[U];
-            bool live[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t i = i0 + u * kSumThreads;
-                live[u] = i < total;
-                uint32_t k = 0;
-#pragma unroll
-                for (uint32_t step = kSumThreads / 2; step > 0; step >>= 1)
-                    if (s_excl[k + step] <= i) k += step;  // past the last run: cnt = 0 and excl = total, never <= a live i
-                r[u] = records[(size_t)s_base[live[u] ? k : 0] + (live[u] ? i - s_excl[k] : 0u)];
-            }
-            if (probe == 2) {  // ablation: + record loads, no accumulation
-                uint32_t x = 0;
-#pragma unroll
-                for (int u = 0; u < U; u++) x ^= r[u].rows;
-                if (x == 0x12345678u) s_wsum[0] = x;
-                continue;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (live[u]) add_record<T>(smem, r[u]);
-        }
-        __syncthreads();  // the run tables are rewritten by the next pass
-    }
-    __syncthreads();
-    if (probe == 3) return;  // ablation: no write-back
-    write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite);
-}
-
-// K4d, per-wave form (round 1): a wave takes 64 runs at a time (chunks c_lo + wave + 16 k): their lengths are prefix-summed into a
-// per-wave LDS table and the wave walks the concatenation as ONE flat list, two records per lane in flight.
-template <typename T>
-__global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_wave_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
-                                                                        const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
-                                                                        const bool overwrite) {
+                                                                   const bool overwrite) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SumItem it;
     if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it)) return;
@@ -490,7 +484,7 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_wave_kernel(const R
         }
         const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
         s_excl[lane] = incl - cnt;
-        s_base[lane] = (uint32_t)(((size_t)it.level * nchunks + (c < it.c_hi ? c : it.c_lo)) * kRegionRecords) + (entry >> 16);
+        s_base[lane] = (uint32_t)(((size_t)it.level * nchunks + (c < it.c_hi ? c : it.c_lo)) * kRegionRecords) + (entry >> 16);  // < 2^32 records
         for (uint32_t i = lane; i < total; i += 2 * kWave) {
             uint32_t k0 = 0, k1 = 0;
             const uint32_t i1 = i + kWave;
@@ -543,20 +537,6 @@ int host_offsets(const int* offsets_dev, uint32_t L, hipStream_t st, std::vector
     return NERFTEX_OK;
 }
 
-template <typename T, int D, int THREADS>
-int launch_fill(const T* grad, bool blc, const float* inputs, const int* offsets_dev, uint32_t B, uint32_t L, const LevelConsts& lc, uint32_t gridtype,
-                bool align_corners, const DirTable& dt, uint32_t* dir, Rec<T>* recs, bool merge, uint32_t nchunks, T* zero_grid, uint32_t probe,
-                hipStream_t st) {
-    constexpr int SPT = (int)kBinSamples / THREADS;
-    auto fill = blc ? bin_fill_dir_kernel<T, D, true, THREADS, SPT> : bin_fill_dir_kernel<T, D, false, THREADS, SPT>;
-    const size_t lds = sizeof(Rec<T>) * (size_t)kStageRecords;
-    NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    KernelTimer kt("bin_fill_dir_kernel", st, kTimeGrid);
-    hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), dim3(THREADS), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype, align_corners,
-                       dt, dir, recs, merge, nchunks, zero_grid, probe);
-    return NERFTEX_OK;
-}
-
 }  // namespace
 
 template <typename T, int D>
@@ -593,26 +573,21 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
     Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes);
     const bool merge = !knob(kKnobGridBwdNoMerge);
-    const uint32_t probe = (uint32_t)knob(kKnobGridBwdProbe);  // K3: low decimal digit, K4: tens
-    T* zero_grid = overwrite ? grad_grid : (T*)nullptr;
-    switch (knob(kKnobGridBwdFill)) {
-        case 2: rc = launch_fill<T, D, 512>(grad, blc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, dt, dir, recs, merge, nchunks, zero_grid, probe % 10, st); break;
-        case 4: rc = launch_fill<T, D, 256>(grad, blc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, dt, dir, recs, merge, nchunks, zero_grid, probe % 10, st); break;
-        default: rc = launch_fill<T, D, 1024>(grad, blc, inputs, offsets_dev, B, L, lc, gridtype, align_corners, dt, dir, recs, merge, nchunks, zero_grid, probe % 10, st); break;
+    const uint32_t probe = (uint32_t)knob(kKnobGridBwdProbe);
+    {
+        auto fill = blc ? bin_fill_dir_kernel<T, D, true> : bin_fill_dir_kernel<T, D, false>;
+        const size_t lds = sizeof(Rec<T>) * (size_t)kStageRecords;
+        NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+        KernelTimer kt("bin_fill_dir_kernel", st, kTimeGrid);
+        hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), dim3(kBinSamples), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype,
+                           align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr, probe);
     }
-    if (rc != NERFTEX_OK) return rc;
     if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
-    const long sum_form = knob(kKnobGridBwdSum);
-    if (sum_form == 1) {
-        auto kernel = sum_tiles_dir_wave_kernel<T>;
+    {
+        auto kernel = sum_tiles_dir_kernel<T>;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
         KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
         hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite);
-    } else {
-        auto kernel = sum_form == 4 ? sum_tiles_dir_kernel<T, 4> : sum_form == 16 ? sum_tiles_dir_kernel<T, 16> : sum_tiles_dir_kernel<T, 8>;
-        NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kRunTableBytes)), "hipFuncSetAttribute");
-        KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kRunTableBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, probe / 10);
     }
     return check_launch("grid_encode_backward(sum)");
 }

@@ -83,27 +83,13 @@ def main():
             res[st], _ = measure(**kn)
         print(json.dumps(res, indent=1))
         return
-    base_k, base = measure(grid_bwd_fill=1, grid_bwd_sum=1)
-    res["r1_fill1_sumwave"] = base_k
-    scale = float(base.float().abs().max())
-    for fill in (1, 2, 4):
-        for sm in (8, 4, 16):
-            if fill != 1 and sm != 8:
-                continue
-            k, out = measure(grid_bwd_fill=fill, grid_bwd_sum=sm)
-            diff = (out.float() - base.float()).abs()
-            k["max_abs_diff_vs_r1"] = float(diff.max())
-            k["rows_differing"] = int((diff.amax(dim=1) > 0).sum())
-            res[f"fill{fill}_sum{sm}"] = k
-    res["scale"] = scale
-    for fill in (1, 2, 4):
-        for probe in (1, 2, 3):
-            k, _ = measure(grid_bwd_fill=fill, grid_bwd_sum=8, grid_bwd_probe=probe)
-            res[f"probe_fill{fill}_k3phase{probe}"] = k.get("bin_fill")
-    for probe in (10, 20, 30):
-        k, _ = measure(grid_bwd_fill=1, grid_bwd_sum=8, grid_bwd_probe=probe)
-        res[f"probe_k4phase{probe // 10}"] = k.get("sum_tiles")
-    k, _ = measure(grid_bwd_fill=1, grid_bwd_sum=8, grid_bwd_nomerge=1)
+    res["default"], base = measure()
+    res["scale"] = float(base.float().abs().max())
+    for probe in (1, 2, 3):
+        k, _ = measure(grid_bwd_probe=probe)
+        res[f"probe_k3phase{probe}"] = k.get("bin_fill")
+    k, out = measure(grid_bwd_nomerge=1)
+    k["max_abs_diff_vs_default"] = float((out.float() - base.float()).abs().max())
     res["nomerge"] = k
     print(json.dumps(res, indent=1))
 
