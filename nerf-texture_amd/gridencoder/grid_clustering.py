@@ -9,7 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .grid import GridEncoder, grid_encode  # noqa: F401  (re-exported like the reference module)
+from .grid import GridEncoder, _grid_encode, grid_encode  # noqa: F401  (the reference module carries its own copy of both)
 
 
 class ClusteringLayer(nn.Module):

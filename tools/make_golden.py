@@ -12,6 +12,16 @@ What can be executed / evaluated there without nvcc:
                       importing the reference class with a stubbed `_gridencoder` backend.
   ffmlp_params.json   FFMLP.__init__ parameter counts (ffmlp/ffmlp.py:99-144), same mechanism.
 
+  api_signatures.json, ref_python_*.npz, ref_host_pieces.npz
+                      the reference's OWN Python (raymarching/raymarching.py, gridencoder/grid.py, grid_clustering.py,
+                      shencoder/sphere_harmonics.py, ffmlp/ffmlp.py, nerf/renderer.py, nerf/network_ff.py, tools/activation.py,
+                      tools/encoding.py) imported and RUN on the CPU: the four native modules it binds are replaced by the
+                      oracle's C restatement (oracle/backends.py), `.cuda()` by the identity, and custom_fwd's input casts are
+                      applied to CPU tensors too (they only touch CUDA tensors otherwise), so the wrappers' allocation rules,
+                      autograd plumbing, renderer control flow (run / run_cuda train + inference / update_extra_state /
+                      mark_untrained_grid) and the network's op sequence are the reference's, executed -- see
+                      reference_python_goldens().
+
 Import discipline (SURVEY.md incident): the reference wrappers fall back to a JIT build that
 hipifies sources INTO /root/reference unless the `_X` backend modules are pre-seeded, so every
 `_gridencoder/_raymarching/_shencoder/_ffmlp` (+ `turtle`) is stubbed and bytecode writing is off.
@@ -37,6 +47,68 @@ def _stub(name, **attrs):
         setattr(m, k, v)
     sys.modules[name] = m
     return m
+
+
+_installed = False
+
+
+def install_reference_imports():
+    """Put /root/reference on the path with its native modules backed by the oracle and its absent third-party imports stubbed."""
+    global _installed
+    if _installed:
+        return
+    _installed = True
+    import torch
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path.insert(0, repo)  # for `oracle` only: the drop-in packages under nerf-texture_amd/ must NOT be importable here
+    assert not any(p.rstrip("/").endswith("nerf-texture_amd") for p in sys.path)
+    from oracle import backends
+
+    sys.modules["_raymarching"] = backends.Raymarching
+    sys.modules["_gridencoder"] = backends.GridEncoder
+    sys.modules["_shencoder"] = backends.SHEncoder
+    sys.modules["_ffmlp"] = backends.FFMLP
+    _stub("turtle", backward=None, forward=None, bgcolor=None)
+    _stub("trimesh")
+    _stub("nerf.utils", custom_meshgrid=lambda *a: torch.meshgrid(*a, indexing="ij"))  # nerf/utils.py:107-112 (its other imports are absent here)
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "external", "RayTracer"))
+    # no GPU here: `.cuda()` is the identity, and custom_fwd casts CPU tensors the way it casts CUDA tensors on a GPU
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import torch.amp.autocast_mode as am
+
+    def cast_any_device(value, device_type, dtype):
+        if isinstance(value, torch.Tensor):
+            return value.to(dtype) if value.is_floating_point() and value.dtype is not torch.float64 else value
+        if isinstance(value, (str, bytes)):
+            return value
+        if isinstance(value, dict):
+            return {cast_any_device(k, device_type, dtype): cast_any_device(v, device_type, dtype) for k, v in value.items()}
+        if isinstance(value, (list, tuple)):
+            out = [cast_any_device(v, device_type, dtype) for v in value]
+            return type(value)(out) if isinstance(value, (list, tuple)) and type(value) in (list, tuple) else out
+        return value
+
+    am._cast = cast_any_device
+
+
+class emulated_autocast:
+    """`with torch.cuda.amp.autocast()` as the reference's Python sees it: is_autocast_enabled() is true (grid.py:41 then narrows the
+    table), custom_fwd(cast_inputs=...) casts; framework ops on CPU tensors are not autocast -- the ones on this path (cat, sigmoid,
+    slicing) behave the same either way."""
+
+    def __enter__(self):
+        import torch
+
+        torch.set_autocast_enabled("cuda", True)
+        torch.set_autocast_dtype("cuda", torch.float16)
+
+    def __exit__(self, *exc):
+        import torch
+
+        torch.set_autocast_enabled("cuda", False)
+        return False
 
 
 def sh_golden():
@@ -85,12 +157,7 @@ def sh_golden():
 def module_goldens():
     import torch
 
-    sys.path.insert(0, REF)
-    _stub("_gridencoder")
-    _stub("_shencoder")
-    _stub("_raymarching")
-    _stub("_ffmlp", allocate_splitk=lambda n: None, free_splitk=lambda: None)
-    _stub("turtle", backward=None, forward=None, bgcolor=None)
+    install_reference_imports()
 
     from gridencoder.grid import GridEncoder  # noqa: E402
 
@@ -173,7 +240,214 @@ def module_goldens():
     assert new == "", "files appeared under the reference tree:\n" + new
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's own Python, executed on the CPU over the oracle's kernels
+# ---------------------------------------------------------------------------------------------------------------------------
+def _scene_bitfield(bound, cascade, H=128):
+    """An analytic occupancy (a ball of radius 0.45 bound plus two blobs), Morton-ordered and packed exactly like update_extra_state does
+    (nerf/renderer.py:592-599, 648-654).  Densities take the values 0 / 5 / 40 only, so no cell sits near a threshold."""
+    import torch
+
+    import raymarching
+
+    g = torch.arange(H, dtype=torch.int32)
+    xx, yy, zz = torch.meshgrid(g, g, g, indexing="ij")
+    coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+    idx = raymarching.morton3D(coords).long()
+    unit = 2 * coords.float() / (H - 1) - 1
+    grid = torch.zeros(cascade, H ** 3)
+    for cas in range(cascade):
+        b = min(2 ** cas, bound)
+        x = unit * (b - b / H)
+        d = torch.zeros(H ** 3)
+        d[(x.norm(dim=-1) < 0.45 * bound)] = 40.0
+        d[((x - torch.tensor([0.9, 0.3, -0.2]) * bound * 0.5).norm(dim=-1) < 0.12 * bound)] = 5.0
+        d[((x - torch.tensor([-0.5, -0.8, 0.6]) * bound * 0.5).norm(dim=-1) < 0.10 * bound)] = 40.0
+        grid[cas, idx] = d
+    mean = float(grid.clamp(min=0).mean())
+    return grid, raymarching.packbits(grid, min(mean, 10.0))
+
+
+def _rays(n, seed, radius=2.6):
+    """n rays from a few look-at-origin cameras (pixel centres of an 800 x 800, fovy 50 camera), as float32 arrays."""
+    rng = np.random.default_rng(seed)
+    f = 800 / (2 * np.tan(np.radians(25)))
+    o, d = [], []
+    for k in range(n):
+        th, ph = rng.uniform(np.pi / 3, 2 * np.pi / 3), rng.uniform(0, 2 * np.pi)
+        c = radius * np.array([np.sin(th) * np.sin(ph), np.cos(th), np.sin(th) * np.cos(ph)])
+        fw = -c / np.linalg.norm(c)
+        rt = np.cross(fw, [0, -1, 0]); rt /= np.linalg.norm(rt)
+        up = np.cross(rt, fw)
+        i, j = rng.uniform(200, 600, 2)
+        v = np.array([(i - 400) / f, (j - 400) / f, 1.0])
+        w = v[0] * rt + v[1] * up + v[2] * fw
+        o.append(c); d.append(w / np.linalg.norm(w))
+    return np.asarray(o, np.float32), np.asarray(d, np.float32)
+
+
+def _table(model, seed):
+    """The hash table as the tests rebuild it: uniform(-0.5, 0.5) from torch's CPU generator (values must be O(1) for the encoding to matter)."""
+    import torch
+
+    gen = torch.Generator().manual_seed(seed)
+    model.encoder.embeddings.data.copy_(torch.rand(model.encoder.embeddings.shape, generator=gen) - 0.5)
+
+
+def reference_python_goldens():
+    import inspect
+
+    import torch
+
+    install_reference_imports()
+    import ffmlp.ffmlp as ref_ffmlp
+    import gridencoder.grid as ref_grid
+    import gridencoder.grid_clustering as ref_gc
+    import raymarching.raymarching as ref_rm
+    import shencoder.sphere_harmonics as ref_sh
+    from nerf.network_ff import NeRFNetwork
+    from nerf.renderer import NeRFRenderer, sample_pdf
+    from tools.activation import trunc_exp
+    from tools.encoding import FreqEncoder
+
+    # ---- 1. the API surface: every autograd.Function's forward, every public function / module constructor and forward
+    def sig(fn):
+        out = []
+        for n, p in inspect.signature(fn).parameters.items():
+            d = None if p.default is inspect.Parameter.empty else repr(p.default)
+            out.append([n, d])
+        return out
+
+    api = {}
+    for mod in (ref_rm, ref_grid, ref_gc, ref_sh, ref_ffmlp):
+        name = mod.__name__
+        for k, v in vars(mod).items():
+            if isinstance(v, type) and issubclass(v, torch.autograd.Function) and v.__module__ == name:
+                api[f"{name}.{k}.forward"] = sig(v.forward)
+            elif isinstance(v, type) and issubclass(v, torch.nn.Module) and v.__module__ == name:
+                api[f"{name}.{k}.__init__"] = sig(v.__init__)
+                api[f"{name}.{k}.forward"] = sig(v.forward)
+    api["public"] = {m.__name__: sorted(k for k, v in vars(m).items() if not k.startswith("_") and (callable(v)) and getattr(v, "__module__", m.__name__) in (m.__name__, "torch.autograd.function"))
+                     for m in (ref_rm, ref_grid, ref_gc, ref_sh, ref_ffmlp)}
+    json.dump(api, open(os.path.join(OUT, "api_signatures.json"), "w"), indent=1, sort_keys=True)
+    print("api_signatures.json:", len(api) - 1, "callables")
+
+    # ---- 2. small host-side pieces: trunc_exp, FreqEncoder, sample_pdf, ClusteringLayer, GridEncoder_clustering
+    torch.manual_seed(11)
+    host = {}
+    x = (torch.randn(64) * 8).requires_grad_(True)
+    y = trunc_exp(x)
+    y.backward(torch.linspace(-1, 1, 64))
+    host.update(trunc_exp_x=x.detach().numpy(), trunc_exp_y=y.detach().numpy(), trunc_exp_gx=x.grad.numpy())
+    fx = torch.rand(16, 1) * 0.1
+    host.update(freq_x=fx.numpy(), freq_y=FreqEncoder(input_dim=1, max_freq_log2=5, N_freqs=6, log_sampling=True)(fx).numpy())  # tools/map.py:229 style
+    bins = torch.sort(torch.rand(8, 33), dim=-1)[0]
+    w = torch.rand(8, 32)
+    host.update(pdf_bins=bins.numpy(), pdf_w=w.numpy(), pdf_out=sample_pdf(bins, w, 16, det=True).numpy())
+    torch.manual_seed(12)
+    layer = ref_gc.ClusteringLayer(n_clusters=6, hidden=2)
+    feats = torch.rand(40, 2) * 2e-4 - 1e-4
+    q = layer(feats)
+    host.update(cl_centers=layer.cluster_centers.detach().numpy(), cl_x=feats.numpy(), cl_q=q.detach().numpy(),
+                cl_loss=float(layer.clustering_loss(feats)))
+    torch.manual_seed(13)
+    enc = ref_gc.GridEncoder_clustering(input_dim=3, num_levels=3, level_dim=2, base_resolution=8, log2_hashmap_size=9, desired_resolution=32)
+    pts = torch.rand(50, 3) * 2 - 1
+    host.update(gc_emb=enc.embeddings.detach().numpy(), gc_offsets=enc.offsets.numpy(), gc_x=pts.numpy(), gc_y=enc(pts, bound=1).detach().numpy(),
+                gc_centers=np.stack([l.cluster_centers.detach().numpy() for l in enc.cluster_layers]),
+                gc_loss_all=float(enc.clustering_loss(pick_level=False)),
+                gc_scale=float(enc.per_level_scale))
+    np.savez_compressed(os.path.join(OUT, "ref_host_pieces.npz"), **host)
+    print("ref_host_pieces.npz:", sorted(host))
+
+    # ---- 3. the --ff network (nerf/network_ff.py) through NeRFRenderer.run_cuda: one training step and one inference render
+    bound = 2
+    torch.manual_seed(0)
+    model = NeRFNetwork(bound=bound, cuda_ray=True, min_near=0.2, density_thresh=10)
+    _table(model, 5)
+    grid, bits = _scene_bitfield(bound, model.cascade)
+    model.density_grid.copy_(grid)
+    model.density_bitfield = bits
+    ro, rd = _rays(96, 21)
+    tgt = np.random.default_rng(22).uniform(0, 1, (96, 3)).astype(np.float32)
+    out = {"bitfield": bits.numpy(), "rays_o": ro, "rays_d": rd, "target": tgt, "table_seed": 5, "bound": bound}
+    model.train()
+    with emulated_autocast():
+        res = model.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], staged=False, bg_color=1, perturb=True, force_all_rays=False,
+                           dt_gamma=1 / 128, max_steps=1024)
+        loss = torch.nn.functional.mse_loss(res["image"][0], torch.from_numpy(tgt)) * 1024.0
+    loss.backward()
+    g = model.encoder.embeddings.grad
+    nz = torch.nonzero(g.abs().sum(-1)).squeeze(-1)
+    pick = nz[torch.from_numpy(np.random.default_rng(23).choice(nz.numel(), 2048, replace=False)).long()]
+    off = model.encoder.offsets.long()
+    out.update(train_image=res["image"][0].detach().numpy(), train_depth=res["depth"][0].detach().numpy(),
+               train_counter=model.step_counter[0].numpy().copy(), train_loss=float(loss),
+               g_sigma=model.sigma_net.weights.grad.numpy(), g_color=model.color_net.weights.grad.numpy(),
+               g_table_rows=pick.numpy(), g_table_vals=g[pick].numpy(), g_table_nonzero_rows=int(nz.numel()),
+               g_table_level_abs=np.array([float(g[off[l]:off[l + 1]].abs().double().sum()) for l in range(16)]),
+               g_table_level_sum=np.array([float(g[off[l]:off[l + 1]].double().sum()) for l in range(16)]))
+    model.eval()
+    ro2, rd2 = _rays(256, 31)
+    with torch.no_grad(), emulated_autocast():
+        res = model.render(torch.from_numpy(ro2)[None], torch.from_numpy(rd2)[None], staged=False, bg_color=1, perturb=False, dt_gamma=1 / 128,
+                           max_steps=1024)
+    out.update(infer_rays_o=ro2, infer_rays_d=rd2, infer_image=res["image"][0].numpy(), infer_depth=res["depth"][0].numpy())
+    np.savez_compressed(os.path.join(OUT, "ref_python_run_cuda.npz"), **out)
+    print("ref_python_run_cuda.npz: train", int(out["train_counter"][0]), "samples /", int(out["train_counter"][1]), "rays; loss", out["train_loss"])
+
+    # ---- 4. the same network through NeRFRenderer.run (cuda_ray=False: uniform samples, sample_pdf upsampling, cumprod compositing)
+    torch.manual_seed(0)
+    m2 = NeRFNetwork(bound=bound, cuda_ray=False, min_near=0.2, density_thresh=10)
+    _table(m2, 5)
+    m2.eval()
+    ro3, rd3 = _rays(48, 41)
+    with torch.no_grad(), emulated_autocast():
+        r0 = m2.render(torch.from_numpy(ro3)[None], torch.from_numpy(rd3)[None], staged=False, bg_color=1, perturb=False, num_steps=64, upsample_steps=32)
+        r1 = m2.render(torch.from_numpy(ro3)[None], torch.from_numpy(rd3)[None], staged=False, bg_color=1, perturb=False, num_steps=96, upsample_steps=0)
+    np.savez_compressed(os.path.join(OUT, "ref_python_run.npz"), rays_o=ro3, rays_d=rd3, table_seed=5, bound=bound,
+                        image_64_32=r0["image"][0].numpy(), depth_64_32=r0["depth"][0].numpy(), image_96_0=r1["image"][0].numpy(),
+                        depth_96_0=r1["depth"][0].numpy())
+    print("ref_python_run.npz: 48 rays, (64+32) and (96+0) samples")
+
+    # ---- 5. occupancy maintenance on an analytic density: mark_untrained_grid, two full updates, two partial updates
+    class Analytic(NeRFRenderer):
+        def density(self, x):
+            s = torch.zeros(x.shape[0])
+            s[x.norm(dim=-1) < 0.9] = 40.0
+            s[(x - torch.tensor([1.1, 0.4, -0.3])).norm(dim=-1) < 0.35] = 5.0
+            s[(x - torch.tensor([-0.7, -1.2, 0.8])).norm(dim=-1) < 0.3] = 40.0
+            return {"sigma": s}
+
+    r = Analytic(bound=bound, cuda_ray=True, min_near=0.2, density_thresh=10)
+    po, pd = _rays(6, 51, radius=3.0)
+    poses = np.tile(np.eye(4, dtype=np.float32), (6, 1, 1))
+    for k in range(6):  # c2w with the camera looking along +z at the origin (mark_untrained_grid keeps points with z_cam > 0)
+        fw = -po[k] / np.linalg.norm(po[k])
+        rt = np.cross(fw, [0, -1, 0]); rt /= np.linalg.norm(rt)
+        poses[k, :3, 0], poses[k, :3, 1], poses[k, :3, 2], poses[k, :3, 3] = rt, np.cross(fw, rt), fw, po[k]
+    intr = np.array([300.0, 300.0, 200.0, 200.0], np.float32)  # fx fy cx cy: a narrow camera, so that part of the volume stays unseen
+    torch.manual_seed(7)
+    r.mark_untrained_grid(poses, intr)
+    states = {"poses": poses, "intrinsic": intr, "untrained": np.packbits((r.density_grid < 0).numpy().reshape(-1), bitorder="little")}
+    probe = np.random.default_rng(52).choice(r.density_grid.numel(), 8192, replace=False)
+    states["probe"] = probe
+    for step in range(4):
+        if step == 2:
+            r.iter_density = 16  # from here on update_extra_state takes its partial-update branch
+        r.local_step, r.step_counter[:5, 0] = 5, torch.tensor([700, 720, 690, 710, 705], dtype=torch.int32)
+        r.update_extra_state()
+        states[f"grid_probe_{step}"] = r.density_grid.reshape(-1).numpy()[probe].copy()
+        states[f"grid_sum_{step}"] = float(r.density_grid.double().sum())
+        states[f"bitfield_{step}"] = r.density_bitfield.numpy().copy()
+        states[f"mean_density_{step}"] = r.mean_density
+        states[f"mean_count_{step}"] = r.mean_count
+    np.savez_compressed(os.path.join(OUT, "ref_python_extra_state.npz"), **states)
+    print("ref_python_extra_state.npz: mean densities", [round(states[f"mean_density_{k}"], 5) for k in range(4)], "mean_count", states["mean_count_3"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     sh_golden()
     module_goldens()
+    reference_python_goldens()
