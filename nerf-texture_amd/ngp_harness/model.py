@@ -142,6 +142,86 @@ class Renderer(nn.Module):
         thresh = min(self.mean_density, self.density_thresh)
         self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
 
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """nerf/renderer.py:502-559: cells no training camera sees get density -1 (never marched, never updated).
+        poses [B,4,4] camera-to-world, intrinsic (fx, fy, cx, cy)."""
+        if not torch.is_tensor(poses):
+            poses = torch.as_tensor(poses)
+        dev, H = self.density_grid.device, self.grid_size
+        poses = poses.to(dev)
+        fx, fy, cx, cy = (float(v) for v in intrinsic)
+        count = torch.zeros_like(self.density_grid)
+        axis = torch.arange(H, dtype=torch.int32, device=dev).split(S)
+        for xs in axis:
+            for ys in axis:
+                for zs in axis:
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                    indices = raymarching.morton3D(coords).long()
+                    world = (2 * coords.float() / (H - 1) - 1).unsqueeze(0)
+                    for cas in range(self.cascade):
+                        bound = min(2 ** cas, self.bound)
+                        half_grid = bound / H
+                        cas_world = world * (bound - half_grid)
+                        for head in range(0, poses.shape[0], S):
+                            p = poses[head:head + S]
+                            cam = (cas_world - p[:, :3, 3].unsqueeze(1)) @ p[:, :3, :3]
+                            mask = (cam[:, :, 2] > 0) & (cam[:, :, 0].abs() < cx / fx * cam[:, :, 2] + half_grid * 2) \
+                                & (cam[:, :, 1].abs() < cy / fy * cam[:, :, 2] + half_grid * 2)
+                            count[cas, indices] += mask.sum(0).reshape(-1)
+        self.density_grid[count == 0] = -1
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128, force_full_update=False, force_full_grid=False, cpu_rng=False):
+        """nerf/renderer.py:566-660: re-estimate the occupancy grid (full sweep for the first 16 calls, then N = H^3/4 random cells + as
+        many already-occupied ones per cascade), EMA-max it into density_grid, re-pack the bitfield, refresh mean_count.
+        cpu_rng: draw the jitter / cell picks from torch's CPU generator in the reference's order (what the reference does when it runs
+        on the CPU; used to compare against its fixtures) instead of the device generator."""
+        dev, H = self.density_grid.device, self.grid_size
+        rdev = "cpu" if cpu_rng else dev
+        tmp_grid = -torch.ones_like(self.density_grid)
+
+        def query(coords, cas):
+            xyzs = 2 * coords.float() / (H - 1) - 1
+            bound = min(2 ** cas, self.bound)
+            half_grid = bound / H
+            cas_xyzs = xyzs * (bound - half_grid)
+            cas_xyzs += ((torch.rand(cas_xyzs.shape, device=rdev) * 2 - 1) * half_grid).to(dev)
+            sigmas = self.field.density(cas_xyzs)["sigma"].reshape(-1).detach().float()
+            return sigmas * self.density_scale
+
+        if self.iter_density < 16 or force_full_update:
+            axis = torch.arange(H, dtype=torch.int32, device=dev).split(S)
+            for xs in axis:
+                for ys in axis:
+                    for zs in axis:
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                        indices = raymarching.morton3D(coords).long()
+                        for cas in range(self.cascade):
+                            tmp_grid[cas, indices] = query(coords, cas)
+        else:
+            N = H ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, H, (N, 3), device=rdev).to(dev)
+                indices = raymarching.morton3D(coords).long()
+                occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                if occ.shape[0] > 0:
+                    pick = torch.randint(0, occ.shape[0], [N], dtype=torch.long, device=rdev).to(dev)
+                    occ = occ[pick]
+                    indices = torch.cat([indices, occ], dim=0)
+                    coords = torch.cat([coords, raymarching.morton3D_invert(occ)], dim=0)
+                tmp_grid[cas, indices] = query(coords, cas)
+        valid = (self.density_grid >= 0) & (tmp_grid >= 0)
+        if force_full_grid:
+            valid = torch.ones_like(valid)
+        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp_grid[valid])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
+        self.update_mean_count()
+
     def commit_counter(self, counter):
         """Ring bookkeeping for a step that ran with a caller-owned counter (graph replay)."""
         self.step_counter[self.local_step % 16].copy_(counter)

@@ -393,6 +393,16 @@ def reference_python_goldens():
         res = model.render(torch.from_numpy(ro2)[None], torch.from_numpy(rd2)[None], staged=False, bg_color=1, perturb=False, dt_gamma=1 / 128,
                            max_steps=1024)
     out.update(infer_rays_o=ro2, infer_rays_d=rd2, infer_image=res["image"][0].numpy(), infer_depth=res["depth"][0].numpy())
+    # march_rays_train_differentiable (raymarching.py:238-287): forward + its Python backward, on the first 24 training rays
+    o24 = torch.from_numpy(ro[:24]).requires_grad_(True)
+    d24 = torch.from_numpy(rd[:24]).requires_grad_(True)
+    n24, f24 = ref_rm.near_far_from_aabb(o24.detach(), d24.detach(), model.aabb_train, 0.2)
+    cnt = torch.zeros(2, dtype=torch.int32)
+    xyzs, dirs, deltas, rays24 = ref_rm.march_rays_train_differentiable(o24, d24, bound, bits, model.cascade, 128, n24, f24, cnt, -1, False, 128, False, 1 / 128, 64)
+    gx = torch.from_numpy(np.random.default_rng(24).standard_normal(tuple(xyzs.shape)).astype(np.float32))
+    xyzs.backward(gx)
+    out.update(diff_max_steps=64, diff_grad_xyzs=gx.numpy(), diff_counter=cnt.numpy().copy(), diff_rays=rays24.numpy(), diff_xyzs=xyzs.detach().numpy(),
+               diff_grad_o=o24.grad.numpy(), diff_grad_d=d24.grad.numpy())
     np.savez_compressed(os.path.join(OUT, "ref_python_run_cuda.npz"), **out)
     print("ref_python_run_cuda.npz: train", int(out["train_counter"][0]), "samples /", int(out["train_counter"][1]), "rays; loss", out["train_loss"])
 
@@ -426,7 +436,7 @@ def reference_python_goldens():
         fw = -po[k] / np.linalg.norm(po[k])
         rt = np.cross(fw, [0, -1, 0]); rt /= np.linalg.norm(rt)
         poses[k, :3, 0], poses[k, :3, 1], poses[k, :3, 2], poses[k, :3, 3] = rt, np.cross(fw, rt), fw, po[k]
-    intr = np.array([300.0, 300.0, 200.0, 200.0], np.float32)  # fx fy cx cy: a narrow camera, so that part of the volume stays unseen
+    intr = np.array([900.0, 900.0, 150.0, 150.0], np.float32)  # fx fy cx cy: narrow cameras (+-9.5 degrees), so that part of the volume stays unseen
     torch.manual_seed(7)
     r.mark_untrained_grid(poses, intr)
     states = {"poses": poses, "intrinsic": intr, "untrained": np.packbits((r.density_grid < 0).numpy().reshape(-1), bitorder="little")}
