@@ -71,74 +71,70 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(args, sc, bits, field_state, n_rays):
-    """The oracle port of ONE training step (forward + backward) on the host, single thread, on a bounded sample.
+def cpu_baseline(args, bits, n_rays):
+    """The reference's path on the host's cores, as SURVEY.md 8(d) defines it (oracle/cpu_path.py, pinned against the reference's own
+    Python by tests/test_reference_python_cpu.py), each leg on a BOUNDED sample of the workload:
 
-    R1 + R6 + G1 + MLPs + S1 + R8 forward, R9 + MLP + G2 backward: oracle C for every op the reference implements
-    natively, torch-CPU (1 thread) autograd for the two small MLPs (the reference's "MLP still PyTorch")."""
+      value            one training step of the --cuda_ray path (R1 + R6 march, G1, MLPs, S1, R8, loss, R9, MLP backward, G2; no optimizer):
+                       oracle C (OpenMP over samples / rays / levels) for every native op + torch-CPU nn.Linear MLPs, ALL host threads;
+      one_thread       the same on one thread;
+      run_path         BASELINE.json configs[0], "the reference's pure-PyTorch CPU path": NeRFRenderer.run semantics (512 uniform samples per
+                       ray, exp / cumprod compositing, main_nerf.py:29-30 defaults) on rays of a 400 x 400 view, inference, all threads."""
     from ngp_harness import scene
+    from oracle import cpu_path
     from oracle import oracle as orc
 
-    torch.set_num_threads(1)
-    o, d = scene.train_batch(n_rays, seed=1234)
+    cores = os.cpu_count() or 1
     b = args.bound
-    aabb = np.array([-b, -b, -b, b, b, b], np.float32)
-    emb = field_state["emb"]
-    offsets = field_state["offsets"]
-    S = field_state["S"]
-    sig_w = [torch.from_numpy(w) for w in field_state["sigma_w"]]
-    col_w = [torch.from_numpy(w) for w in field_state["color_w"]]
-    cascade = sc.cascade
+    field = cpu_path.Field(bound=b, mlp="linear")  # nerf/network.py: bias-free nn.Linear MLPs, fp32 ("MLP still PyTorch")
+    r = cpu_path.Renderer(field, bound=b, min_near=0.2)
+    r.density_bitfield = torch.from_numpy(np.ascontiguousarray(bits))
+    o, d = scene.train_batch(n_rays, seed=1234)
+    ro, rd = torch.from_numpy(o), torch.from_numpy(d)
 
-    def step():
-        nears, fars = orc.near_far_from_aabb(o, d, aabb, 0.2)
-        xyzs, dirs, deltas, rays, counter, _ = orc.march_rays_train(o, d, b, bits, cascade, 128, nears, fars, n_rays * 1024, True, 1 / 128, 1024)
-        m = int(counter[0])
-        m_pad = m + 128 - m % 128
-        xyzs, dirs, deltas = xyzs[:m_pad], dirs[:m_pad], deltas[:m_pad]
-        x01 = (xyzs + b) / (2 * b)
-        feat_lbc, _ = orc.grid_encode_forward(x01, emb, offsets, S, 16, False, 0, True)
-        feat = torch.from_numpy(np.ascontiguousarray(feat_lbc.transpose(1, 0, 2).reshape(m_pad, -1))).requires_grad_(True)
-        sh, _ = orc.sh_encode_forward(dirs, 4)
-        ws_ = [w.clone().requires_grad_(True) for w in sig_w + col_w]
-        h = feat
-        for i, w in enumerate(ws_[: len(sig_w)]):
-            h = h @ w.t()
-            if i != len(sig_w) - 1:
-                h = torch.relu(h)
-        sigma = torch.exp(h[:, 0])
-        hc = torch.cat([torch.from_numpy(sh), h[:, 1:]], dim=-1)
-        for i, w in enumerate(ws_[len(sig_w):]):
-            hc = hc @ w.t()
-            if i != len(col_w) - 1:
-                hc = torch.relu(hc)
-        rgb = torch.sigmoid(hc)
-        sg, cg = sigma.detach().numpy(), rgb.detach().numpy()
-        wsum, depth, image = orc.composite_rays_train_forward(sg, cg, deltas, rays)
-        pred = image + (1 - wsum)[:, None]
-        g_img = (2.0 / pred.size) * (pred - 0.5)
-        g_ws = -g_img.sum(-1)
-        gs, gc = orc.composite_rays_train_backward(g_ws.astype(np.float32), g_img.astype(np.float32), sg, cg, deltas, rays, wsum, image)
-        torch.autograd.backward([sigma, rgb], [torch.from_numpy(gs), torch.from_numpy(gc)])
-        g_lbc = np.ascontiguousarray(feat.grad.numpy().reshape(m_pad, 16, 2).transpose(1, 0, 2))
-        orc.grid_encode_backward(g_lbc, x01, emb.shape[0], offsets, S, 16, 0, True)
-        return m
+    def train_step():
+        field.zero_grad(set_to_none=True)
+        image, _, counter = r.run_cuda_train(ro, rd, dt_gamma=1 / 128, perturb=True)
+        torch.nn.functional.mse_loss(image, torch.full_like(image, 0.5)).backward()
+        return int(counter[0])
 
-    step()  # warm caches / page in the table
-    t0 = time.perf_counter()
-    total, reps = 0, 0
-    while time.perf_counter() - t0 < 10.0 and reps < 50:
-        total += step()
-        reps += 1
-    dt = time.perf_counter() - t0
-    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    def timed(fn, budget_s, max_reps):
+        fn()  # warm caches / page in the table
+        t0, total, reps = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < budget_s and reps < max_reps:
+            total += fn()
+            reps += 1
+        return total / (time.perf_counter() - t0), total // max(reps, 1), reps
+
+    legs = {}
+    for name, threads, budget in (("all", cores, 8.0), ("one", 1, 6.0)):
+        torch.set_num_threads(threads)
+        orc.set_threads(threads)
+        legs[name] = timed(train_step, budget, 50)
+    torch.set_num_threads(cores)
+    orc.set_threads(cores)
+    field.eval()
+    pose = scene.rand_poses(1, 2.0, np.random.default_rng(7))[0]
+    o4, d4 = scene.get_rays(pose, scene.intrinsics(400, 400), 400, 400)
+    n_run = 8192  # rows 190..210 of the 400 x 400 view: rays through the middle of the scene
+    sl = slice(190 * 400, 190 * 400 + n_run)
+    r4o, r4d = torch.from_numpy(np.ascontiguousarray(o4[sl])), torch.from_numpy(np.ascontiguousarray(d4[sl]))
+
+    def run_frame_part():
+        with torch.no_grad():
+            return r.run(r4o, r4d, num_steps=512, upsample_steps=0)[2]
+
+    run_rate, run_samples, run_reps = timed(run_frame_part, 8.0, 20)
+    torch.set_num_threads(max(1, cores // 2))
     return {
-        "value": total / dt,
-        "unit": "ray-samples/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{reps} training steps (fwd+bwd, no optimizer) of {n_rays} rays / ~{total // max(reps, 1)} samples each, oracle C + 1-thread torch MLPs, "
-                  f"host has {os.cpu_count()} hardware threads",
+        "value": legs["all"][0], "unit": "ray-samples/s", "cores": cores, "kind": "port",
+        "sample": f"{legs['all'][2]} training steps (forward + backward, no optimizer) of {n_rays} rays / ~{legs['all'][1]} marched samples each; "
+                  f"oracle C with OpenMP + torch-CPU nn.Linear MLPs on all {cores} hardware threads of the host",
+        "one_thread": {"value": legs["one"][0], "cores": 1, "sample": f"{legs['one'][2]} of the same steps on one thread"},
+        "run_path": {"value": run_rate, "unit": "ray-samples/s", "cores": cores, "workload": "BASELINE.json configs[0]: NeRFRenderer.run semantics, "
+                     "512 uniform samples per ray, nn.Linear MLPs, 400x400 view, inference", "sample": f"{run_reps} x {n_run} rays of the view "
+                     f"({run_samples} samples each); a whole 400 x 400 frame is {160000 * 512} samples",
+                     "s_per_400x400_frame": 160000 * 512 / run_rate},
     }
 
 
@@ -479,15 +475,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.mlp == "torch":
-            layers = lambda net: [l.weight.detach().float().cpu().numpy() for l in net]  # noqa: E731
-            sw, cw = layers(field.sigma_net), layers(field.color_net)
-        else:  # same layer shapes as the nn.Linear variant; values are irrelevant for timing
-            sw = [np.zeros((64, 32), np.float32), np.zeros((16, 64), np.float32)]
-            cw = [np.zeros((64, 31), np.float32), np.zeros((64, 64), np.float32), np.zeros((3, 64), np.float32)]
-        state = dict(emb=field.encoder.embeddings.detach().float().cpu().numpy(), offsets=field.encoder.offsets.cpu().numpy(),
-                     S=float(np.log2(field.encoder.per_level_scale)), sigma_w=sw, color_w=cw)
-        cpu = cpu_baseline(args, sc, bits, state, args.cpu_rays)
+        cpu = cpu_baseline(args, bits, args.cpu_rays)
 
     if rank == 0:
         out = {

@@ -40,6 +40,15 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle's loops over independent samples / rays / levels (the results do not depend on it)."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

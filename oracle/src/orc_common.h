@@ -27,6 +27,10 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* number of OpenMP threads the loops over independent samples / rays / levels use (results do not depend on it) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
 #endif
 
 /* IEEE binary16 <-> binary32, round-to-nearest-even (what __half conversion does) */
@@ -93,6 +97,10 @@ static inline uint16_t orc_f2h(float f) {
 }
 
 static inline float orc_clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+/* number of OpenMP threads of the loops over independent samples / rays / levels (results do not depend on it) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 
 #ifdef __cplusplus
 }

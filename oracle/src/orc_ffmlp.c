@@ -19,6 +19,8 @@
  * test exists for this path).
  */
 #include "orc_common.h"
+
+#define ORC_MAX_WIDTH 256 /* widest layer the reference supports (ffmlp.py:111) */
 #include <stdlib.h>
 
 #define K_ACT 10.0f /* utils.h:41 */
@@ -57,8 +59,9 @@ static void dense(const uint16_t* x, const uint16_t* W, uint16_t* y, uint32_t B,
                   uint32_t act) {
     float* wf = (float*)malloc(sizeof(float) * in * out);
     for (size_t i = 0; i < (size_t)in * out; i++) wf[i] = orc_h2f(W[i]);
-    float* xf = (float*)malloc(sizeof(float) * in);
+#pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++) {
+        float xf[ORC_MAX_WIDTH];
         for (uint32_t i = 0; i < in; i++) xf[i] = orc_h2f(x[(size_t)b * in + i]);
         for (uint32_t o = 0; o < out; o++) {
             double acc = 0.0;
@@ -68,7 +71,6 @@ static void dense(const uint16_t* x, const uint16_t* W, uint16_t* y, uint32_t B,
         }
     }
     free(wf);
-    free(xf);
 }
 
 /* F1 / F3.  forward_buffer may be NULL (inference). */
@@ -99,8 +101,9 @@ static void dense_T(const uint16_t* dy, const uint16_t* W, const uint16_t* fwd, 
                     uint32_t in, uint32_t out, uint32_t act) {
     float* wf = (float*)malloc(sizeof(float) * in * out);
     for (size_t i = 0; i < (size_t)in * out; i++) wf[i] = orc_h2f(W[i]);
-    double* acc = (double*)malloc(sizeof(double) * in);
+#pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++) {
+        double acc[ORC_MAX_WIDTH];
         for (uint32_t i = 0; i < in; i++) acc[i] = 0.0;
         for (uint32_t o = 0; o < out; o++) {
             const double g = (double)orc_h2f(dy[(size_t)b * out + o]);
@@ -114,14 +117,14 @@ static void dense_T(const uint16_t* dy, const uint16_t* W, const uint16_t* fwd, 
         }
     }
     free(wf);
-    free(acc);
 }
 
 /* dW[o,i] = half( sum_b dy[b,o] x[b,i] ) */
 static void wgrad(const uint16_t* dy, const uint16_t* x, uint16_t* dW, uint32_t B, uint32_t in, uint32_t out) {
     double* acc = (double*)calloc((size_t)in * out, sizeof(double));
-    for (uint32_t b = 0; b < B; b++)
-        for (uint32_t o = 0; o < out; o++) {
+#pragma omp parallel for schedule(static) /* an output row per iteration: every sum keeps its batch order */
+    for (uint32_t o = 0; o < out; o++)
+        for (uint32_t b = 0; b < B; b++) {
             const double g = (double)orc_h2f(dy[(size_t)b * out + o]);
             if (g == 0.0) continue;
             for (uint32_t i = 0; i < in; i++) acc[(size_t)o * in + i] += g * (double)orc_h2f(x[(size_t)b * in + i]);

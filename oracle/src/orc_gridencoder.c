@@ -67,6 +67,7 @@ void orc_grid_encode_forward(const float* inputs, const void* embeddings, const 
         uint32_t resolution;
         level_consts(level, S, H, &scale, &resolution);
 
+#pragma omp parallel for schedule(static)
         for (uint32_t b = 0; b < B; b++) {
             const float* x = inputs + (size_t)b * D;
             const size_t out_off = ((size_t)level * B + b) * C;
@@ -151,6 +152,7 @@ void orc_grid_encode_forward(const float* inputs, const void* embeddings, const 
 void orc_grid_encode_backward(const void* grad, const float* inputs, const int32_t* offsets,
                               double* grad_embeddings_f64, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                               float S, uint32_t H, uint32_t gridtype, int align_corners, int half_mode) {
+#pragma omp parallel for schedule(dynamic, 1) /* levels own disjoint rows; inside a level the sum keeps its sample order */
     for (uint32_t level = 0; level < L; level++) {
         const size_t base = (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
@@ -199,6 +201,7 @@ void orc_grid_encode_backward(const void* grad, const float* inputs, const int32
 /* G3: gridencoder.cu:317-343.  grad [L,B,C], dy_dx [B,L,D,C] -> grad_inputs [B,D] */
 void orc_grid_input_backward(const void* grad, const void* dy_dx, void* grad_inputs, uint32_t B, uint32_t D,
                              uint32_t C, uint32_t L, int half_mode) {
+#pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++)
         for (uint32_t d = 0; d < D; d++) {
             float result = 0;

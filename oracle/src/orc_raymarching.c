@@ -108,6 +108,7 @@ void orc_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords) {
 /* ------------------------------ R1 / R2 / R5 ----------------------------- */
 void orc_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
                             float min_near, float* nears, float* fars) {
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < N; n++) {
         const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
         const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
@@ -131,6 +132,7 @@ void orc_near_far_from_aabb(const float* rays_o, const float* rays_d, const floa
 }
 
 void orc_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords) {
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < N; n++) {
         const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
         const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
@@ -147,6 +149,7 @@ void orc_polar_from_ray(const float* rays_o, const float* rays_d, float radius, 
 }
 
 void orc_packbits(const float* grid, uint32_t N, float thresh, uint8_t* bitfield) {
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < N; n++) {
         uint8_t bits = 0;
         for (int i = 0; i < 8; i++) bits |= (grid[(size_t)n * 8 + i] > thresh) ? (uint8_t)(1u << i) : 0;
@@ -286,6 +289,7 @@ void orc_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
 void orc_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                       const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
                                       float* depth, float* image) {
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < N; n++) {
         const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
                        num_steps = (uint32_t)rays[n * 3 + 2];
@@ -320,6 +324,7 @@ void orc_composite_rays_train_backward(const float* grad_weights_sum, const floa
                                        const float* sigmas, const float* rgbs, const float* deltas,
                                        const int32_t* rays, const float* weights_sum, const float* image,
                                        uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs) {
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < N; n++) {
         const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
                        num_steps = (uint32_t)rays[n * 3 + 2];
@@ -359,6 +364,7 @@ void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive
                     uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                     float* xyzs, float* dirs, float* deltas, uint32_t perturb) {
     (void)nears;
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < n_alive; n++) {
         const int index = rays_alive[n];
         float t = rays_t[n];
@@ -395,6 +401,7 @@ void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive
 void orc_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
                         const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
                         float* depth, float* image) {
+#pragma omp parallel for schedule(static)
     for (uint32_t n = 0; n < n_alive; n++) {
         const int index = rays_alive[n];
         float t = rays_t[n];

@@ -35,6 +35,7 @@ static float tri_hit(v3 a, v3 b, v3 c, v3 ro, v3 rd) {
 /* second_best[n] = smallest t among the OTHER triangles (1e6 if none): lets tests skip ambiguous (tied) rays */
 void orc_raytrace(const float* vertices, const uint32_t* triangles, uint32_t n_triangles, const float* rays_o, const float* rays_d,
                   uint32_t N, float* positions, float* normals, float* depth, int64_t* face_idx, float* second_best) {
+#pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < N; i++) {
         const v3 ro = {rays_o[3 * (size_t)i], rays_o[3 * (size_t)i + 1], rays_o[3 * (size_t)i + 2]};
         const v3 rd = {rays_d[3 * (size_t)i], rays_d[3 * (size_t)i + 1], rays_d[3 * (size_t)i + 2]};
@@ -68,3 +69,8 @@ void orc_raytrace(const float* vertices, const uint32_t* triangles, uint32_t n_t
         }
     }
 }
+
+/* ---- thread control (OpenMP) ------------------------------------------------------------------ */
+#include <omp.h>
+void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int orc_get_threads(void) { return omp_get_max_threads(); }

@@ -52,6 +52,7 @@ void orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint
     double P[SH_MAXL][SH_MAXL];
     legendre_coeffs(P);
     const uint32_t C2 = C * C;
+#pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++) {
         const double x = inputs[(size_t)b * D], y = inputs[(size_t)b * D + 1], z = inputs[(size_t)b * D + 2];
         /* (x+iy)^m = cm[m] + i sm[m] */
@@ -108,6 +109,7 @@ void orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint
 void orc_sh_encode_backward(const float* grad, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx,
                             float* grad_inputs) {
     const uint32_t C2 = C * C;
+#pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++)
         for (uint32_t d = 0; d < D; d++) {
             float acc = grad_inputs[(size_t)b * D + d];
