@@ -48,6 +48,42 @@ class HalfLeafAdam(torch.optim.Optimizer):
         """The tensors whose `.grad` the backward pass fills (what a gradient all-reduce has to cover)."""
         return list(self.leaves)
 
+    @torch.no_grad()
+    def resync(self):
+        """Re-derive the fp16 leaves from the fp32 masters: after `load_state_dict` on the owning modules (a checkpoint) the kernels
+        would otherwise keep reading the old copies."""
+        for master, leaf in zip(self.masters, self.leaves):
+            leaf.copy_(master)
+
+    def state_dict(self):
+        """torch.optim.Adam's layout (state: {index: {step, exp_avg, exp_avg_sq}}, param_groups), so that a checkpoint written here
+        loads into `torch.optim.Adam` over the fp32 parameters and vice versa (nerf/utils.py:1505, 1581-1586)."""
+        step = self.step_count.detach().clone()
+        return {"state": {i: {"step": step.clone(), "exp_avg": self.exp_avg[i].detach().clone(), "exp_avg_sq": self.exp_avg_sq[i].detach().clone()}
+                          for i in range(len(self.masters))},
+                "param_groups": [{**{k: v for k, v in self.param_groups[0].items() if k != "params"}, "params": list(range(len(self.masters)))}]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        state = sd["state"]
+        if len(state) not in (0, len(self.masters)):
+            raise ValueError(f"loaded state has {len(state)} parameters, this optimizer {len(self.masters)}")
+        for i in range(len(self.masters)):
+            st = state.get(i, state.get(str(i))) if state else None
+            if st is None:
+                self.exp_avg[i].zero_()
+                self.exp_avg_sq[i].zero_()
+                continue
+            self.exp_avg[i].copy_(st["exp_avg"])
+            self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
+            self.step_count.fill_(float(st["step"]))
+        if not state:
+            self.step_count.zero_()
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        self.resync()
+
     def _launch(self, step_offset, grad_scale, found_inf, amp=None):
         """One launch over every leaf that has a gradient.  amp = (scale, growth_tracker, found_inf, ticket, growth, backoff, interval):
         the loss scaler's update rides along (step number *step_count + 1; the launch advances step_count itself)."""
@@ -105,6 +141,16 @@ class FusedAmp:
 
     def scale_loss(self, loss):
         return loss * self.scale
+
+    def state_dict(self):
+        """torch.amp.GradScaler.state_dict()'s keys (what the reference trainer saves as 'scaler', nerf/utils.py:1507)."""
+        return {"scale": float(self.scale.item()), "growth_factor": self.consts[0], "backoff_factor": self.consts[1], "growth_interval": self.consts[2],
+                "_growth_tracker": int(self.growth_tracker.item())}
+
+    def load_state_dict(self, sd):
+        self.scale.fill_(float(sd["scale"]))
+        self.growth_tracker.fill_(int(sd["_growth_tracker"]))
+        self.consts = (float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"]))
 
     def get_scale(self):
         return float(self.scale.item())

@@ -208,3 +208,53 @@ def test_amp_check_and_update_follow_gradscaler_rules(dev):
         assert found.item() == 0.0
         assert scale.item() == ref._scale.item() and tracker.item() == ref._growth_tracker.item()
         assert step.item() == good
+
+
+def test_half_leaf_adam_checkpoint_resume_is_bit_identical(dev, knobs):
+    """optimizer.state_dict() / load_state_dict() of HalfLeafAdam + FusedAmp (what the reference trainer saves as 'optimizer' and
+    'scaler', nerf/utils.py:1505-1507): 6 steps == 3 steps, save, fresh objects, load (masters through load_state_dict on the modules,
+    moments / step / scale through the optimizer and scaler), 3 more steps.  The state has torch.optim.Adam's layout and loads into it."""
+    from ffmlp import FFMLP
+    from gridencoder import GridEncoder
+    from ngp_harness.optim import FusedAmp, HalfLeafAdam
+
+    knobs(grid_bwd=2)
+    torch.manual_seed(5)
+    x = torch.rand(4096, 3, device=dev) * 2 - 1
+    y = torch.rand(4096, 3, device=dev)
+
+    def make():
+        torch.manual_seed(3)
+        enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=12, desired_resolution=128).to(dev)
+        net = FFMLP(input_dim=16, output_dim=3, hidden_dim=64, num_layers=2).to(dev)
+        enc.train(), net.train()
+        opt = HalfLeafAdam([(enc, "embeddings"), (net, "weights")], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        return enc, net, opt, FusedAmp(opt, init_scale=2.0 ** 20, growth_interval=2)
+
+    def steps(enc, net, opt, amp, n):
+        for _ in range(n):
+            for t in opt.trainable():
+                t.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = torch.nn.functional.mse_loss(net(enc(x, bound=1)).float(), y)
+            amp.scale_loss(loss).backward()
+            amp.step()
+
+    a = make()
+    steps(*a, 6)
+    b = make()
+    steps(*b, 3)
+    saved = {"enc": b[0].state_dict(), "net": b[1].state_dict(), "optimizer": b[2].state_dict(), "scaler": b[3].state_dict()}
+    assert sorted(saved["optimizer"]["state"][0]) == ["exp_avg", "exp_avg_sq", "step"] and float(saved["optimizer"]["state"][0]["step"]) > 0
+    c = make()
+    c[0].load_state_dict(saved["enc"])
+    c[1].load_state_dict(saved["net"])
+    c[2].load_state_dict(saved["optimizer"])  # also re-derives the fp16 leaves the kernels read from the loaded masters
+    c[3].load_state_dict(saved["scaler"])
+    assert torch.equal(c[2].leaves[0], c[0].embeddings.detach().half())
+    steps(*c, 3)
+    assert torch.equal(a[0].embeddings, c[0].embeddings) and torch.equal(a[1].weights, c[1].weights)
+    assert a[3].get_scale() == c[3].get_scale() and torch.equal(a[2].step_count, c[2].step_count)
+    ref = torch.optim.Adam([b[0].embeddings, b[1].weights], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ref.load_state_dict(saved["optimizer"])
+    assert torch.equal(ref.state[b[0].embeddings]["exp_avg"], saved["optimizer"]["state"][0]["exp_avg"])

@@ -154,6 +154,46 @@ def sh_golden():
     print("sh_golden.npz: 64 basis + 3x64 derivative polynomials on", B, "points")
 
 
+def checkpoint_roundtrip():
+    """N2, both directions, with the REAL reference class: a checkpoint written like Trainer.save_checkpoint (nerf/utils.py:1485-1523)
+    from a reference NeRFNetwork is loaded by the drop-in harness in a child process (tools/ckpt_roundtrip_child.py: the two sets of
+    same-named packages cannot share an interpreter), every tensor compared, written back by the harness, and loaded here with
+    load_state_dict(strict=True) into a fresh reference network.  The record goes into checkpoint_keys.json."""
+    import subprocess
+    import tempfile
+
+    import torch
+
+    install_reference_imports()
+    from nerf.network_ff import NeRFNetwork
+
+    torch.manual_seed(3)
+    model = NeRFNetwork(bound=2, cuda_ray=True, min_near=0.2, density_thresh=10)
+    with torch.no_grad():
+        model.encoder.embeddings.uniform_(-1, 1)
+        model.density_grid.uniform_(0, 20)
+        model.density_bitfield.random_(0, 256)
+        model.step_counter.random_(0, 5000)
+    model.mean_count, model.mean_density = 4321, 1.25
+    state = {"epoch": 7, "global_step": 1234, "stats": {"loss": [0.5], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None},
+             "mean_count": model.mean_count, "mean_density": model.mean_density, "model": model.state_dict()}
+    with tempfile.TemporaryDirectory() as tmp:
+        a, b = os.path.join(tmp, "ref.pth"), os.path.join(tmp, "dropin.pth")
+        torch.save(state, a)
+        env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ckpt_roundtrip_child.py"), a, b], env=env,
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        back = torch.load(b, weights_only=False)
+        torch.manual_seed(4)
+        fresh = NeRFNetwork(bound=2, cuda_ray=True, min_near=0.2, density_thresh=10)
+        res = fresh.load_state_dict(back["model"], strict=True)
+        same = all(torch.equal(v, state["model"][k]) for k, v in fresh.state_dict().items())
+        assert same and back["epoch"] == 7 and back["global_step"] == 1234 and back["mean_count"] == 4321 and back["mean_density"] == 1.25
+    return {"reference_checkpoint_loaded_by_dropin": json.loads(out.stdout.strip().splitlines()[-1])["loaded_keys"],
+            "dropin_checkpoint_loaded_by_reference_strict": {"missing": list(res.missing_keys), "unexpected": list(res.unexpected_keys), "tensors_equal": same}}
+
+
 def module_goldens():
     import torch
 
@@ -227,9 +267,10 @@ def module_goldens():
             entries[f"{prefix}.{k}"] = [list(v.shape), str(v.dtype).replace("torch.", "")]
     src = open(os.path.join(REF, "nerf/renderer.py")).read()
     buffers = sorted(set(re.findall(r"register_buffer\(\s*['\"](\w+)['\"]", src)))
-    json.dump(dict(bound=2, cascade=2, grid_size=128, entries=entries, renderer_buffers=buffers),
+    roundtrip = checkpoint_roundtrip()
+    json.dump(dict(bound=2, cascade=2, grid_size=128, entries=entries, renderer_buffers=buffers, roundtrip=roundtrip),
               open(os.path.join(OUT, "checkpoint_keys.json"), "w"), indent=1)
-    print("checkpoint_keys.json:", sorted(entries), buffers)
+    print("checkpoint_keys.json:", sorted(entries), buffers, roundtrip)
 
     # guard: nothing may have been written into the reference tree
     import subprocess
