@@ -236,6 +236,22 @@ int nerftex_ffmlp_backward(const void* grad, const void* inputs, const void* wei
                            uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
                            void* backward_buffer, void* grad_inputs, void* grad_weights,
                            void* stream);
+/* Extension: the same three entry points on bfloat16 tensors (inputs, weights, buffers, outputs, gradients all bf16; fp32 accumulation
+ * on v_mfma_f32_16x16x32_bf16).  The reference has no bf16 mode (utils.h:23 accepts at::Half only); BASELINE.json configs[2] names it. */
+int nerftex_ffmlp_forward_bf16(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                               uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                               uint32_t activation, uint32_t output_activation, void* forward_buffer,
+                               void* outputs, void* stream);
+int nerftex_ffmlp_inference_bf16(const void* inputs, const void* weights, uint32_t B,
+                                 uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                                 uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                 void* inference_buffer, void* outputs, void* stream);
+int nerftex_ffmlp_backward_bf16(const void* grad, const void* inputs, const void* weights,
+                                const void* forward_buffer, uint32_t B, uint32_t input_dim,
+                                uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                                uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                                void* backward_buffer, void* grad_inputs, void* grad_weights, void* stream);
+
 /* ffmlp.cu:711-740: the reference creates side streams for its split-K wgrad
  * GEMMs.  Here wgrad is reduced inside one launch, so these only size / drop
  * the fp32 partial-sum workspace; kept so `FFMLP.__init__` binds unchanged.  */

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "nerftex_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "nerftex_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "nerftex_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i, _vp, _vp, _vp, _vp],
+    "nerftex_ffmlp_forward_bf16": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_ffmlp_inference_bf16": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_ffmlp_backward_bf16": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i, _vp, _vp, _vp, _vp],
     "nerftex_ffmlp_allocate_splitk": [_sz],
     "nerftex_ffmlp_free_splitk": [],
     "nerftex_create_raytracer": [_vp, _u32, _vp, _u32, C.POINTER(_vp)],

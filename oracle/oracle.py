@@ -270,12 +270,38 @@ def _h(a):
     return np.ascontiguousarray(a, dtype=np.float16)
 
 
+def to_bf16(a):
+    """float array -> bfloat16 bit patterns (uint16), round to nearest even."""
+    x = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((x + 0x7FFF + ((x >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16(u):
+    return (np.ascontiguousarray(u, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def _h16(a):
+    """16-bit storage as the C side takes it: float16 arrays, or uint16 bit patterns (bfloat16 mode) passed through."""
+    return np.ascontiguousarray(a) if a.dtype == np.uint16 else _h(a)
+
+
+class ffmlp_bf16:
+    """`with ffmlp_bf16(): ...` -- ffmlp_forward / ffmlp_backward take and return bfloat16 bit patterns (uint16 arrays)."""
+
+    def __enter__(self):
+        lib().orc_ffmlp_set_storage(C.c_int(1))
+
+    def __exit__(self, *exc):
+        lib().orc_ffmlp_set_storage(C.c_int(0))
+        return False
+
+
 def ffmlp_forward(inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation=0, output_activation=6,
                   inference=False):
-    inputs, weights = _h(inputs), _h(weights)
+    inputs, weights = _h16(inputs), _h16(weights)
     B = inputs.shape[0]
-    fb = None if inference else np.zeros((num_layers, B, hidden_dim), np.float16)
-    out = np.zeros((B, output_dim), np.float16)
+    fb = None if inference else np.zeros((num_layers, B, hidden_dim), inputs.dtype)
+    out = np.zeros((B, output_dim), inputs.dtype)
     lib().orc_ffmlp_forward(_p(inputs), _p(weights), u32(B), u32(input_dim), u32(output_dim), u32(hidden_dim),
                             u32(num_layers), u32(activation), u32(output_activation), _p(fb), _p(out))
     return out, fb
@@ -283,10 +309,10 @@ def ffmlp_forward(inputs, weights, input_dim, output_dim, hidden_dim, num_layers
 
 def ffmlp_backward(grad, inputs, weights, forward_buffer, input_dim, output_dim, hidden_dim, num_layers, activation=0,
                    calc_grad_inputs=False):
-    grad, inputs, weights, forward_buffer = _h(grad), _h(inputs), _h(weights), _h(forward_buffer)
+    grad, inputs, weights, forward_buffer = _h16(grad), _h16(inputs), _h16(weights), _h16(forward_buffer)
     B = inputs.shape[0]
-    bb = np.zeros((num_layers, B, hidden_dim), np.float16)
-    gi = np.zeros((B, input_dim), np.float16) if calc_grad_inputs else None
+    bb = np.zeros((num_layers, B, hidden_dim), inputs.dtype)
+    gi = np.zeros((B, input_dim), inputs.dtype) if calc_grad_inputs else None
     gw = np.zeros_like(weights)
     lib().orc_ffmlp_backward(_p(grad), _p(inputs), _p(weights), _p(forward_buffer), u32(B), u32(input_dim),
                              u32(output_dim), u32(hidden_dim), u32(num_layers), u32(activation), _p(bb), _p(gi), _p(gw))

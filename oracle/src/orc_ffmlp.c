@@ -22,8 +22,28 @@
 
 #define ORC_MAX_WIDTH 256 /* widest layer the reference supports (ffmlp.py:111) */
 #include <stdlib.h>
+#include <string.h>
 
 #define K_ACT 10.0f /* utils.h:41 */
+
+/* Storage type of the tensors: IEEE half (the reference's only mode, utils.h:23) or bfloat16 (the MI355X build's second
+ * instantiation; BASELINE.json configs[2]).  Values are rounded to it wherever the kernels store 16-bit. */
+static int g_bf16 = 0;
+void orc_ffmlp_set_storage(int bf16) { g_bf16 = bf16 != 0; }
+static inline float bf2f(uint16_t h) {
+    uint32_t x = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+static inline uint16_t f2bf(float f) { /* round to nearest even; NaN stays NaN */
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x0040u);
+    return (uint16_t)((x + 0x7fffu + ((x >> 16) & 1u)) >> 16);
+}
+static inline float ld16(uint16_t h) { return g_bf16 ? bf2f(h) : orc_h2f(h); }
+static inline uint16_t st16(float f) { return g_bf16 ? f2bf(f) : orc_f2h(f); }
 
 static float act_forward(uint32_t a, float x) {
     switch (a) {
@@ -42,9 +62,9 @@ static float act_backward(uint32_t a, float g, float y) {
     case 0: return y > 0.0f ? g : 0.0f;
     case 1: return g * y;
     case 2: return g; /* sine: the reference leaves the gradient untouched (:552-556) */
-    case 3: return g * orc_h2f(orc_f2h(y * (1.0f - y)));
-    case 4: { float s = y * K_ACT; return g * orc_h2f(orc_f2h(s * s / (s * s + 1))); }
-    case 5: return g * orc_h2f(orc_f2h(1.0f - expf(-y * K_ACT)));
+    case 3: return g * ld16(st16(y * (1.0f - y)));
+    case 4: { float s = y * K_ACT; return g * ld16(st16(s * s / (s * s + 1))); }
+    case 5: return g * ld16(st16(1.0f - expf(-y * K_ACT)));
     default: return g;
     }
 }
@@ -58,16 +78,16 @@ static const uint16_t* layer_weights(const uint16_t* w, uint32_t in, uint32_t hi
 static void dense(const uint16_t* x, const uint16_t* W, uint16_t* y, uint32_t B, uint32_t in, uint32_t out,
                   uint32_t act) {
     float* wf = (float*)malloc(sizeof(float) * in * out);
-    for (size_t i = 0; i < (size_t)in * out; i++) wf[i] = orc_h2f(W[i]);
+    for (size_t i = 0; i < (size_t)in * out; i++) wf[i] = ld16(W[i]);
 #pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++) {
         float xf[ORC_MAX_WIDTH];
-        for (uint32_t i = 0; i < in; i++) xf[i] = orc_h2f(x[(size_t)b * in + i]);
+        for (uint32_t i = 0; i < in; i++) xf[i] = ld16(x[(size_t)b * in + i]);
         for (uint32_t o = 0; o < out; o++) {
             double acc = 0.0;
             const float* wr = wf + (size_t)o * in;
             for (uint32_t i = 0; i < in; i++) acc += (double)wr[i] * (double)xf[i];
-            y[(size_t)b * out + o] = orc_f2h(act_forward(act, (float)acc));
+            y[(size_t)b * out + o] = st16(act_forward(act, (float)acc));
         }
     }
     free(wf);
@@ -100,20 +120,20 @@ void orc_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t
 static void dense_T(const uint16_t* dy, const uint16_t* W, const uint16_t* fwd, uint16_t* dx, uint32_t B,
                     uint32_t in, uint32_t out, uint32_t act) {
     float* wf = (float*)malloc(sizeof(float) * in * out);
-    for (size_t i = 0; i < (size_t)in * out; i++) wf[i] = orc_h2f(W[i]);
+    for (size_t i = 0; i < (size_t)in * out; i++) wf[i] = ld16(W[i]);
 #pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < B; b++) {
         double acc[ORC_MAX_WIDTH];
         for (uint32_t i = 0; i < in; i++) acc[i] = 0.0;
         for (uint32_t o = 0; o < out; o++) {
-            const double g = (double)orc_h2f(dy[(size_t)b * out + o]);
+            const double g = (double)ld16(dy[(size_t)b * out + o]);
             const float* wr = wf + (size_t)o * in;
             for (uint32_t i = 0; i < in; i++) acc[i] += (double)wr[i] * g;
         }
         for (uint32_t i = 0; i < in; i++) {
             float g = (float)acc[i];
-            if (fwd) g = act_backward(act, orc_h2f(orc_f2h(g)), orc_h2f(fwd[(size_t)b * in + i]));
-            dx[(size_t)b * in + i] = orc_f2h(g);
+            if (fwd) g = act_backward(act, ld16(st16(g)), ld16(fwd[(size_t)b * in + i]));
+            dx[(size_t)b * in + i] = st16(g);
         }
     }
     free(wf);
@@ -125,11 +145,11 @@ static void wgrad(const uint16_t* dy, const uint16_t* x, uint16_t* dW, uint32_t 
 #pragma omp parallel for schedule(static) /* an output row per iteration: every sum keeps its batch order */
     for (uint32_t o = 0; o < out; o++)
         for (uint32_t b = 0; b < B; b++) {
-            const double g = (double)orc_h2f(dy[(size_t)b * out + o]);
+            const double g = (double)ld16(dy[(size_t)b * out + o]);
             if (g == 0.0) continue;
-            for (uint32_t i = 0; i < in; i++) acc[(size_t)o * in + i] += g * (double)orc_h2f(x[(size_t)b * in + i]);
+            for (uint32_t i = 0; i < in; i++) acc[(size_t)o * in + i] += g * (double)ld16(x[(size_t)b * in + i]);
         }
-    for (size_t i = 0; i < (size_t)in * out; i++) dW[i] = orc_f2h((float)acc[i]);
+    for (size_t i = 0; i < (size_t)in * out; i++) dW[i] = st16((float)acc[i]);
     free(acc);
 }
 

@@ -200,3 +200,87 @@ def test_ffmlp_backward_recompute_equals_stored_activations(dev, case):
         res.append((gi.cpu().numpy(), gw.cpu().numpy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.count_nonzero(res[1][1]) > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------ bf16 storage
+BF16_CASES = [CASES[0], CASES[1], CASES[3], CASES[4], CASES[5]]
+
+
+def _close_bf16(got, want, ulps, floor):
+    tol = ulps * 2.0 ** -7 * np.maximum(np.abs(want), floor)  # bfloat16 has a 7-bit mantissa
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), f"{bad.sum()} / {bad.size} beyond {ulps} bf16-ulps; worst {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=[f"in{c[0]}_h{c[1]}_L{c[2]}_act{c[3]}" for c in BF16_CASES])
+def test_ffmlp_bf16_forward_and_backward(oracle, dev, case):
+    """The bf16 instantiation of the same kernels (BASELINE.json configs[2]) against the oracle run in its bf16 storage mode: forward with
+    and without forward_buffer, inference == training forward bit for bit, fused recomputing backward (where instantiated) == stored-
+    activation backward, gradients vs the exact-accumulation oracle."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    IN, H, NL, act, B, w, x = _setup(case, 41)
+    wb, xb = oracle.to_bf16(w.astype(np.float32)), oracle.to_bf16(x.astype(np.float32))
+    rng = np.random.default_rng(42)
+    gb = oracle.to_bf16((rng.standard_normal((B, 16)) * 0.05).astype(np.float32))
+    with oracle.ffmlp_bf16():
+        want_out, want_fb = oracle.ffmlp_forward(xb, wb, IN, 16, H, NL, act, 6)
+        want_gw, want_gx, _ = oracle.ffmlp_backward(gb, xb, wb, want_fb, IN, 16, H, NL, act, True)
+    view = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(dev).view(torch.bfloat16)  # noqa: E731
+    xt, wt, gt = view(xb), view(wb), view(gb)
+    out = torch.full((B, 16), 9.0, dtype=torch.bfloat16, device=dev)
+    fb = torch.full((NL, B, H), 9.0, dtype=torch.bfloat16, device=dev)
+    check(lib.nerftex_ffmlp_forward_bf16(ptr(xt), ptr(wt), B, IN, 16, H, NL, act, 6, ptr(fb), ptr(out), stream()))
+    got_fb = fb.float().cpu().numpy()
+    _close_bf16(got_fb[0], oracle.from_bf16(want_fb[0]), 1.01, 1e-2)
+    for l in range(1, NL):
+        _close_bf16(got_fb[l], oracle.from_bf16(want_fb[l]), 4.0, 5e-2)
+    _close_bf16(out.float().cpu().numpy(), oracle.from_bf16(want_out), 6.0, 1e-1)
+    inf = torch.empty_like(out)
+    check(lib.nerftex_ffmlp_inference_bf16(ptr(xt), ptr(wt), B, IN, 16, H, NL, act, 6, None, ptr(inf), stream()))
+    assert torch.equal(inf, out)
+
+    def backward(fwd_buffer):
+        gw = torch.full_like(wt, 7.0)
+        gx = torch.full_like(xt, 7.0)
+        bb = torch.zeros_like(fb)
+        check(lib.nerftex_ffmlp_backward_bf16(ptr(gt), ptr(xt), ptr(wt), ptr(fwd_buffer), B, IN, 16, H, NL, act, 6, 1, ptr(bb), ptr(gx), ptr(gw), stream()))
+        torch.cuda.synchronize()
+        return gw.float().cpu().numpy(), gx.float().cpu().numpy()
+
+    gw, gx = backward(fb)
+    wgw, wgx = oracle.from_bf16(want_gw), oracle.from_bf16(want_gx)
+    np.testing.assert_allclose(gw, wgw, rtol=0, atol=2.5e-2 * np.abs(wgw).max())  # bf16: 2^-8 per rounding, sums over the batch
+    np.testing.assert_allclose(gx, wgx, rtol=0, atol=2.5e-2 * np.abs(wgx).max())
+    if H == 64 and 2 <= NL <= 4 and IN <= 64:  # the fused kernel can rebuild the activations from the inputs
+        gw2, gx2 = backward(None)
+        assert np.array_equal(gw2, gw) and np.array_equal(gx2, gx)
+
+
+def test_ffmlp_module_bf16_trains(dev):
+    """FFMLP(dtype=torch.bfloat16) under bf16 autocast: outputs / gradients are bf16-valued, close to the fp16 module's, and a few Adam
+    steps reduce the loss (no loss scaling: bf16 has fp32's exponent range)."""
+    from ffmlp import FFMLP
+
+    torch.manual_seed(0)
+    a = FFMLP(32, 16, 64, 2).to(dev)
+    b = FFMLP(32, 16, 64, 2, dtype=torch.bfloat16).to(dev)
+    x = torch.rand(1000, 32, device=dev) * 2 - 1
+    y = torch.rand(1000, 16, device=dev)
+    with torch.autocast("cuda", dtype=torch.float16):
+        ya = a(x)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = b(x)
+    assert ya.dtype == torch.float16 and yb.dtype == torch.bfloat16
+    torch.testing.assert_close(yb.float(), ya.float(), rtol=0, atol=3e-2)
+    opt = torch.optim.Adam(b.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.mse_loss(b(x).float(), y)
+        loss.backward()
+        assert b.weights.grad.dtype == torch.float32 and torch.isfinite(b.weights.grad).all()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.7 * losses[0]
