@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # CPU-baseline leg: idle OpenMP workers sleep instead of spinning (set before libgomp loads)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "nerf-texture_amd")):
     if p not in sys.path:
@@ -62,7 +64,8 @@ def parse():
     ap.add_argument("--graph-split", action="store_true", help="1 GPU: use the two-graph form of the multi-GPU path (for testing it)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
-    ap.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O")
+    ap.add_argument("--dtype", choices=["fp16", "bf16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O; bf16 = "
+                    "bf16 autocast with the FFMLPs on their bf16 kernels (BASELINE.json configs[2] names bf16)")
     ap.add_argument("--bound", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -106,17 +109,29 @@ def cpu_baseline(args, bits, n_rays):
             reps += 1
         return total / (time.perf_counter() - t0), total // max(reps, 1), reps
 
-    legs = {}
-    for name, threads, budget in (("all", cores, 8.0), ("one", 1, 6.0)):
+    def use(threads):
         torch.set_num_threads(threads)
         orc.set_threads(threads)
+
+    # "all cores" = the thread count that is fastest on this host: a 70 k-sample step does not feed 256 threads (barrier and wake-up
+    # costs grow with the team); one probe step per candidate, the best one is timed
+    probe = {}
+    for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
+        use(threads)
+        train_step()
+        t0 = time.perf_counter()
+        train_step()
+        probe[threads] = time.perf_counter() - t0
+    best = min(probe, key=probe.get)
+    legs = {}
+    for name, threads, budget in (("all", best, 6.0), ("one", 1, 5.0)):
+        use(threads)
         legs[name] = timed(train_step, budget, 50)
-    torch.set_num_threads(cores)
-    orc.set_threads(cores)
+    use(best)
     field.eval()
     pose = scene.rand_poses(1, 2.0, np.random.default_rng(7))[0]
     o4, d4 = scene.get_rays(pose, scene.intrinsics(400, 400), 400, 400)
-    n_run = 8192  # rows 190..210 of the 400 x 400 view: rays through the middle of the scene
+    n_run = 4096  # rows 190..200 of the 400 x 400 view: rays through the middle of the scene
     sl = slice(190 * 400, 190 * 400 + n_run)
     r4o, r4d = torch.from_numpy(np.ascontiguousarray(o4[sl])), torch.from_numpy(np.ascontiguousarray(d4[sl]))
 
@@ -127,11 +142,12 @@ def cpu_baseline(args, bits, n_rays):
     run_rate, run_samples, run_reps = timed(run_frame_part, 8.0, 20)
     torch.set_num_threads(max(1, cores // 2))
     return {
-        "value": legs["all"][0], "unit": "ray-samples/s", "cores": cores, "kind": "port",
+        "value": legs["all"][0], "unit": "ray-samples/s", "cores": best, "kind": "port",
         "sample": f"{legs['all'][2]} training steps (forward + backward, no optimizer) of {n_rays} rays / ~{legs['all'][1]} marched samples each; "
-                  f"oracle C with OpenMP + torch-CPU nn.Linear MLPs on all {cores} hardware threads of the host",
+                  f"oracle C with OpenMP + torch-CPU nn.Linear MLPs on {best} threads -- the fastest of "
+                  f"{ {k: round(v, 3) for k, v in probe.items()} } (threads: seconds per step) on a host with {cores} hardware threads",
         "one_thread": {"value": legs["one"][0], "cores": 1, "sample": f"{legs['one'][2]} of the same steps on one thread"},
-        "run_path": {"value": run_rate, "unit": "ray-samples/s", "cores": cores, "workload": "BASELINE.json configs[0]: NeRFRenderer.run semantics, "
+        "run_path": {"value": run_rate, "unit": "ray-samples/s", "cores": best, "workload": "BASELINE.json configs[0]: NeRFRenderer.run semantics, "
                      "512 uniform samples per ray, nn.Linear MLPs, 400x400 view, inference", "sample": f"{run_reps} x {n_run} rays of the view "
                      f"({run_samples} samples each); a whole 400 x 400 frame is {160000 * 512} samples",
                      "s_per_400x400_frame": 160000 * 512 / run_rate},
@@ -139,14 +155,20 @@ def cpu_baseline(args, bits, n_rays):
 
 
 # ----------------------------------------------------------------------------------------------------- training leg
-def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid, bits, time_grid_kernels, graph=False):
-    """K timed training steps of one configuration. Returns (result dict, field, renderer)."""
+def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid, bits, time_grid_kernels, graph=False, dtype=None, dropin_only=False):
+    """K timed training steps of one configuration. Returns (result dict, field, renderer).
+    dtype: "fp16" | "bf16" | "fp32" (default args.dtype).  bf16 = bf16 autocast with the FFMLPs on their bf16 kernels (the hash table is
+    narrowed to fp16 under any autocast, gridencoder/grid.py:41), no loss scaling, torch's fused Adam.
+    dropin_only: the reference's callers unchanged -- eager launches, no field glue / render tail kernels, torch.optim.Adam + GradScaler."""
+    dtype = dtype or args.dtype
+    no_ext = dropin_only
     import nerftex_hip
     from ngp_harness import dp, scene
     from ngp_harness.model import NGPField, Renderer
 
     torch.manual_seed(0)
-    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=not args.no_fused_glue).to(dev)
+    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=not (args.no_fused_glue or no_ext or dtype == "bf16"),
+                     mlp_dtype=torch.bfloat16 if dtype == "bf16" else torch.float16).to(dev)
     torch.manual_seed(1)  # FFMLP.reset_parameters reseeds with 42; give the table its own stream
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
     renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
@@ -169,9 +191,10 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # is two graphs (forward + backward | optimizer) with the gradient all-reduce launched eagerly between them.
     use_graph = graph
     split_graph = use_graph and (world > 1 or args.graph_split)
-    use_amp = args.dtype == "fp16"
-    fused_opt = use_amp and mlp == "ffmlp" and not args.no_fused_opt
-    fused_tail = not args.no_fused_tail
+    use_amp = dtype in ("fp16", "bf16")
+    amp_dtype = torch.bfloat16 if dtype == "bf16" else torch.float16
+    fused_opt = dtype == "fp16" and mlp == "ffmlp" and not (args.no_fused_opt or no_ext)
+    fused_tail = not (args.no_fused_tail or no_ext)
     fused_amp = fused_opt and not args.no_fused_amp
     dp.broadcast([p.data for p in field.parameters()])
     if fused_opt:  # same Adam; every parameter's fp16 copy is the autograd leaf, its fp16 gradient consumed as produced (ngp_harness/optim.py)
@@ -185,22 +208,22 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         trainable = list(field.parameters())
     # the hash-table gradient crosses xGMI as fp16 (it is fp16-valued under autocast): half the all-reduce bytes
     # (the 1/world of the gradient average is folded into the loss below, so the exchange is a plain sum: no division pass over 48 MB)
-    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=torch.float16 if args.dtype == "fp16" else None,
+    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=torch.float16 if dtype == "fp16" else None,
                                    big_numel=0 if fused_opt else 1 << 20)
     inv_world = 1.0 / world
     # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
     amp = FusedAmp(opt) if fused_amp else None
-    scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=use_amp)
+    scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=dtype == "fp16")
     one = torch.ones((), dtype=torch.float32, device=dev)  # root gradient, so that autograd does not fill one per step
 
     def march(ro, rd, **kw):
-        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=use_amp):
             return renderer.march_train(ro, rd, dt_gamma=dt_gamma, perturb=True, max_steps=1024, **kw)
 
     def forward_backward(ro, rd, tgt, marched=None, **kw):
         """One training render + loss + backward; marched = (sample tensors, counter) of an earlier `march` of the same rays, or None."""
         marched, counter = march(ro, rd, **kw) if marched is None else marched
-        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=use_amp):
             if fused_tail:
                 image, depth, loss, scaled = renderer.shade_train(marched, 1, target=tgt, loss_mul=inv_world, scale=amp.scale if amp else None)
             else:
@@ -383,7 +406,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         if not replicas_identical:
             print(f"[bench] rank {rank}: parameter replicas differ across ranks after training", file=sys.stderr)
     res = dict(replicas_identical=replicas_identical, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
-               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt,
+               mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
@@ -452,7 +475,7 @@ def main():
         pose = scene.rand_poses(1, 2.0, rng)[0]
         o, d = scene.get_rays(pose, scene.intrinsics(800, 800), 800, 800)
         ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=use_amp):
+        with torch.autocast("cuda", dtype=torch.bfloat16 if res["dtype"] == "bf16" else torch.float16, enabled=use_amp):
             renderer.render_infer(ro, rd, dt_gamma=dt_gamma)  # warm-up frame
             torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -465,13 +488,21 @@ def main():
         field.train()
     dp.barrier()
 
-    # ---- the other single-GPU configuration of BASELINE.json, short run, for the record (rank 0, N = 1 only)
+    # ---- the other single-GPU configurations, short eager runs, for the record (rank 0, N = 1 only)
     other = None
     if rank == 0 and world == 1 and not args.no_other:
+        other = []
         o_mlp, o_rays = ("torch", 4096) if args.mlp == "ffmlp" else ("ffmlp", 8192)
-        r2, _, _ = measure_training(args, o_mlp, o_rays, 16, 16, dev, rank, world, sc, grid, bits, False)
-        other = {"workload": WORKLOADS[o_mlp], "rays_per_batch": o_rays, "value": r2["value"], "unit": "ray-samples/s", "ms_per_step": r2["ms_per_step"],
-                 "steps": 16}
+        runs = [("configs[1]" if o_mlp == "torch" else "configs[2]", o_mlp, o_rays, args.dtype, False, False),
+                # the step the UNMODIFIED reference callers would run: drop-in packages only, eager launches, torch.optim.Adam + GradScaler
+                ("configs[2] through the drop-in API only (reference callers unchanged: no graph, no field-glue / render-tail kernels, torch Adam + GradScaler)",
+                 "ffmlp", 8192, "fp16", True, False),
+                ("configs[2] with bf16 FFMLPs (bf16 autocast, torch fused Adam, no loss scaling), one replayed HIP graph per step", "ffmlp", 8192, "bf16", False, True)]
+        for label, mlp_k, rays_k, dt_k, dropin, graph_k in runs:
+            r2, _, _ = measure_training(args, mlp_k, rays_k, 16, 16, dev, rank, world, sc, grid, bits, False, graph=graph_k, dtype=dt_k, dropin_only=dropin)
+            other.append({"workload": label if "configs[2]" in label and len(label) > 12 else WORKLOADS[mlp_k], "rays_per_batch": rays_k, "dtype": dt_k,
+                          "value": r2["value"], "unit": "ray-samples/s", "ms_per_step": r2["ms_per_step"], "steps": 16,
+                          "launch": r2["graph"] if r2["graph"] else "eager launches"})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -489,7 +520,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16" if use_amp else "f32",
+            "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[res["dtype"]],
             "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[args.mlp],

@@ -40,22 +40,23 @@ trunc_exp = _trunc_exp.apply
 
 class NGPField(nn.Module):
     def __init__(self, bound=2.0, mlp="torch", num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
-                 fused_glue=False):
+                 fused_glue=False, mlp_dtype=torch.float16):
         super().__init__()
         assert mlp in ("torch", "ffmlp")
         self.bound = bound
         self.mlp = mlp
         # fused_glue: the elementwise ops between / after the two FFMLPs as two HIP kernels per direction (ngp_harness/fused.py),
         # and the FFMLPs fed without the reference's extra 128-row pad copy (the sample buffers are multiples of 128 already)
-        self.fused_glue = bool(fused_glue) and mlp == "ffmlp" and geo_feat_dim == 15
+        self.fused_glue = bool(fused_glue) and mlp == "ffmlp" and geo_feat_dim == 15 and mlp_dtype == torch.float16  # the glue kernels are fp16
         self.geo_feat_dim = geo_feat_dim
         self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                                    desired_resolution=2048 * bound, gridtype="hash", align_corners=True)
         self.encoder_dir = SHEncoder(input_dim=3, degree=4)
         in_dim, in_dir = self.encoder.output_dim, self.encoder_dir.output_dim
         if mlp == "ffmlp":
-            self.sigma_net = FFMLP(input_dim=in_dim, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
-            self.color_net = FFMLP(input_dim=in_dir + geo_feat_dim + 1, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
+            self.sigma_net = FFMLP(input_dim=in_dim, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers, dtype=mlp_dtype)
+            self.color_net = FFMLP(input_dim=in_dir + geo_feat_dim + 1, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color,
+                                   dtype=mlp_dtype)
         else:
             dims = [in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]
             self.sigma_net = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
