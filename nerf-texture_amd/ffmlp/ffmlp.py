@@ -173,9 +173,12 @@ class FFMLP(nn.Module):
 
     def forward(self, inputs, force_grad=False):
         B, C = inputs.shape
-        pad = 128 - (B % 128)  # always >= 1 block of padding, like the reference
-        if pad > 0:
-            inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
+        # The reference pads by 128 - B % 128 rows, i.e. by a whole extra block when B is already a multiple of 128 (ffmlp.py:157-159):
+        # a copy of the complete input per call for rows whose outputs are thrown away.  The kernels need B % 128 == 0 and nothing more,
+        # so an aligned batch -- every march_rays_train buffer is one -- goes in as it is; the outputs of the real rows are the same.
+        pad = (128 - B % 128) % 128
+        if pad > 0 or B == 0:
+            inputs = torch.cat([inputs, torch.zeros(pad if B else 128, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
         outputs = (ffmlp_forward if self.dtype == torch.float16 else ffmlp_forward_bf16)(inputs, self._weights(), self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
                                 self.activation, self.output_activation, (not self.training) and (not force_grad), inputs.requires_grad)
         if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
