@@ -205,6 +205,37 @@ int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* r
                          void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Extension: occupancy-grid maintenance on the device --
+ * NeRFRenderer.update_extra_state (nerf/renderer.py:566-660) without its
+ * framework glue, torch.nonzero and .item() read-backs.  Given the same random
+ * numbers (noise / rand_coords / rand_pick, each optional: NULL = the library's
+ * counter-based generator keyed by `seed`) the grid and bitfield equal what the
+ * reference's Python computes.
+ * ------------------------------------------------------------------------- */
+
+/* Full sweep (renderer.py:579-605): jittered query position of every cell of every cascade, row = cas * H^3 + Morton index,
+ * so that the density estimates of these rows ARE the Morton-ordered grid.  xyzs [cascade*H^3, 3]; noise [cascade*H^3, 3] in [0,1). */
+int nerftex_occupancy_sample_full(float* xyzs, uint32_t cascade, uint32_t H, float bound, const float* noise,
+                                  uint64_t seed, void* stream);
+
+/* Partial update (renderer.py:609-637): per cascade N uniformly random cells (rows 0..N-1 of the cascade's 2N) and N cells drawn from
+ * the currently occupied ones (density_grid > 0, ascending order like torch.nonzero; rows N..2N-1, index -1 when there is none).
+ *   density_grid [cascade, H^3]; rand_coords [cascade, N, 3] int32 in [0,H); rand_pick [cascade, N] int32 in [0, occupied count);
+ *   noise [cascade*2N, 3]; indices [cascade, 2N] int32 (Morton cell index); xyzs [cascade*2N, 3];
+ *   n_occupied [cascade] uint32 (optional): the per-cascade occupied counts, left on the device.                              */
+int nerftex_occupancy_sample_partial(const float* density_grid, uint32_t cascade, uint32_t H, float bound, uint32_t N,
+                                     const int32_t* rand_coords, const int32_t* rand_pick, const float* noise, uint64_t seed,
+                                     int32_t* indices, float* xyzs, uint32_t* n_occupied, void* stream);
+
+/* renderer.py:639-654: tmp grid from (indices, sigmas) -- indices NULL = a full sweep, sigmas [cascade, H^3] in Morton order; a cell named
+ * several times takes the largest estimate --, density_grid = max(density_grid * decay, tmp) where both are >= 0 (everywhere with
+ * force_full_grid), mean_thresh[0] = mean(clamp(density_grid, 0)), mean_thresh[1] = min(mean, density_thresh), bitfield = packbits at that
+ * threshold.  mean_thresh: 2 floats on the device; nothing is read back.                                                       */
+int nerftex_occupancy_update(float* density_grid, const float* sigmas, const int32_t* indices, uint32_t rows_per_cascade,
+                             uint32_t cascade, uint32_t H, float decay, int force_full_grid, float density_thresh,
+                             float* mean_thresh, uint8_t* bitfield, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * ffmlp  (reference: ffmlp/src/bindings.cpp:5-10, ffmlp.h:8-13,
  *         ffmlp.cu:630-895).  fp16 storage; MFMA with fp32 accumulation.
  *   weights  flat: [hidden,in] + (num_layers-1)*[hidden,hidden] + [out16,hidden],

@@ -51,6 +51,30 @@ def shard(n_global, rank, world):
     return lo, hi
 
 
+def sync_occupancy(renderer, src=0, check_only=False):
+    """The must-sync state of SURVEY.md 8(e) besides the weights: density_grid, density_bitfield, mean_density, iter_density.
+    Ranks that run `update_extra_state_device` with the same seed already agree (the jitter and the cell picks are a function of (seed,
+    row), the field replicas are identical), so the default use is `check_only=True` -- one MIN/MAX all-reduce of a checksum, returns
+    whether all ranks hold the same grid -- and a broadcast from `src` (4.5 MiB for cascade 2) is the repair / the mode for a rank-0-only
+    update."""
+    if world_size() == 1:
+        return True
+    grid, bits = renderer.density_grid, renderer.density_bitfield
+    if check_only:
+        sums = torch.stack([grid.double().sum(), grid.double().abs().sum(), bits.double().sum(),
+                            torch.as_tensor(float(renderer.mean_density), dtype=torch.float64, device=grid.device)])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi))
+    dist.broadcast(grid, src)
+    dist.broadcast(bits, src)
+    meta = torch.tensor([float(renderer.mean_density), float(renderer.iter_density)], dtype=torch.float64, device=grid.device)
+    dist.broadcast(meta, src)
+    renderer.mean_density, renderer.iter_density = float(meta[0]), int(meta[1])
+    return True
+
+
 def broadcast(tensors, src=0):
     """Rank `src`'s values to every rank (replica initialisation)."""
     if world_size() > 1:

@@ -223,6 +223,44 @@ class Renderer(nn.Module):
         self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh), self.density_bitfield)
         self.update_mean_count()
 
+    @torch.no_grad()
+    def update_extra_state_device(self, decay=0.95, force_full_update=False, force_full_grid=False, seed=None, chunk=1 << 21, noise=None):
+        """update_extra_state (nerf/renderer.py:566-660) on the library's occupancy kernels (csrc/occupancy.hip): the cell positions come
+        out in Morton order (no index tensors, no scatter for a full sweep), the occupied cells are compacted on the device (no
+        torch.nonzero), the mean density and the packing threshold never leave it (no .item()): the only host read left is mean_count's.
+        seed: the jitter / cell picks are a pure function of (seed, row) -- data-parallel ranks that pass the same seed (default: the call
+        count) keep identical grids without a broadcast.  noise: dict of explicit random numbers (tests)."""
+        from nerftex_hip import check, lib, ptr, stream
+
+        dev, H, cas = self.density_grid.device, self.grid_size, self.cascade
+        seed = self.iter_density if seed is None else int(seed)
+        noise = noise or {}
+        if not hasattr(self, "_mean_thresh"):
+            self._mean_thresh = torch.zeros(2, dtype=torch.float32, device=dev)
+
+        def density(xyzs):
+            out = torch.empty(xyzs.shape[0], dtype=torch.float32, device=dev)
+            for a in range(0, xyzs.shape[0], chunk):
+                out[a:a + chunk] = self.field.density(xyzs[a:a + chunk])["sigma"].reshape(-1).float()
+            return out * self.density_scale if self.density_scale != 1 else out
+
+        if self.iter_density < 16 or force_full_update:
+            xyzs = torch.empty(cas * H ** 3, 3, dtype=torch.float32, device=dev)
+            check(lib.nerftex_occupancy_sample_full(ptr(xyzs), cas, H, float(self.bound), ptr(noise.get("jitter")), seed, stream()))
+            sigmas, indices, rows = density(xyzs), None, H ** 3
+        else:
+            N = H ** 3 // 4
+            xyzs = torch.empty(cas * 2 * N, 3, dtype=torch.float32, device=dev)
+            indices = torch.empty(cas, 2 * N, dtype=torch.int32, device=dev)
+            check(lib.nerftex_occupancy_sample_partial(ptr(self.density_grid), cas, H, float(self.bound), N, ptr(noise.get("coords")), ptr(noise.get("pick")),
+                                                       ptr(noise.get("jitter")), seed, ptr(indices), ptr(xyzs), None, stream()))
+            sigmas, rows = density(xyzs), 2 * N
+        check(lib.nerftex_occupancy_update(ptr(self.density_grid), ptr(sigmas), ptr(indices), rows, cas, H, float(decay), int(force_full_grid),
+                                           float(self.density_thresh), ptr(self._mean_thresh), ptr(self.density_bitfield), stream()))
+        self.mean_density = self._mean_thresh[0]  # a device scalar: float(renderer.mean_density) reads it when somebody asks
+        self.iter_density += 1
+        self.update_mean_count()
+
     def commit_counter(self, counter):
         """Ring bookkeeping for a step that ran with a caller-owned counter (graph replay)."""
         self.step_counter[self.local_step % 16].copy_(counter)

@@ -46,7 +46,18 @@ def _worker(rank, world, port, q, comm_dtype=None):
         else:
             red.all_reduce()
         opt.step()
-    mc = dp.all_reduce_max_int(100 + rank, torch.device("cpu"))
+    # must-sync state besides the weights: the occupancy grid.  Different grids are detected, a broadcast repairs them.
+    import types
+
+    gen = torch.Generator().manual_seed(50 + rank)
+    occ = types.SimpleNamespace(density_grid=torch.rand(2, 512, generator=gen), density_bitfield=torch.randint(0, 256, (128,), generator=gen, dtype=torch.uint8),
+                                mean_density=1.0 + rank, iter_density=3 + rank)
+    differs = not dp.sync_occupancy(occ, check_only=True)
+    dp.sync_occupancy(occ, src=0)
+    agree = dp.sync_occupancy(occ, check_only=True)
+    ref_gen = torch.Generator().manual_seed(50)
+    occ_ok = differs and agree and torch.equal(occ.density_grid, torch.rand(2, 512, generator=ref_gen)) and occ.mean_density == 1.0 and occ.iter_density == 3
+    mc = dp.all_reduce_max_int(100 + rank, torch.device("cpu")) if occ_ok else -1
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     q.put((rank, flat.numpy().copy(), mc))  # by value: torch tensors travel as shared-memory fds that die with the worker
     dp.barrier()
