@@ -475,16 +475,24 @@ def main():
         pose = scene.rand_poses(1, 2.0, rng)[0]
         o, d = scene.get_rays(pose, scene.intrinsics(800, 800), 800, 800)
         ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-        with torch.autocast("cuda", dtype=torch.bfloat16 if res["dtype"] == "bf16" else torch.float16, enabled=use_amp):
-            renderer.render_infer(ro, rd, dt_gamma=dt_gamma)  # warm-up frame
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            n_frames = 3
-            for _ in range(n_frames):
-                img, _, n_inf = renderer.render_infer(ro, rd, dt_gamma=dt_gamma)
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-        mpix = {"mpix_per_s": 0.64 * n_frames / (t3 - t2), "ms_per_frame": (t3 - t2) / n_frames * 1e3, "samples_per_frame": int(n_inf)}
+        def frames(render, n_frames=3):
+            with torch.autocast("cuda", dtype=torch.bfloat16 if res["dtype"] == "bf16" else torch.float16, enabled=use_amp):
+                render(ro, rd, dt_gamma=dt_gamma)  # warm-up frame
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(n_frames):
+                    img, _, n_inf = render(ro, rd, dt_gamma=dt_gamma)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t2) / n_frames, img, int(n_inf), renderer.last_iters
+
+        t_ref, img_ref, n_ref, it_ref = frames(renderer.render_infer)
+        t_pipe, img_pipe, n_pipe, it_pipe = frames(renderer.render_infer_pipelined)
+        mpix = {"mpix_per_s": 0.64 / t_pipe, "ms_per_frame": t_pipe * 1e3, "samples_per_frame": n_pipe, "iterations": it_pipe,
+                "loop": "run_cuda's inference loop with launches sized by the previous iteration's alive count and the true count read on the device "
+                        "(nerftex_*_rays_dev): no per-iteration host stall",
+                "reference_loop": {"mpix_per_s": 0.64 / t_ref, "ms_per_frame": t_ref * 1e3, "samples_per_frame": n_ref, "iterations": it_ref,
+                                   "loop": "nerf/renderer.py:436-487 as written, alive_counter.item() every iteration"},
+                "max_abs_image_difference": float((img_pipe - img_ref).abs().max())}
         field.train()
     dp.barrier()
 

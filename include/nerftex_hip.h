@@ -205,6 +205,25 @@ int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* r
                          void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Extension: the inference loop without a host stall.
+ * nerf/renderer.py:455-470 reads the number of alive rays back every iteration
+ * (`alive_counter.item()`) to size the next launches; here the launches are sized
+ * by an upper bound the host already has (the count of the PREVIOUS iteration:
+ * alive rays never increase) and the kernels read the true count from the device.
+ * Same arithmetic per ray as the three reference-shaped entry points above.
+ * ------------------------------------------------------------------------- */
+int nerftex_march_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive,
+                           const float* rays_t, const float* rays_o, const float* rays_d, float bound, float dt_gamma,
+                           uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* fars, float* xyzs,
+                           float* dirs, float* deltas, uint32_t perturb, void* stream);
+int nerftex_composite_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive,
+                               float* rays_t, const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                               float* depth, float* image, void* stream);
+/* n_alive_dev[0]: alive entries of the old arrays; alive_counter[0] is overwritten with the number of survivors (a different word). */
+int nerftex_compact_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old,
+                             float* rays_t, const float* rays_t_old, int32_t* alive_counter, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Extension: occupancy-grid maintenance on the device --
  * NeRFRenderer.update_extra_state (nerf/renderer.py:566-660) without its
  * framework glue, torch.nonzero and .item() read-backs.  Given the same random

@@ -897,8 +897,10 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
                                                             const float* __restrict__ rays_d, float bound, float dt_gamma,
                                                             uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                             const float* __restrict__ fars, float* __restrict__ xyzs,
-                                                            float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb) {
+                                                            float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb,
+                                                            const int* __restrict__ n_alive_dev) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);  // the launch was sized by an upper bound; the true count lives on the device
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     const Dda s(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
@@ -926,8 +928,9 @@ __global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(uint32_t n_al
                                                                 float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                                 const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                                float* __restrict__ image) {
+                                                                float* __restrict__ image, const int* __restrict__ n_alive_dev) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     float t = rays_t[n];
@@ -960,9 +963,11 @@ __global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(uint32_t n_al
 
 // pass 1: survivors per workgroup.  ws layout (uint32): [0] base (old alive_counter[0]), [1..] totals
 __global__ __launch_bounds__(kBlock) void compact_count_kernel(uint32_t n_alive, const float* __restrict__ rays_t_old,
-                                                               const int* __restrict__ alive_counter, uint32_t* __restrict__ ws) {
+                                                               const int* __restrict__ alive_counter, uint32_t* __restrict__ ws,
+                                                               const int* __restrict__ n_alive_dev) {
     __shared__ uint32_t wave_tot[kBlock / kWave];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
     const bool keep = n < n_alive && rays_t_old[n] >= 0;
     const uint64_t mask = __ballot(keep);
     if ((threadIdx.x & (kWave - 1)) == 0) wave_tot[threadIdx.x / kWave] = (uint32_t)__popcll(mask);
@@ -972,17 +977,18 @@ __global__ __launch_bounds__(kBlock) void compact_count_kernel(uint32_t n_alive,
 #pragma unroll
         for (uint32_t i = 0; i < kBlock / kWave; i++) tot += wave_tot[i];
         ws[1 + blockIdx.x] = tot;
-        if (blockIdx.x == 0) ws[0] = (uint32_t)alive_counter[0];
+        if (blockIdx.x == 0) ws[0] = n_alive_dev ? 0u : (uint32_t)alive_counter[0];  // device-count form: the new counter starts from zero
     }
 }
 
 __global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive, int* __restrict__ rays_alive,
                                                                const int* __restrict__ rays_alive_old, float* __restrict__ rays_t,
                                                                const float* __restrict__ rays_t_old, int* __restrict__ alive_counter,
-                                                               const uint32_t* __restrict__ ws) {
+                                                               const uint32_t* __restrict__ ws, const int* __restrict__ n_alive_dev) {
     __shared__ uint32_t red[kBlock / kWave];
     __shared__ uint32_t wave_tot[kBlock / kWave];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
     const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     uint32_t part = 0;
     for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) part += ws[1 + j];
@@ -1173,36 +1179,80 @@ extern "C" int nerftex_composite_rays_train_backward(const float* grad_weights_s
     return check_launch("composite_rays_train_backward");
 }
 
-extern "C" int nerftex_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
-                                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
-                                  uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
-                                  float* dirs, float* deltas, uint32_t perturb, void* stream) {
-    (void)nears;  // read by the reference kernel but unused (raymarching.cu:940)
+static int march_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                           const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                           const uint8_t* grid, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
     {
         KernelTimer kt("march_rays_kernel", as_stream(stream));
         hipLaunchKernelGGL(march_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,
-                           rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+                           rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb, n_alive_dev);
     }
     return check_launch("march_rays");
 }
 
-extern "C" int nerftex_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
-                                      const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
-                                      float* image, void* stream) {
+extern "C" int nerftex_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                  uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                                  float* dirs, float* deltas, uint32_t perturb, void* stream) {
+    (void)nears;  // read by the reference kernel but unused (raymarching.cu:940)
+    return march_rays_impl(n_alive, nullptr, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
+                           deltas, perturb, stream);
+}
+
+// Extension (sync-free inference loop): the launch is sized by `n_alive_bound`, an upper bound the host knows without waiting for the
+// device; the true number of alive rays is read from n_alive_dev[0] by the kernels.  Rows of rays >= the true count stay untouched.
+extern "C" int nerftex_march_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive,
+                                      const float* rays_t, const float* rays_o, const float* rays_d, float bound, float dt_gamma,
+                                      uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* fars, float* xyzs,
+                                      float* dirs, float* deltas, uint32_t perturb, void* stream) {
+    return march_rays_impl(n_alive_bound, n_alive_dev, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
+                           xyzs, dirs, deltas, perturb, stream);
+}
+
+static int composite_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
+                               const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                               void* stream) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
     {
         KernelTimer kt("composite_rays_kernel", as_stream(stream));
         hipLaunchKernelGGL(composite_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive,
-                           rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+                           rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, n_alive_dev);
     }
     return check_launch("composite_rays");
 }
 
+extern "C" int nerftex_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
+                                      const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                                      float* image, void* stream) {
+    return composite_rays_impl(n_alive, nullptr, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, stream);
+}
+
+extern "C" int nerftex_composite_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive,
+                                          float* rays_t, const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                                          float* depth, float* image, void* stream) {
+    return composite_rays_impl(n_alive_bound, n_alive_dev, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, stream);
+}
+
+static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
+                             const float* rays_t_old, int32_t* alive_counter, void* stream);
+
 extern "C" int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
                                     const float* rays_t_old, int32_t* alive_counter, void* stream) {
+    return compact_rays_impl(n_alive, nullptr, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter, stream);
+}
+
+// device-count form: n_alive_dev[0] = how many entries of the old arrays are alive; alive_counter[0] is OVERWRITTEN with the survivors
+// (no host-side zeroing).  n_alive_dev and alive_counter must be different words.
+extern "C" int nerftex_compact_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old,
+                                        float* rays_t, const float* rays_t_old, int32_t* alive_counter, void* stream) {
+    return compact_rays_impl(n_alive_bound, n_alive_dev, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter, stream);
+}
+
+static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
+                             const float* rays_t_old, int32_t* alive_counter, void* stream) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
     const uint32_t nblocks = div_up(n_alive, kBlock);
@@ -1211,14 +1261,14 @@ extern "C" int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const
     hipStream_t st = as_stream(stream);
     {
         KernelTimer kt("compact_count_kernel", st);
-        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_t_old, alive_counter, ws);
+        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_t_old, alive_counter, ws, n_alive_dev);
     }
     int rc = check_launch("compact_rays(count)");
     if (rc != NERFTEX_OK) return rc;
     {
         KernelTimer kt("compact_write_kernel", st);
         hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_alive, rays_alive_old, rays_t,
-                           rays_t_old, alive_counter, ws);
+                           rays_t_old, alive_counter, ws, n_alive_dev);
     }
     return check_launch("compact_rays(write)");
 }

@@ -358,3 +358,69 @@ class Renderer(nn.Module):
         self.last_iters = i
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         return image, depth, n_samples
+
+    @torch.no_grad()
+    def render_infer_pipelined(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024):
+        """The inference loop of run_cuda (nerf/renderer.py:436-487) without its per-iteration stall: the reference reads the alive count
+        back (`alive_counter.item()`, :469) before it can size the next launches, so the device idles while the host wakes up and
+        enqueues ~12 launches, 60 times per frame.  Here iteration i is launched with the count of iteration i-1 as an upper bound
+        (alive rays never increase; that number was copied to pinned memory a whole iteration ago) and the kernels read the true count
+        from the device (nerftex_*_rays_dev).  Per ray the arithmetic is that of the reference loop: the image is the same."""
+        from collections import deque
+
+        from nerftex_hip import check, lib, ptr, stream
+
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+        weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        rays_alive = torch.zeros(2, N, dtype=torch.int32, device=dev)
+        rays_t = torch.zeros(2, N, dtype=torch.float32, device=dev)
+        counters = torch.tensor([N, 0], dtype=torch.int32, device=dev)
+        ring = 4
+        host = torch.empty(ring, dtype=torch.int32).pin_memory()
+        events = [torch.cuda.Event() for _ in range(ring)]
+        pending = deque()
+        torch.arange(N, out=rays_alive[0])
+        rays_t[0] = nears
+        bound, step, i, n_samples = N, 0, 0, 0
+        perturb_u32 = int(perturb)
+        while step < max_steps:
+            cur, old = i % 2, (i + 1) % 2
+            if i > 0:
+                check(lib.nerftex_compact_rays_dev(bound, ptr(counters[old:]), ptr(rays_alive[cur]), ptr(rays_alive[old]), ptr(rays_t[cur]), ptr(rays_t[old]),
+                                                   ptr(counters[cur:]), stream()))
+                slot = i % ring
+                host[slot:slot + 1].copy_(counters[cur:cur + 1], non_blocking=True)
+                events[slot].record()
+                pending.append(slot)
+                while len(pending) > 1:  # every count but the one just requested is (long) done: no stall
+                    s = pending.popleft()
+                    events[s].synchronize()
+                    bound = min(bound, int(host[s]))
+                if bound <= 0:
+                    break
+            n_step = max(min(N // bound, 8), 1)
+            M = bound * n_step
+            M += 128 - M % 128
+            xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+            dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+            deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+            check(lib.nerftex_march_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(rays_o), ptr(rays_d), float(self.bound),
+                                             float(dt_gamma), int(max_steps), self.cascade, self.grid_size, ptr(self.density_bitfield), ptr(fars), ptr(xyzs),
+                                             ptr(dirs), ptr(deltas), perturb_u32, stream()))
+            sigmas, rgbs, _ = self.field(xyzs, dirs)
+            if self.density_scale != 1:
+                sigmas = self.density_scale * sigmas
+            sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
+            check(lib.nerftex_composite_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                                 ptr(weights_sum), ptr(depth), ptr(image), stream()))
+            n_samples += M
+            step += n_step
+            i += 1
+        self.last_iters = i
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return image, depth, n_samples

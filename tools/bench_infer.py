@@ -26,6 +26,15 @@ with torch.autocast("cuda", dtype=torch.float16):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
 print(json.dumps({"ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n), "iters": getattr(r, "last_iters", None)}))
+with torch.autocast("cuda", dtype=torch.float16):
+    img2, _, n2 = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        img2, _, n2 = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+print(json.dumps({"pipelined_ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n2), "iters": r.last_iters, "max_abs_diff": float((img2 - img).abs().max())}))
 if len(sys.argv) > 2:  # per-kernel device time of one more frame (library kernels only)
     import nerftex_hip
     nerftex_hip.kernel_profile(1, reset=True)
