@@ -205,6 +205,25 @@ int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* r
                          void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Extension: the curved-field projector in one kernel --
+ * MeshProjector.project (tools/map.py:414-433) with its coarse normal from the K
+ * nearest mesh vertices (knn(), :454-501, use_dir_vec=True, Shepard weights), the
+ * two closest-hit traces along +-normal, the nearer hit as surface point / signed
+ * height / face id / tangent frame, the height mask, and FreqEncoder(height)
+ * (tools/encoding.py:5-43, tools/map.py:635).  The neighbour search itself (frnn,
+ * un-vendored) stays with the caller: knn_idx / knn_dist are its output.
+ *   xyz [N,3]; knn_idx [N,K] int32; knn_dist [N,K] (euclidean, ascending);
+ *   mesh_vertices, vertex_normals [V,3]; tbn [F,9] or NULL; n_freqs = multires;
+ *   p_sur [N,3]; sdf [N]; h_mask [N] uint8; normal [N,3]; face_idx [N] int64
+ *   (-1: no hit within 10); tbn_out [N,9] or NULL; z_embed [N, 1 + 2 n_freqs] or NULL.
+ * ------------------------------------------------------------------------- */
+int nerftex_curved_project(const nerftex_raytracer* rt, const float* xyz, const int32_t* knn_idx, const float* knn_dist,
+                           uint32_t N, uint32_t K, const float* mesh_vertices, const float* vertex_normals,
+                           float dir_vec_wdist, float h_threshold, const float* tbn, uint32_t n_freqs, float* p_sur,
+                           float* sdf, uint8_t* h_mask, float* normal, int64_t* face_idx, float* tbn_out,
+                           float* z_embed, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Extension: the inference loop without a host stall.
  * nerf/renderer.py:455-470 reads the number of alive rays back every iteration
  * (`alive_counter.item()`) to size the next launches; here the launches are sized

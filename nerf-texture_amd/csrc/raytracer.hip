@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -156,19 +157,13 @@ __device__ __forceinline__ float box_entry(const Node& n, const V3& o, const V3&
     return tmin;
 }
 
-__global__ __launch_bounds__(64) void raytrace_kernel(uint32_t N, const float* rays_o, const float* rays_d,
-                                                      float* positions, float* normals, float* __restrict__ depth,  // positions/normals may alias rays_o/rays_d (inplace)
-                                                      int64_t* __restrict__ face_idx, const Node* __restrict__ nodes,
-                                                      const Tri* __restrict__ tris) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const V3 ro = load3(rays_o + 3 * (size_t)i), rd = load3(rays_d + 3 * (size_t)i);
-
+// closest hit of one ray: returns the distance (kMaxDist on a miss) and the index of the hit triangle in the reordered array (-1)
+__device__ __forceinline__ float closest_hit(const V3& ro, const V3& rd, const Node* __restrict__ nodes, const Tri* __restrict__ tris, int& best) {
     int stack[kStack];
     int sp = 0;
     stack[sp++] = 0;
     float mint = kMaxDist;
-    int best = -1;
+    best = -1;
     while (sp > 0) {
         const Node node = nodes[stack[--sp]];
         if (node.left < 0) {
@@ -192,9 +187,21 @@ __global__ __launch_bounds__(64) void raytrace_kernel(uint32_t N, const float* r
 #undef NERFTEX_CAS
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                if (dist[c] < mint && sp < kStack) stack[sp++] = idx[c];
+                if (dist[c] < mint) stack[sp++] = idx[c];  // cannot overflow: create_raytracer rejects trees deeper than the stack allows
         }
     }
+    return mint;
+}
+
+__global__ __launch_bounds__(64) void raytrace_kernel(uint32_t N, const float* rays_o, const float* rays_d,
+                                                      float* positions, float* normals, float* __restrict__ depth,  // positions/normals may alias rays_o/rays_d (inplace)
+                                                      int64_t* __restrict__ face_idx, const Node* __restrict__ nodes,
+                                                      const Tri* __restrict__ tris) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const V3 ro = load3(rays_o + 3 * (size_t)i), rd = load3(rays_d + 3 * (size_t)i);
+    int best;
+    const float mint = closest_hit(ro, rd, nodes, tris, best);
     depth[i] = mint;
     positions[3 * (size_t)i] = fmaf(mint, rd.x, ro.x);
     positions[3 * (size_t)i + 1] = fmaf(mint, rd.y, ro.y);
@@ -213,6 +220,102 @@ __global__ __launch_bounds__(64) void raytrace_kernel(uint32_t N, const float* r
         normals[3 * (size_t)i + 1] = 0.0f;
         normals[3 * (size_t)i + 2] = 0.0f;
     }
+}
+
+// ---------------------------------------------------------------- curved-field projector
+// MeshProjector.project of the reference (tools/map.py:414-433) for one sample point per thread, in one kernel:
+//   coarse normal from the K nearest mesh vertices (knn(), :454-501, use_dir_vec=True, Shepard weights: the vertex normals and the
+//   mean direction to the neighbours, inverse-distance weighted) -> closest hit along +normal and along -normal -> the nearer one is the
+//   surface point, its signed distance the height (inside negative) -> |height| < min(9.5, h_threshold) mask, face id, the face's
+//   tangent frame, and the frequency encoding of the height that MeshFeatureField.forward feeds its networks (tools/map.py:635,
+//   tools/encoding.py:5-43).  The reference runs this as ~35 framework launches + two trace launches and materialises every
+//   intermediate ([N,K,3] gathers, two full hit records); the neighbour search itself (frnn, un-vendored) stays outside.
+constexpr int kMaxK = 16;
+__global__ __launch_bounds__(64) void curved_project_kernel(uint32_t N, const float* __restrict__ xyz, const int32_t* __restrict__ knn_idx,
+                                                            const float* __restrict__ knn_dist, uint32_t K, const float* __restrict__ verts,
+                                                            const float* __restrict__ vnormals, float dir_vec_wdist, float h_limit,
+                                                            const Node* __restrict__ nodes, const Tri* __restrict__ tris,
+                                                            const float* __restrict__ tbn, uint32_t n_freqs, float* __restrict__ p_sur,
+                                                            float* __restrict__ sdf_out, uint8_t* __restrict__ h_mask, float* __restrict__ normal_out,
+                                                            int64_t* __restrict__ face_idx, float* __restrict__ tbn_out, float* __restrict__ z_embed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const V3 x = load3(xyz + 3 * (size_t)i);
+    // ---- knn(): weighted normal
+    V3 mean_dir{0, 0, 0}, nsum{0, 0, 0}, acc{0, 0, 0};
+    float wsum = 0;
+    for (uint32_t k = 0; k < K; k++) {
+        const int v = knn_idx[(size_t)i * K + k];
+        const float dis = knn_dist[(size_t)i * K + k];
+        const V3 n = load3(vnormals + 3 * (size_t)v);
+        const V3 d = sub(x, load3(verts + 3 * (size_t)v));
+        const float dl = sqrtf(dot(d, d)) + 1e-5f;
+        const float w = 1.0f / (dis + 1e-7f);
+        mean_dir = {fmaf(w, d.x / dl, mean_dir.x), fmaf(w, d.y / dl, mean_dir.y), fmaf(w, d.z / dl, mean_dir.z)};
+        nsum = {nsum.x + n.x, nsum.y + n.y, nsum.z + n.z};
+        const float nl = sqrtf(dot(n, n)) + 1e-5f;
+        acc = {fmaf(w, n.x / nl, acc.x), fmaf(w, n.y / nl, acc.y), fmaf(w, n.z / nl, acc.z)};
+        wsum += w;
+    }
+    if (dot(mean_dir, nsum) < 0) mean_dir = {-mean_dir.x, -mean_dir.y, -mean_dir.z};  // the sign test against mean(normals) = against their sum
+    {
+        const float ml = sqrtf(dot(mean_dir, mean_dir)) + 1e-5f;
+        mean_dir = {mean_dir.x / ml, mean_dir.y / ml, mean_dir.z / ml};
+        const float w = 1.0f / (fmaxf(dir_vec_wdist, 1e-5f) + 1e-7f);
+        const float nl = sqrtf(dot(mean_dir, mean_dir)) + 1e-5f;
+        acc = {fmaf(w, mean_dir.x / nl, acc.x), fmaf(w, mean_dir.y / nl, acc.y), fmaf(w, mean_dir.z / nl, acc.z)};
+        wsum += w;
+    }
+    V3 nrm{acc.x / wsum, acc.y / wsum, acc.z / wsum};
+    {
+        const float l = sqrtf(dot(nrm, nrm)) + 1e-5f;
+        nrm = {nrm.x / l, nrm.y / l, nrm.z / l};
+    }
+    // ---- project(): two closest hits, the nearer wins
+    int b1, b2;
+    const float d1 = closest_hit(x, nrm, nodes, tris, b1);
+    const V3 neg{-nrm.x, -nrm.y, -nrm.z};
+    const float d2 = closest_hit(x, neg, nodes, tris, b2);
+    const bool inner = d1 < d2;
+    const float d = inner ? d1 : d2;
+    const V3 dir = inner ? nrm : neg;
+    const int best = inner ? b1 : b2;
+    const float sdf = inner ? -d1 : d2;
+    p_sur[3 * (size_t)i] = fmaf(d, dir.x, x.x);
+    p_sur[3 * (size_t)i + 1] = fmaf(d, dir.y, x.y);
+    p_sur[3 * (size_t)i + 2] = fmaf(d, dir.z, x.z);
+    sdf_out[i] = sdf;
+    h_mask[i] = fabsf(sdf) < h_limit ? 1 : 0;
+    normal_out[3 * (size_t)i] = nrm.x; normal_out[3 * (size_t)i + 1] = nrm.y; normal_out[3 * (size_t)i + 2] = nrm.z;
+    const int64_t face = best >= 0 ? tris[best].id : -1;
+    face_idx[i] = face;
+    if (tbn_out) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) tbn_out[9 * (size_t)i + k] = tbn[9 * (size_t)(face >= 0 ? face : (int64_t)0) + k];  // face -1 indexes the last row in torch; the mask covers it
+    }
+    if (z_embed) {  // FreqEncoder(input_dim=1, log sampling): [h, sin(h 2^0), cos(h 2^0), sin(h 2^1), ...]
+        float* z = z_embed + (size_t)i * (1 + 2 * n_freqs);
+        z[0] = sdf;
+        float f = 1.0f;
+        for (uint32_t k = 0; k < n_freqs; k++, f *= 2.0f) {
+            z[1 + 2 * k] = sinf(sdf * f);
+            z[2 + 2 * k] = cosf(sdf * f);
+        }
+    }
+}
+
+// depth of the BVH-4 (root = 1)
+int bvh_depth(const std::vector<Node>& nodes) {
+    int deepest = 1;
+    std::vector<std::pair<int, int>> st{{0, 1}};
+    while (!st.empty()) {
+        const auto [n, d] = st.back();
+        st.pop_back();
+        deepest = std::max(deepest, d);
+        if (nodes[n].left >= 0)
+            for (int c = 0; c < 4; c++) st.push_back({nodes[n].left + c, d + 1});
+    }
+    return deepest;
 }
 
 }  // namespace
@@ -242,6 +345,12 @@ extern "C" int nerftex_create_raytracer(const float* host_vertices, uint32_t n_v
     }
     std::vector<Node> nodes;
     build_bvh(tris, nodes);
+    // the traversal pops one node and pushes up to four: at most 3 * depth + 1 entries are ever on its stack
+    if (3 * bvh_depth(nodes) + 1 > kStack) {
+        set_error("create_raytracer: a BVH of depth %d needs a traversal stack of %d entries (the kernel has %d); mesh too large", bvh_depth(nodes),
+                  3 * bvh_depth(nodes) + 1, kStack);
+        return NERFTEX_ERR_INVALID;
+    }
 
     nerftex_raytracer* rt = new nerftex_raytracer();
     rt->n_nodes = (uint32_t)nodes.size();
@@ -283,4 +392,24 @@ extern "C" int nerftex_raytracer_trace(const nerftex_raytracer* rt, const float*
                            static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles));
     }
     return check_launch("raytracer_trace");
+}
+
+extern "C" int nerftex_curved_project(const nerftex_raytracer* rt, const float* xyz, const int32_t* knn_idx, const float* knn_dist, uint32_t N, uint32_t K,
+                                      const float* mesh_vertices, const float* vertex_normals, float dir_vec_wdist, float h_threshold, const float* tbn,
+                                      uint32_t n_freqs, float* p_sur, float* sdf, uint8_t* h_mask, float* normal, int64_t* face_idx, float* tbn_out,
+                                      float* z_embed, void* stream) {
+    clear_error();
+    if (!rt || K == 0 || K > (uint32_t)kMaxK || (tbn_out && !tbn)) {
+        set_error("curved_project: need a raytracer, 1 <= K <= %d neighbours per point, and the per-face frames when tbn_out is requested", kMaxK);
+        return NERFTEX_ERR_INVALID;
+    }
+    if (N == 0) return NERFTEX_OK;
+    const float h_limit = fminf(9.5f, h_threshold);  // depth_threshold of tools/map.py:407
+    {
+        KernelTimer kt("curved_project_kernel", as_stream(stream));
+        hipLaunchKernelGGL(curved_project_kernel, dim3(div_up(N, 64u)), dim3(64), 0, as_stream(stream), N, xyz, knn_idx, knn_dist, K, mesh_vertices, vertex_normals,
+                           dir_vec_wdist, h_limit, static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles), tbn, n_freqs, p_sur, sdf, h_mask,
+                           normal, face_idx, tbn_out, z_embed);
+    }
+    return check_launch("curved_project");
 }

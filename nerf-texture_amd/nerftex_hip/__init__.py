@@ -75,6 +75,7 @@ _SIGNATURES = {
     "nerftex_ffmlp_free_splitk": [],
     "nerftex_create_raytracer": [_vp, _u32, _vp, _u32, C.POINTER(_vp)],
     "nerftex_destroy_raytracer": [_vp],
+    "nerftex_curved_project": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _f32, _f32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_raytracer_trace": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
 }
 EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get"] + list(_SIGNATURES)

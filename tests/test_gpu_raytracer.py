@@ -127,3 +127,33 @@ def test_curved_field_lookup_chain(oracle, dev):
     got = feat.detach().cpu().numpy()
     assert np.array_equal(got[ok], want[ok]), "hash lookup at the projected surface point is bit-exact"
     assert torch.isfinite(field.encoder.clustering_loss(pick_level=False).detach())
+
+
+def test_fused_curved_projector_matches_the_reference_op_sequence(dev):
+    """nerftex_curved_project (coarse normal from the K nearest vertices + two closest-hit traces + select + mask + frame gather +
+    FreqEncoder of the height, one kernel) vs the reference's op sequence (tools/map.py:414-433, 454-501; tools/encoding.py:5-43)
+    restated with framework ops over RayTracer.trace, on a ~20 k-face star_flower-shaped mesh."""
+    from ngp_harness.curved import MeshProjector, star_flower_mesh
+    from oracle import cpu_path
+
+    v, f = star_flower_mesh()
+    proj = MeshProjector(v, f, h_threshold=0.05).to(dev)
+    rng = np.random.default_rng(5)
+    base = v[rng.integers(0, len(v), 20000)]
+    pts = torch.from_numpy((base * (1 + rng.uniform(-0.08, 0.08, (len(base), 1)))).astype(np.float32)).to(dev)  # a shell around the surface
+    p0, sdf0, m0, n0, tbn0, face0 = proj.project_reference(pts)
+    p1, sdf1, m1, n1, tbn1, face1, z1 = proj.project(pts)
+    torch.testing.assert_close(n1, n0, rtol=0, atol=2e-5)
+    same_face = face1 == face0
+    assert same_face.float().mean() > 0.998, "a ray that grazes an edge may pick the neighbouring face when the normal differs in the last bits"
+    torch.testing.assert_close(sdf1[same_face], sdf0[same_face], rtol=0, atol=2e-5)
+    torch.testing.assert_close(p1[same_face], p0[same_face], rtol=0, atol=2e-5)
+    assert torch.equal(tbn1[same_face], tbn0[same_face])
+    assert (m1 == m0).float().mean() > 0.999 and 0.2 < m1.float().mean() < 0.95
+    assert (sdf1 < 0).float().mean() > 0.2 and (sdf1 > 0).float().mean() > 0.2, "points inside and outside the surface"
+    want_z = cpu_path.freq_encode(sdf1.cpu(), 11, 12)
+    torch.testing.assert_close(z1.cpu(), want_z, rtol=0, atol=2e-4)  # sin / cos of up to 2048 h: argument reduction differs in the last bits
+    with pytest.raises(RuntimeError, match="1 <= K"):
+        from nerftex_hip import check, lib
+
+        check(lib.nerftex_curved_project(proj.tracer._handle, None, None, None, 4, 99, None, None, 0.05, 0.05, None, 12, None, None, None, None, None, None, None, None))
