@@ -44,6 +44,9 @@ extern "C" {
  * the caller's fill pass over the table; the large-batch path then writes every row itself.                               */
 #define NERFTEX_LAYOUT_GRAD_OVERWRITE 0x100
 
+/* opaque handle of a triangle mesh + its BVH on the device (the RayTracer section below) */
+typedef struct nerftex_raytracer nerftex_raytracer;
+
 /* thread-local text of the last error on this thread ("" if none) */
 const char* nerftex_last_error(void);
 /* library / build identification: "nerftex_hip <ver> gfx950" */
@@ -331,7 +334,6 @@ int nerftex_ffmlp_free_splitk(void);
  * RayTracer / BVH  (reference: external/RayTracer/src/bindings.cpp:13-18,
  *                   src/raytracer.cu:21-64, src/bvh.cu:527-721)
  * ------------------------------------------------------------------------- */
-typedef struct nerftex_raytracer nerftex_raytracer;
 
 /* replaces _raytracing.create_raytracer: HOST arrays in, BVH-4 built on the
  * host (median split on the max-variance axis, <= 8 triangles per leaf),

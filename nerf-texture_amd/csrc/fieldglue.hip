@@ -20,7 +20,6 @@ __device__ __forceinline__ half_t narrow(float v) {
     return (half_t)v;
 }
 
-constexpr uint32_t kGeo = 15;  // geometry features handed from the sigma net to the colour net (network_ff.py:35)
 
 // h [B,16] half, dirs [B,3] fp32  ->  sigma [B] fp32 = exp(h[:,0]),  cin [B,32] half = [SH4(dir) | h[:,1:16] | 0]
 __global__ __launch_bounds__(256) void field_mid_forward_kernel(const half_t* __restrict__ h, const float* __restrict__ dirs, uint32_t B,
