@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
     ap.add_argument("--dtype", choices=["fp16", "bf16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O; bf16 = "
                     "bf16 autocast with the FFMLPs on their bf16 kernels (BASELINE.json configs[2] names bf16)")
+    ap.add_argument("--wire", choices=["fp16", "fp32"], default="fp16", help="N > 1: dtype of the table gradient on xGMI. fp16 = the gradient's own dtype "
+                    "under autocast (half the bytes); fp32 = SURVEY 8(e)'s parity form: the cross-rank sum is formed in fp32 and rounded once")
+    ap.add_argument("--no-perturb", action="store_true", help="march without the per-ray start jitter (it is seeded by the ray's index in the LOCAL batch, so "
+                    "a sharded run and a single-rank run of the same global batch only see the same samples without it)")
     ap.add_argument("--bound", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -183,7 +187,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         o, d = scene.train_batch(n_global, seed=100 + k, n_views=4)
         lo, hi = dp.shard(n_global, rank, world)
         pool.append((torch.from_numpy(o[lo:hi]).to(dev), torch.from_numpy(d[lo:hi]).to(dev)))
-    gt = torch.rand(n_pool, rays, 3, device=dev)
+    lo, hi = dp.shard(n_global, rank, world)  # the targets belong to the rays: a global tensor, sharded like them
+    gt = torch.rand(n_pool, n_global, 3, generator=torch.Generator().manual_seed(4321))[:, lo:hi].contiguous().to(dev)
 
     # same optimizer as main_nerf.py:128 (Adam, betas (0.9, 0.99), eps 1e-15); fused=True keeps GradScaler.step free of its
     # per-step found_inf .item() read-back (the unscale / skip-on-inf logic runs inside the fused kernel instead)
@@ -208,7 +213,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         trainable = list(field.parameters())
     # the hash-table gradient crosses xGMI as fp16 (it is fp16-valued under autocast): half the all-reduce bytes
     # (the 1/world of the gradient average is folded into the loss below, so the exchange is a plain sum: no division pass over 48 MB)
-    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=torch.float16 if dtype == "fp16" else None,
+    wire_dtype = torch.float32 if args.wire == "fp32" else (torch.float16 if dtype == "fp16" else None)
+    reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=wire_dtype,
                                    big_numel=0 if fused_opt else 1 << 20)
     inv_world = 1.0 / world
     # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
@@ -218,7 +224,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
 
     def march(ro, rd, **kw):
         with torch.autocast("cuda", dtype=amp_dtype, enabled=use_amp):
-            return renderer.march_train(ro, rd, dt_gamma=dt_gamma, perturb=True, max_steps=1024, **kw)
+            return renderer.march_train(ro, rd, dt_gamma=dt_gamma, perturb=not args.no_perturb, max_steps=1024, **kw)
 
     def forward_backward(ro, rd, tgt, marched=None, **kw):
         """One training render + loss + backward; marched = (sample tensors, counter) of an earlier `march` of the same rays, or None."""
@@ -395,6 +401,24 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         dist.all_reduce(samples, op=dist.ReduceOp.SUM)
     elapsed = float(elapsed.item())
     samples = int(samples.item())
+    collective = None
+    if world > 1:  # what the collective library reports, and the cost of one gradient exchange on its own (outside the timed region)
+        import torch.distributed as dist
+
+        grads = reducer.big_grads()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            reducer.all_reduce(grads=grads)
+        ev1.record()
+        torch.cuda.synchronize()
+        collective = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""), "world_size": dist.get_world_size(),
+                      "wire_dtype": str(wire_dtype).replace("torch.", "") if wire_dtype is not None else "the gradient's dtype",
+                      "bytes_per_step": int(sum(g.numel() * (torch.finfo(wire_dtype).bits // 8 if wire_dtype else g.element_size()) for g in grads if g is not None)),
+                      "allreduce_us_per_step": ev0.elapsed_time(ev1) * 100.0}
+    param_l1 = float(sum(p.detach().double().abs().sum() for p in field.parameters()))
     replicas_identical = None
     if world > 1:  # data parallelism keeps full replicas: after the run every rank must hold the same bits (cheap: one checksum vector)
         torch.cuda.synchronize()
@@ -405,7 +429,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         replicas_identical = bool(torch.equal(lo, hi))
         if not replicas_identical:
             print(f"[bench] rank {rank}: parameter replicas differ across ranks after training", file=sys.stderr)
-    res = dict(replicas_identical=replicas_identical, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
+    res = dict(replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
@@ -536,7 +560,7 @@ def main():
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
                 "optimizer": ("Adam(eps=1e-15) + GradScaler rules, as HIP kernels on the fp16 gradients (fp32 masters + fp16 copies; bit-identical to torch fused Adam)"
                               if res.get("fused_opt") else "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)"),
-                "replicas_identical_after_run": res.get("replicas_identical"),
+                "replicas_identical_after_run": res.get("replicas_identical"), "collective": res.get("collective"), "param_l1_after_run": res.get("param_l1"),
                 "launch": res["graph"] if res["graph"] else "eager launches",
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
             },

@@ -132,6 +132,16 @@ class FlatGradAllReduce:
         if world_size() == 1:
             return None
         works, post = [], []
+        off = 0
+        for p in self.small:  # a caller's optimizer.zero_grad(set_to_none=True) drops the views into the flat buffer: put them back
+            n = p.numel()
+            view = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+            off += n
         for p, g in zip(self.big, grads if grads is not None else self.big_grads()):
             if g is None:
                 continue
