@@ -138,7 +138,12 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
     constexpr int NP = Sample<T, D>::NP;
     constexpr uint32_t kRows = rows_per_tile<T>();
     const int lane = threadIdx.x & (kWave - 1);
-    bool valid = in_batch;
+    // a sample whose gradient is exactly zero on this level adds nothing to any row: it emits no records (in training that is every
+    // sample behind the point where its ray's transmittance fell below 1e-4 -- the compositing backward leaves those at zero)
+    bool valid = in_batch && (g[0] != 0.0f || g[1] != 0.0f);
+    sm.live = false;
+    sm.split = 0;
+    if (__ballot(valid) == 0ull) return;  // wave-uniform: nothing to do for these 64 samples
     float pos[D];
     uint32_t pg[D];
 #pragma unroll

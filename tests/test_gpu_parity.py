@@ -188,6 +188,8 @@ def test_grid_backward_large_batch_fp16_is_tight_per_row(oracle, dev):
     B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
     s["x"][9000:29000] = np.clip(np.repeat(s["x"][9000:9200], 100, axis=0) + np.tile(np.linspace(0, 0.03, 100, dtype=np.float32)[:, None], (200, D)), 0, 1)
     g = (rng.standard_normal((B, L * C)) * 1e-2).astype(np.float16)
+    g[rng.random(B) < 0.3] = 0  # samples with no gradient at all (rays past their termination point): skipped, exactly
+    g[30000:33000] = 0          # ... whole waves of them
     g_lbc = np.ascontiguousarray(g.reshape(B, L, C).transpose(1, 0, 2))
     # true sums and L1 masses in float64 from the float32 arithmetic of the weights (the oracle's fp32 mode keeps w * g unrounded)
     true = oracle.grid_encode_backward(g_lbc.astype(np.float32), s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
@@ -200,7 +202,7 @@ def test_grid_backward_large_batch_fp16_is_tight_per_row(oracle, dev):
                                            int(s["align"]), F16, 1, stream()))
     got = ge.cpu().numpy().astype(np.float64)
     # shares: half(w_yz g) then a 2^-16 split -> <= 2^-11 |share| each; result rounded to half once: <= 2^-11 |sum|; fixed-point grain 2^-24 per share (two per hit)
-    bound = 2.0 ** -10 * mass + 2.0 ** -11 * np.abs(true) + 2.0 ** -23 * (hits + 1)
+    bound = 1.01 * 2.0 ** -10 * mass + 2.0 ** -11 * np.abs(true) + 2.0 ** -23 * (hits + 1)
     bad = np.abs(got - true) > bound
     assert not bad.any(), f"{bad.sum()} entries off; worst excess {(np.abs(got - true) - bound).max()}"
     assert (hits.max(axis=1) >= 8).sum() > 1000, "rows with many hits are covered"
