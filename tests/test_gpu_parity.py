@@ -202,7 +202,8 @@ def test_grid_backward_large_batch_fp16_is_tight_per_row(oracle, dev):
                                            int(s["align"]), F16, 1, stream()))
     got = ge.cpu().numpy().astype(np.float64)
     # shares: half(w_yz g) then a 2^-16 split -> <= 2^-11 |share| each; result rounded to half once: <= 2^-11 |sum|; fixed-point grain 2^-24 per share (two per hit)
-    bound = 1.01 * 2.0 ** -10 * mass + 2.0 ** -11 * np.abs(true) + 2.0 ** -23 * (hits + 1)
+    # + the x fraction of a pair is stored in 16 bits: a row that gets a tiny share of a large pair gradient sees 2^-17 of THAT gradient
+    bound = 2.0 ** -10 * mass + 2.0 ** -11 * np.abs(true) + 2.0 ** -23 * (hits + 1) + 2.0 ** -17 * float(np.abs(g.astype(np.float32)).max())
     bad = np.abs(got - true) > bound
     assert not bad.any(), f"{bad.sum()} entries off; worst excess {(np.abs(got - true) - bound).max()}"
     assert (hits.max(axis=1) >= 8).sum() > 1000, "rows with many hits are covered"
