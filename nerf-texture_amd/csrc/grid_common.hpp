@@ -51,6 +51,7 @@ struct IndexFn {
     uint32_t ndense;     // number of dimensions the dense loop covers
     bool hashed;
     bool pow2;
+    bool modulo;  // a real `% size` is needed: only a tiled (never hashed) level whose dense index range exceeds its table
     uint32_t size;
 
     __device__ IndexFn(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
@@ -67,6 +68,9 @@ struct IndexFn {
         hashed = (gridtype == 0) && (s > hashmap_size);
         size = hashmap_size;
         pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
+        // a dense level has f^D <= size (f = points per axis), and a corner coordinate is at most f, so its index stays below
+        // f + f^2 + ... + f^D < 2 size: the reference's `index % hashmap_size` (gridencoder.cu:69) is one conditional subtraction there
+        modulo = !hashed && s > hashmap_size;
     }
 
     // The same index, factored: every corner coordinate is pg[d] or pg[d] + 1, so the per-dimension terms are computed once (one
@@ -84,7 +88,8 @@ struct IndexFn {
     __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return hashed ? (a ^ b) : (a + b); }
     __device__ __forceinline__ uint32_t wrap(uint32_t index) const {
         if (pow2) return index & (size - 1);
-        return index >= size ? index % size : index;
+        if (modulo) return index % size;
+        return index >= size ? index - size : index;
     }
 
     __device__ __forceinline__ uint32_t operator()(const uint32_t (&p)[D]) const {
@@ -100,8 +105,7 @@ struct IndexFn {
             for (int d = 0; d < D; d++)
                 if ((uint32_t)d < ndense) index += p[d] * stride[d];
         }
-        if (pow2) return index & (size - 1);
-        return index >= size ? index % size : index;
+        return wrap(index);
     }
 };
 

@@ -47,6 +47,11 @@ constexpr uint32_t kSumThreads = 1024;
 template <typename T> struct Rec;
 template <> struct Rec<half_t> { uint32_t word; half2_t g; };
 template <> struct Rec<float> { uint32_t word; float p, g0, g1; };
+// the same bytes as a vector of dwords: LDS-qualified pointers cannot carry class types
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct RecBits { using type = u32x2_t; };
+template <> struct RecBits<float> { using type = u32x4_t; };
 constexpr uint32_t kSingle = 15;
 template <typename T> constexpr uint32_t row_bits() { return sizeof(T) == 2 ? 12u : 14u; }
 
@@ -63,13 +68,6 @@ __device__ __forceinline__ long long half_to_fixed(half_t h) {
     const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
     const unsigned long long mag = e ? (unsigned long long)(f | 1024u) << (e - 1u) : (unsigned long long)f;
     return (b & 0x8000u) ? -(long long)mag : (long long)mag;
-}
-// the share p16 / 65536 of a fixed-point value, rounded to nearest; an overflowed value (>= 2^40) is handed on whole so that both
-// rows of the pair come back as inf
-__device__ __forceinline__ long long fixed_share(long long v, uint32_t p16) {
-    const unsigned long long m = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
-    const unsigned long long r = (m >> 40) ? m : (m * p16 + 32768ull) >> 16;
-    return v < 0 ? -(long long)r : (long long)r;
 }
 // round-to-nearest-even of s * 2^-24 to half, overflow -> inf
 __device__ __forceinline__ half_t fixed_to_half(long long s) {
@@ -270,7 +268,12 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel];
     constexpr int NP = Sample<T, D>::NP;
     constexpr uint32_t kRows = rows_per_tile<T>();
-    Rec<T>* stage = reinterpret_cast<Rec<T>*>(smem);
+    // an LDS-qualified pointer: with a generic one the compiler merges the LDS store and the rare overflow store to global memory of
+    // the placement phase into one flat_store with a selected address
+    using Bits = typename RecBits<T>::type;
+    static_assert(sizeof(Bits) == sizeof(Rec<T>), "record size");
+    typedef Bits __attribute__((address_space(3))) LdsBits;
+    LdsBits* stage = (LdsBits*)smem;
     if (blockIdx.x == 0 && threadIdx.x <= L && offsets[threadIdx.x] != tab.offsets[threadIdx.x]) __builtin_trap();  // host copy vs device table
     const uint32_t group = blockIdx.x / (kXcds * L), rem = blockIdx.x % (kXcds * L);
     const uint32_t level = rem / kXcds, chunk = group * kXcds + rem % kXcds;  // id % 8 = chunk % 8 = the XCD that runs it
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
         const uint32_t t = row / kRows;
         const uint32_t at = lbase[t] + atomicAdd(&lcount[t], 1u);
         const Rec<T> r = make_record<T>(row - t * kRows, code, sm.p, v);
-        if (at < kStageRecords) stage[at] = r;
+        if (at < kStageRecords) stage[at] = __builtin_bit_cast(Bits, r);
         else region[at] = r;
     };
     if (sm.live) {
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     if (probe == 3) return;  // ablation: + placement in LDS
     const uint32_t total = min(lbase[kMaxTilesPerLevel], kStageRecords);
 #pragma unroll 5
-    for (uint32_t i = threadIdx.x; i < total; i += kBinSamples) region[i] = stage[i];  // one contiguous block, tile order preserved
+    for (uint32_t i = threadIdx.x; i < total; i += kBinSamples) reinterpret_cast<Bits*>(region)[i] = stage[i];  // one contiguous block, tile order preserved
 }
 
 // K4d: one record into the tile's accumulators.  fp16: value * 2^24 in 64-bit integers -- every half is an integer multiple of
@@ -369,18 +372,21 @@ __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
     const uint32_t rb = ra ^ ((2u << code) - 1u);
     if constexpr (sizeof(T) == 2) {
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
-        const long long f0 = half_to_fixed(r.g[0]), f1 = half_to_fixed(r.g[1]);
-        if (code == kSingle) {
-            atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)f0);
-            atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)f1);
-        } else {
-            const uint32_t p16 = r.word >> 16;
-            const long long b0 = fixed_share(f0, p16), b1 = fixed_share(f1, p16);
-            const bool ovf0 = ((f0 < 0 ? -f0 : f0) >> 40) != 0, ovf1 = ((f1 < 0 ? -f1 : f1) >> 40) != 0;
-            atomicAdd(acc64 + (size_t)ra * 2, (unsigned long long)(ovf0 ? f0 : f0 - b0));
-            atomicAdd(acc64 + (size_t)ra * 2 + 1, (unsigned long long)(ovf1 ? f1 : f1 - b1));
-            atomicAdd(acc64 + (size_t)rb * 2, (unsigned long long)b0);
-            atomicAdd(acc64 + (size_t)rb * 2 + 1, (unsigned long long)b1);
+        // sign-magnitude all the way: magnitude * 2^24 (< 2^41), the pair's split on magnitudes, the sign applied once per addend
+        const uint32_t gbits = __builtin_bit_cast(uint32_t, r.g);  // (element-wise bit_casts of r.g[1] came back as element 0 with this compiler)
+        const uint32_t h[2] = {gbits & 0xffffu, gbits >> 16};
+        const uint32_t p16 = r.word >> 16;
+        const bool single = code == kSingle;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t e = (h[c] >> 10) & 31u;
+            const unsigned long long mag = (unsigned long long)((h[c] & 1023u) | (e ? 1024u : 0u)) << (e ? e - 1u : 0u);
+            unsigned long long b = (mag * p16 + 32768ull) >> 16;  // row b's share, rounded to nearest; row a gets the exact remainder
+            unsigned long long a = mag - b;
+            if (e == 31u) a = b = mag;  // inf / nan (>= 2^40): both rows come back as inf, which is what GradScaler needs to see
+            const unsigned long long s = (h[c] & 0x8000u) ? ~0ull : 0ull;
+            atomicAdd(acc64 + (size_t)ra * 2 + c, ((single ? mag : a) ^ s) - s);
+            if (!single) atomicAdd(acc64 + (size_t)rb * 2 + c, (b ^ s) - s);
         }
     } else {
         float* acc32 = reinterpret_cast<float*>(smem);
