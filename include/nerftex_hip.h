@@ -208,6 +208,23 @@ int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* r
                          void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Extension: everything of the ngp field behind the hash-grid
+ * gather as ONE kernel -- nerf/network_ff.py:85-101: sigma net (32 -> 64 -> 64 -> 16,
+ * ReLU), trunc_exp of output 0, SH degree 4 of the view direction, colour net
+ * ([SH | geometry features | 0] -> 64 -> 64 -> 64 -> 16), sigmoid of outputs 0..2.
+ *   feats_lbc [16, B, 2] half: the LEVEL-MAJOR features (layout NERFTEX_LAYOUT_LBC of
+ *   nerftex_grid_encode_forward: what the XCD-pinned gather kernel writes; no transpose);
+ *   dirs [B, 3] fp32; sigma_weights / color_weights: the two FFMLP weight vectors (half);
+ *   sigma [B] fp32, rgbs [B, 3] fp32 (half-valued, as the unfused sequence gives them).
+ * Training additionally gets what the backward entry points read (all four or none):
+ *   x_rows [B, 32] (the features as rows), h [B, 16], cin [B, 32], hc [B, 16], half.
+ * B % 128 == 0.  Same values, bit for bit, as grid rows -> nerftex_ffmlp_forward ->
+ * nerftex_field_mid_forward -> nerftex_ffmlp_forward -> nerftex_field_out_forward.
+ * ------------------------------------------------------------------------- */
+int nerftex_field_forward(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                          uint32_t B, float* sigma, float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Extension: the curved-field projector in one kernel --
  * MeshProjector.project (tools/map.py:414-433) with its coarse normal from the K
  * nearest mesh vertices (knn(), :454-501, use_dir_vec=True, Shepard weights), the

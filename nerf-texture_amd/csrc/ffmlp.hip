@@ -24,7 +24,10 @@
 // num_layers >= 2, B % 128 == 0, every activation of ffmlp.py:89-96.  The weights of all layers must
 // fit the 160 KB LDS of a CU (true for every width <= 128 and for 256 with num_layers == 2).
 #include "common.hpp"
+#include "sh_common.hpp"  // the SH basis of the fused field kernel (switches fp contraction off for what follows ...)
 #include "workspace.hpp"
+
+#pragma clang fp contract(fast)  // ... restored: the MLP kernels were written and measured with the default
 
 // The kernels are written against a storage type `elem_t` and compiled twice: fp16 (the reference's only mode, ffmlp/src/utils.h:23) and
 // bf16 (BASELINE.json configs[2] names bf16; same exponent range as fp32, so no loss scaling, 8 significand bits instead of 11).
@@ -77,6 +80,10 @@ using namespace nerftex;
         return NS::backward_entry(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,            \
                                   output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, stream);                       \
     }
+extern "C" int nerftex_field_forward(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B, float* sigma,
+                                     float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream) {
+    return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, x_rows, h, cin, hc, stream);
+}
 NERFTEX_FFMLP_ENTRIES(, ffmlp_f16)        // the reference's exports (ffmlp/src/bindings.cpp:5-10)
 NERFTEX_FFMLP_ENTRIES(_bf16, ffmlp_bf16)  // extension: the same three on bf16 tensors
 #undef NERFTEX_FFMLP_ENTRIES

@@ -31,6 +31,18 @@ def _dtype_tag(t):
     raise RuntimeError("embeddings must be a floating tensor")
 
 
+def register_offsets(offsets, L):
+    """First sight of this offsets tensor object (or of its contents): hand the library the host copy, so that a table living at an
+    address recycled from an earlier encoder's can never be mistaken for that one (one small D2H copy per offsets tensor)."""
+    if getattr(offsets, "_nerftex_registered", None) != offsets._version:
+        host = offsets.detach().to("cpu", torch.int32).contiguous()
+        check(lib.nerftex_grid_register_offsets(ptr(offsets), L, host.data_ptr()))
+        try:
+            offsets._nerftex_registered = offsets._version
+        except AttributeError:
+            pass
+
+
 class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -47,15 +59,7 @@ class _grid_encode(Function):
         S = float(np.log2(per_level_scale))
         H = int(base_resolution)
 
-        if getattr(offsets, "_nerftex_registered", None) != offsets._version:
-            # first sight of this tensor object (or of its contents): hand the library the host copy, so that a table living at an
-            # address recycled from an earlier encoder's can never be mistaken for that one (one small D2H copy per offsets tensor)
-            host = offsets.detach().to("cpu", torch.int32).contiguous()
-            check(lib.nerftex_grid_register_offsets(ptr(offsets), L, host.data_ptr()))
-            try:
-                offsets._nerftex_registered = offsets._version
-            except AttributeError:
-                pass
+        register_offsets(offsets, L)
 
         if torch.is_autocast_enabled() and C % 2 == 0:
             embeddings = embeddings.to(torch.half)

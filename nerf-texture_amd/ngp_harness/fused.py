@@ -61,6 +61,88 @@ sigma_geo_dir = _sigma_geo_dir.apply
 color_out = _color_out.apply
 
 
+class _ngp_field(Function):
+    """The whole --ff field (nerf/network_ff.py:85-101) as two launches forward: the hash-grid gather writing level-major features and
+    nerftex_field_forward (both MLPs, trunc_exp, SH, concat, sigmoid in one kernel; no transpose, no intermediate read-backs).  The
+    backward is the chain of the existing entry points on the side outputs the forward kernel left (bit-identical to the unfused field:
+    tests/test_gpu_field_glue.py)."""
+
+    @staticmethod
+    def forward(ctx, x, dirs, table, offsets, ws, wc, enc, training):
+        import numpy as np
+
+        from nerftex_hip import F16, LAYOUT_LBC
+
+        from gridencoder.grid import register_offsets
+
+        x = x.contiguous().float()
+        dirs = dirs.contiguous().float()
+        B = x.shape[0]
+        L, C, D = offsets.shape[0] - 1, table.shape[1], x.shape[1]
+        assert (L, C, D) == (16, 2, 3) and B % 128 == 0
+        register_offsets(offsets, L)
+        table_h = table if table.dtype == torch.float16 else table.to(torch.float16)
+        ws_h = ws if ws.dtype == torch.float16 else ws.to(torch.float16)
+        wc_h = wc if wc.dtype == torch.float16 else wc.to(torch.float16)
+        S, H, gridtype, align, bound = float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id), int(bool(enc.align_corners)), enc_bound(enc)
+        dev = x.device
+        feats = torch.empty(L, B, C, dtype=torch.float16, device=dev)
+        dummy = torch.empty(1, dtype=torch.float16, device=dev)
+        affine = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
+        check(lib.nerftex_grid_encode_forward_affine(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, 0, ptr(dummy), gridtype, align, F16,
+                                                     LAYOUT_LBC, affine[0], affine[1], stream()))
+        sigma = torch.empty(B, dtype=torch.float32, device=dev)
+        rgbs = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        if training:
+            x_rows = torch.empty(B, 32, dtype=torch.float16, device=dev)
+            h = torch.empty(B, 16, dtype=torch.float16, device=dev)
+            cin = torch.empty(B, 32, dtype=torch.float16, device=dev)
+            hc = torch.empty(B, 16, dtype=torch.float16, device=dev)
+            check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), ptr(hc),
+                                            stream()))
+            ctx.save_for_backward(x, table_h, offsets, ws_h, wc_h, x_rows, h, cin, rgbs)
+            ctx.meta = (S, H, gridtype, align, affine, table.dtype, ws.dtype, wc.dtype)
+        else:
+            check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
+        ctx.set_materialize_grads(False)
+        return sigma, rgbs
+
+    @staticmethod
+    def backward(ctx, grad_sigma, grad_rgbs):
+        from nerftex_hip import F16, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE
+
+        x, table_h, offsets, ws_h, wc_h, x_rows, h, cin, rgbs = ctx.saved_tensors
+        S, H, gridtype, align, affine, t_dtype, ws_dtype, wc_dtype = ctx.meta
+        B, dev = x.shape[0], x.device
+        half = dict(dtype=torch.float16, device=dev)
+        grad_sigma = torch.zeros(B, dtype=torch.float32, device=dev) if grad_sigma is None else grad_sigma.contiguous().float()
+        grad_rgbs = torch.zeros(B, 3, dtype=torch.float32, device=dev) if grad_rgbs is None else grad_rgbs.contiguous().float()
+        grad_hc = torch.empty(B, 16, **half)
+        check(lib.nerftex_field_out_backward(ptr(grad_rgbs), ptr(rgbs), B, ptr(grad_hc), stream()))
+        grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc_h)
+        check(lib.nerftex_ffmlp_backward(ptr(grad_hc), ptr(cin), ptr(wc_h), None, B, 32, 16, 64, 3, 0, 6, 1, None, ptr(grad_cin), ptr(grad_wc), stream()))
+        grad_h = torch.empty(B, 16, **half)
+        check(lib.nerftex_field_mid_backward(ptr(grad_sigma), ptr(grad_cin), ptr(h), B, ptr(grad_h), stream()))
+        grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)
+        check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws_h), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
+        grad_table = torch.empty_like(table_h)
+        dummy = torch.empty(1, **half)
+        check(lib.nerftex_grid_encode_backward_affine(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, 0,
+                                                      ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1],
+                                                      stream()))
+        return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None
+
+
+def enc_bound(enc):
+    return getattr(enc, "_field_bound", 1.0)
+
+
+def ngp_field(x, dirs, encoder, sigma_net, color_net, bound, training):
+    """sigma [B] fp32, rgbs [B,3] fp32 of the --ff field for B % 128 == 0 points, fp16 kernels (call under autocast)."""
+    encoder._field_bound = float(bound)
+    return _ngp_field.apply(x, dirs, encoder._table(), encoder.offsets, sigma_net._weights(), color_net._weights(), encoder, bool(training))
+
+
 class _render_tail(Function):
     """image + (1 - weights_sum) * bg, depth normalisation and mean squared error against `target` in one launch
     (nerf/renderer.py:417-425 + the MSE of nerf/utils.py:602-640); returns (image_out, depth_out, loss * loss_mul, scaled loss).

@@ -40,7 +40,7 @@ trunc_exp = _trunc_exp.apply
 
 class NGPField(nn.Module):
     def __init__(self, bound=2.0, mlp="torch", num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64,
-                 fused_glue=False, mlp_dtype=torch.float16):
+                 fused_glue=False, mlp_dtype=torch.float16, fused_field=True):
         super().__init__()
         assert mlp in ("torch", "ffmlp")
         self.bound = bound
@@ -48,6 +48,8 @@ class NGPField(nn.Module):
         # fused_glue: the elementwise ops between / after the two FFMLPs as two HIP kernels per direction (ngp_harness/fused.py),
         # and the FFMLPs fed without the reference's extra 128-row pad copy (the sample buffers are multiples of 128 already)
         self.fused_glue = bool(fused_glue) and mlp == "ffmlp" and geo_feat_dim == 15 and mlp_dtype == torch.float16  # the glue kernels are fp16
+        # fused_field (on top of fused_glue): everything behind the hash-grid gather as ONE kernel forward (nerftex_field_forward)
+        self.fused_field = self.fused_glue and bool(fused_field) and (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
         self.geo_feat_dim = geo_feat_dim
         self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                                    desired_resolution=2048 * bound, gridtype="hash", align_corners=True)
@@ -92,7 +94,12 @@ class NGPField(nn.Module):
         return sigma, fused.color_out(hc), {}
 
     def forward(self, x, d, **kwargs):
-        if self.fused_glue and x.shape[0] % 128 == 0 and torch.is_autocast_enabled():
+        if self.fused_glue and x.shape[0] % 128 == 0 and x.shape[0] > 0 and torch.is_autocast_enabled():
+            if self.fused_field and x.dtype == torch.float32 and torch.get_autocast_dtype("cuda") == torch.float16:
+                from . import fused
+
+                sigma, rgbs = fused.ngp_field(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, self.training and torch.is_grad_enabled())
+                return sigma, rgbs, {}
             return self._forward_fused(x, d)
         sigma, geo_feat = self._sigma_feat(x)
         d = self.encoder_dir(d)
