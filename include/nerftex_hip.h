@@ -225,6 +225,23 @@ int nerftex_field_forward(const void* feats_lbc, const float* dirs, const void* 
                           uint32_t B, float* sigma, float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Extension (the sync-free inference loop): the two field launches of
+ * an inference iteration sized by an UPPER BOUND of the alive-ray count -- the loop of
+ * nerf/renderer.py:455-483 without its `alive_counter.item()` -- skip the rows that carry
+ * nothing: only the first units_dev[0] * rows_per_unit points (alive rays x n_step) are
+ * encoded / shaded, the rest of the outputs is left untouched (nerftex_composite_rays_dev
+ * never reads it).  Otherwise nerftex_grid_encode_forward_affine (no dy_dx) and the
+ * inference form of nerftex_field_forward; units_dev NULL = all B rows.
+ * ------------------------------------------------------------------------- */
+int nerftex_grid_encode_forward_rows(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                     int align_corners, int dtype, int layout, float in_add, float in_mul,
+                                     const int32_t* units_dev, uint32_t rows_per_unit, void* stream);
+int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                               uint32_t B, float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit,
+                               void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Extension: the curved-field projector in one kernel --
  * MeshProjector.project (tools/map.py:414-433) with its coarse normal from the K
  * nearest mesh vertices (knn(), :454-501, use_dir_vec=True, Shepard weights), the

@@ -41,14 +41,14 @@ constexpr T div_up(T a, T b) { return (a + b - 1) / b; }
 
 // compute units of the current device (256 on an MI355X)
 inline int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    static int cus[16] = {0};  // per device: a process may drive GPUs of different sizes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cus[dev] == 0) {
         hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    return cus;
+    return cus[dev];
 }
 
 // ---- tuning knobs (runtime.hip) ----------------------------------------------------------------------------------------

@@ -82,7 +82,12 @@ using namespace nerftex;
     }
 extern "C" int nerftex_field_forward(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B, float* sigma,
                                      float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream) {
-    return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, x_rows, h, cin, hc, stream);
+    return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, x_rows, h, cin, hc, nullptr, 0, stream);
+}
+extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
+                                          float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {
+    return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, nullptr, nullptr, nullptr, nullptr, units_dev,
+                                          rows_per_unit, stream);
 }
 NERFTEX_FFMLP_ENTRIES(, ffmlp_f16)        // the reference's exports (ffmlp/src/bindings.cpp:5-10)
 NERFTEX_FFMLP_ENTRIES(_bf16, ffmlp_bf16)  // extension: the same three on bf16 tensors

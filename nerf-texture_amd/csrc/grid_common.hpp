@@ -21,6 +21,9 @@ struct LevelConsts {
     // ops over the [B, D] inputs before calling the kernel (gridencoder/grid.py:141, (x + bound) / (2 bound)); same two roundings
     float in_add, in_mul;
     bool in_affine;
+    // optional: only the first units_dev[0] * rows_per_unit points carry anything (a launch sized by an upper bound of a device-side count)
+    const int32_t* units_dev;
+    uint32_t rows_per_unit;
 };
 
 // coordinate d of point b as the kernels see it (identity unless the caller folded its normalisation in)

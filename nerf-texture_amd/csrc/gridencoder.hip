@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     if (level >= L) return;
     const uint32_t b = (q % nchunks) * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (lc.units_dev && b >= (uint32_t)lc.units_dev[0] * lc.rows_per_unit) return;
 
     float x[D];
     bool oob = false;
@@ -766,7 +767,7 @@ int launch_forward(const float* inputs, const T* emb, const int* offsets, T* out
     if (by_level) {
         T* lbc = outputs;
         if (layout == NERFTEX_LAYOUT_BLC) {
-            lbc = static_cast<T*>(workspace(kWsGridFwd, sizeof(T) * (size_t)B * L * C));
+            lbc = static_cast<T*>(workspace(kWsGridFwd, sizeof(T) * (size_t)B * L * C, st));
             if (!lbc) return NERFTEX_ERR_HIP;
         }
         const uint32_t nchunks = div_up(B, 256u);
@@ -830,7 +831,7 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
             if (overwrite && (rc = clear_table()) != NERFTEX_OK) return rc;
             const T* g = grad;
             if (blc) {  // the sweep reads level-major gradients
-                T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C));
+                T* tmp = static_cast<T*>(workspace(kWsGrid, sizeof(T) * (size_t)B * L * C, st));
                 if (!tmp) return NERFTEX_ERR_HIP;
                 {
                     KernelTimer kt("grad_to_level_major_kernel", st, kTimeGrid);
@@ -950,7 +951,7 @@ int affine_ok(float in_mul) {
 }
 int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
-                       int layout, bool affine, float in_add, float in_mul, void* stream);
+                       int layout, bool affine, float in_add, float in_mul, void* stream, const int32_t* units_dev = nullptr, uint32_t rows_per_unit = 0);
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                         int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream);
@@ -974,6 +975,16 @@ extern "C" int nerftex_grid_encode_forward_affine(const float* inputs, const voi
                               layout, true, in_add, in_mul, stream);
 }
 
+extern "C" int nerftex_grid_encode_forward_rows(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                                                uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                                int layout, float in_add, float in_mul, const int32_t* units_dev, uint32_t rows_per_unit,
+                                                void* stream) {
+    clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    return grid_forward_entry(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 0, nullptr, gridtype, align_corners, dtype, layout, true, in_add,
+                              in_mul, stream, units_dev, rows_per_unit);
+}
+
 extern "C" int nerftex_grid_encode_backward_affine(const void* grad, const float* inputs, const void* embeddings,
                                                    const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                                                    uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
@@ -989,11 +1000,13 @@ extern "C" int nerftex_grid_encode_backward_affine(const void* grad, const float
 namespace {
 int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
-                       int layout, bool affine, float in_add, float in_mul, void* stream) {
+                       int layout, bool affine, float in_add, float in_mul, void* stream, const int32_t* units_dev, uint32_t rows_per_unit) {
     if (!affine) clear_error();
     int rc = check_common(L, dtype, layout);
     if (rc != NERFTEX_OK) return rc;
-    const LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
+    LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
+    lc.units_dev = units_dev;
+    lc.rows_per_unit = rows_per_unit;
     if (dtype == NERFTEX_F32)
         return dispatch_forward<float>(inputs, embeddings, offsets, outputs, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
                                        gridtype, align_corners != 0, layout, as_stream(stream));

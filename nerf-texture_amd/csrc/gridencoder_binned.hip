@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     if (blockIdx.x == 0 && threadIdx.x <= L && offsets[threadIdx.x] != tab.offsets[threadIdx.x]) __builtin_trap();  // host copy vs device table
     const uint32_t group = blockIdx.x / (kXcds * L), rem = blockIdx.x % (kXcds * L);
     const uint32_t level = rem / kXcds, chunk = group * kXcds + rem % kXcds;  // id % 8 = chunk % 8 = the XCD that runs it
-    if (chunk >= nchunks) return;
+    if (chunk >= nchunks || probe == 5) return;  // ablation 5: launch only
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
     // caller handed over an uninitialised gradient table: the tiles of this level that several K4d work items will add into
@@ -298,6 +298,10 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
 #pragma unroll
     for (int d = 0; d < D; d++) xs[d] = in_batch ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
     if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
+    if (probe == 4) {  // ablation: launch + loads only
+        if (xs[0] == 1234.5f && xs[D - 1] == 77.0f && g[1] == 3.0f && g[0] == 2.0f) dir[0] = 1;
+        return;
+    }
     const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
     Sample<T, D> sm;
     make_sample<T, D>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, merge_runs);
@@ -579,7 +583,7 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     dt.tile_base[L] = tiles;
     dt.item_base[L] = items;
     const size_t dir_bytes = (sizeof(uint32_t) * (size_t)L * kMaxTilesPerLevel * nchunks + 255) / 256 * 256;
-    char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords));
+    char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
     if (!dbase) return NERFTEX_ERR_HIP;
     uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
     Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes);

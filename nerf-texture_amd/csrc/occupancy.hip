@@ -309,7 +309,7 @@ extern "C" int nerftex_occupancy_sample_partial(const float* density_grid, uint3
     const uint32_t H3 = H * H * H, nblk = div_up(H3, kBlock);
     // scratch: block sums [cascade, nblk], counts [cascade] (when the caller does not want them), the occupied lists [cascade, H^3]
     const size_t head = (sizeof(uint32_t) * ((size_t)cascade * nblk + kMaxCascade) + 255) / 256 * 256;
-    char* base = static_cast<char*>(workspace(kWsOccupancyList, head + sizeof(int32_t) * (size_t)cascade * H3));
+    char* base = static_cast<char*>(workspace(kWsOccupancyList, head + sizeof(int32_t) * (size_t)cascade * H3, st));
     if (!base) return NERFTEX_ERR_HIP;
     uint32_t* bsum = reinterpret_cast<uint32_t*>(base);
     uint32_t* n_occ = n_occupied ? n_occupied : bsum + (size_t)cascade * nblk;
@@ -345,7 +345,7 @@ extern "C" int nerftex_occupancy_update(float* density_grid, const float* sigmas
     const uint32_t ema_blocks = (uint32_t)div_up(n, (size_t)kBlock * kEmaPerThread);
     // scratch: block partials, (partial updates) the tmp grid
     const size_t head = (sizeof(double) * (size_t)ema_blocks + 255) / 256 * 256;
-    char* base = static_cast<char*>(workspace(kWsOccupancy, head + (indices ? sizeof(float) * n : 0)));
+    char* base = static_cast<char*>(workspace(kWsOccupancy, head + (indices ? sizeof(float) * n : 0), st));
     if (!base) return NERFTEX_ERR_HIP;
     double* partial = reinterpret_cast<double*>(base);
     const float* tmp = sigmas;

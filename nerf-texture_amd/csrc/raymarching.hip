@@ -1042,7 +1042,7 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     const size_t log_bytes = sizeof(float) * (size_t)N * max_steps;
     const long force = knob(kKnobMarch);  // 1 replay | 2 log: A/B switch for profiling
     const bool use_log = force ? force == 2 : (log_bytes <= ((size_t)1 << 30));
-    char* base = static_cast<char*>(workspace(kWsMarch, head + (use_log ? log_bytes : 0)));
+    char* base = static_cast<char*>(workspace(kWsMarch, head + (use_log ? log_bytes : 0), as_stream(stream)));
     if (!base) return NERFTEX_ERR_HIP;
     uint32_t* ws = reinterpret_cast<uint32_t*>(base);
     float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
@@ -1256,7 +1256,7 @@ static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
     const uint32_t nblocks = div_up(n_alive, kBlock);
-    uint32_t* ws = static_cast<uint32_t*>(workspace(kWsCompact, sizeof(uint32_t) * (1 + (size_t)nblocks)));
+    uint32_t* ws = static_cast<uint32_t*>(workspace(kWsCompact, sizeof(uint32_t) * (1 + (size_t)nblocks), as_stream(stream)));
     if (!ws) return NERFTEX_ERR_HIP;
     hipStream_t st = as_stream(stream);
     {

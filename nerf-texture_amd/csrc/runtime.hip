@@ -65,26 +65,38 @@ struct KnobInit {
 namespace {
 constexpr int kMaxDevices = 16;
 struct Slot { void* ptr = nullptr; size_t bytes = 0; };
-Slot g_ws[kMaxDevices][kWsSlots];
+struct SlotSet { Slot slot[kWsSlots]; };
+std::map<hipStream_t, SlotSet> g_ws[kMaxDevices];  // a handful of streams per device
+const hipStream_t kCaptureSet = reinterpret_cast<hipStream_t>(~(uintptr_t)0);  // key of the set shared by all stream captures
 std::vector<void*> g_retired;  // outgrown buffers: kept until release_workspaces() because a captured HIP graph may still launch
                                // kernels that were recorded with the old pointer (growth is geometric, so there are only a few)
 std::mutex g_ws_mutex;
 }  // namespace
 
-void* workspace(WorkspaceSlot slot, size_t bytes) {
+void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
         set_error("workspace: bad device");
         return nullptr;
     }
+    // A stream under capture is a one-off handle; what it records is replayed later, on some other stream, against the pointers baked
+    // in now.  All captures share one set (graphs that use it must not be replayed concurrently with each other: INTEGRATION.md) instead
+    // of leaving one set per captured graph behind.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) stream = kCaptureSet;
     std::lock_guard<std::mutex> lock(g_ws_mutex);
-    Slot& s = g_ws[dev][slot];
+    Slot& s = g_ws[dev][stream].slot[slot];
     if (s.bytes < bytes) {
         if (s.ptr) g_retired.push_back(s.ptr);
         s.ptr = nullptr;
         s.bytes = 0;
         size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
-        if (hipMalloc(&s.ptr, want) != hipSuccess) {
+        // an allocation while some stream of the process is being captured is legal only in the relaxed capture mode
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        const hipError_t err = hipMalloc(&s.ptr, want);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (err != hipSuccess) {
             set_error("workspace: hipMalloc(%zu) failed", want);
             s.ptr = nullptr;
             return nullptr;
@@ -96,11 +108,12 @@ void* workspace(WorkspaceSlot slot, size_t bytes) {
 
 void release_workspaces() {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
-    for (auto& d : g_ws)
-        for (auto& s : d) {
-            if (s.ptr) (void)hipFree(s.ptr);
-            s = Slot{};
-        }
+    for (auto& d : g_ws) {
+        for (auto& per_stream : d)
+            for (auto& s : per_stream.second.slot)
+                if (s.ptr) (void)hipFree(s.ptr);
+        d.clear();
+    }
     for (void* p : g_retired) (void)hipFree(p);
     g_retired.clear();
 }

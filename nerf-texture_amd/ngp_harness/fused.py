@@ -68,7 +68,7 @@ class _ngp_field(Function):
     tests/test_gpu_field_glue.py)."""
 
     @staticmethod
-    def forward(ctx, x, dirs, table, offsets, ws, wc, enc, training):
+    def forward(ctx, x, dirs, table, offsets, ws, wc, enc, training, live=None):
         import numpy as np
 
         from nerftex_hip import F16, LAYOUT_LBC
@@ -89,10 +89,19 @@ class _ngp_field(Function):
         feats = torch.empty(L, B, C, dtype=torch.float16, device=dev)
         dummy = torch.empty(1, dtype=torch.float16, device=dev)
         affine = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
-        check(lib.nerftex_grid_encode_forward_affine(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, 0, ptr(dummy), gridtype, align, F16,
-                                                     LAYOUT_LBC, affine[0], affine[1], stream()))
         sigma = torch.empty(B, dtype=torch.float32, device=dev)
         rgbs = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        if live is not None and not training:  # (device count of units, rows per unit): rows past count * rows carry nothing
+            units, rows_per_unit = live
+            assert units.dtype == torch.int32 and units.device == dev
+            check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, gridtype, align, F16, LAYOUT_LBC,
+                                                       affine[0], affine[1], ptr(units), int(rows_per_unit), stream()))
+            check(lib.nerftex_field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(units), int(rows_per_unit),
+                                                 stream()))
+            ctx.set_materialize_grads(False)
+            return sigma, rgbs
+        check(lib.nerftex_grid_encode_forward_affine(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, 0, ptr(dummy), gridtype, align, F16,
+                                                     LAYOUT_LBC, affine[0], affine[1], stream()))
         if training:
             x_rows = torch.empty(B, 32, dtype=torch.float16, device=dev)
             h = torch.empty(B, 16, dtype=torch.float16, device=dev)
@@ -130,17 +139,56 @@ class _ngp_field(Function):
         check(lib.nerftex_grid_encode_backward_affine(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, 0,
                                                       ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1],
                                                       stream()))
-        return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None
+        return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None
+
+
+_INFER_CACHE = {}
+
+
+def ngp_field_infer(x, dirs, encoder, sigma_net, color_net, bound, live=None):
+    """The no-grad form of `ngp_field` for a loop that calls it a few dozen times per frame: two launches and nothing else -- the level
+    constants and the fp16 copies of the MLP weights are kept between calls (re-made when a parameter changes), no autograd node.
+    x [B,3] fp32 contiguous, dirs [B,3] fp32 contiguous, B % 128 == 0; call under autocast(float16)."""
+    import numpy as np
+
+    from nerftex_hip import F16, LAYOUT_LBC
+
+    from gridencoder.grid import register_offsets
+
+    B, dev = x.shape[0], x.device
+    table_h = encoder._table()
+    ws, wc = sigma_net._weights(), color_net._weights()
+    key = id(encoder)
+    c = _INFER_CACHE.get(key)
+    stamp = (ws._version, ws.data_ptr(), wc._version, wc.data_ptr(), float(bound), encoder.offsets.data_ptr())
+    if c is None or c[0] != stamp:
+        L = encoder.offsets.shape[0] - 1
+        register_offsets(encoder.offsets, L)
+        c = (stamp, L, float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), int(encoder.gridtype_id), int(bool(encoder.align_corners)),
+             float(bound), float(np.float32(1.0) / np.float32(2 * bound)), ws.detach().to(torch.float16), wc.detach().to(torch.float16))
+        _INFER_CACHE[key] = c
+    _, L, S, H, gridtype, align, add, mul, ws_h, wc_h = c
+    assert table_h.dtype == torch.float16 and (L, table_h.shape[1], x.shape[1]) == (16, 2, 3) and B % 128 == 0
+    feats = torch.empty(L, B, 2, dtype=torch.float16, device=dev)
+    out = torch.empty(4 * B, dtype=torch.float32, device=dev)  # [sigma | rgb] in one allocation
+    sigma, rgbs = out[:B], out[B:].view(B, 3)
+    units, rows_per_unit = (ptr(live[0]), int(live[1])) if live is not None else (None, 0)
+    st = stream()
+    check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table_h), ptr(encoder.offsets), ptr(feats), B, 3, 2, L, S, H, gridtype, align, F16, LAYOUT_LBC, add,
+                                               mul, units, rows_per_unit, st))
+    check(lib.nerftex_field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), units, rows_per_unit, st))
+    return sigma, rgbs
 
 
 def enc_bound(enc):
     return getattr(enc, "_field_bound", 1.0)
 
 
-def ngp_field(x, dirs, encoder, sigma_net, color_net, bound, training):
-    """sigma [B] fp32, rgbs [B,3] fp32 of the --ff field for B % 128 == 0 points, fp16 kernels (call under autocast)."""
+def ngp_field(x, dirs, encoder, sigma_net, color_net, bound, training, live=None):
+    """sigma [B] fp32, rgbs [B,3] fp32 of the --ff field for B % 128 == 0 points, fp16 kernels (call under autocast).
+    live = (int32 device tensor, rows per unit), inference only: just the first live[0][0] * live[1] points are evaluated."""
     encoder._field_bound = float(bound)
-    return _ngp_field.apply(x, dirs, encoder._table(), encoder.offsets, sigma_net._weights(), color_net._weights(), encoder, bool(training))
+    return _ngp_field.apply(x, dirs, encoder._table(), encoder.offsets, sigma_net._weights(), color_net._weights(), encoder, bool(training), live)
 
 
 class _render_tail(Function):

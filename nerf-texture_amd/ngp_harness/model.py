@@ -98,7 +98,8 @@ class NGPField(nn.Module):
             if self.fused_field and x.dtype == torch.float32 and torch.get_autocast_dtype("cuda") == torch.float16:
                 from . import fused
 
-                sigma, rgbs = fused.ngp_field(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, self.training and torch.is_grad_enabled())
+                sigma, rgbs = fused.ngp_field(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, self.training and torch.is_grad_enabled(),
+                                              live=kwargs.get("live"))
                 return sigma, rgbs, {}
             return self._forward_fused(x, d)
         sigma, geo_feat = self._sigma_feat(x)
@@ -111,6 +112,17 @@ class NGPField(nn.Module):
         else:
             h = self._chain(self.color_net, torch.cat([d.to(geo_feat.dtype), geo_feat], dim=-1))
         return sigma, torch.sigmoid(h), {}
+
+    @torch.no_grad()
+    def infer(self, x, d, live=None):
+        """(sigma, rgbs) without autograd bookkeeping: the fused field's two launches when it applies, else forward()."""
+        if (self.fused_glue and self.fused_field and x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.float16 and self.encoder._table().dtype == torch.float16):
+            from . import fused
+
+            return fused.ngp_field_infer(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, live)
+        sigma, rgbs, _ = self.forward(x, d, live=live)
+        return sigma, rgbs
 
     def density(self, x):
         sigma, geo_feat = self._sigma_feat(x)
@@ -326,8 +338,9 @@ class Renderer(nn.Module):
         return image, depth
 
     @torch.no_grad()
-    def render_infer(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024):
-        """Inference branch of run_cuda (:436-487), including its per-iteration alive-count read-back."""
+    def render_infer(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024, slots_per_ray=1):
+        """Inference branch of run_cuda (:436-487), including its per-iteration alive-count read-back (slots_per_ray: see
+        render_infer_pipelined; 1 = the reference's schedule)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         N, dev = rays_o.shape[0], rays_o.device
@@ -351,7 +364,8 @@ class Renderer(nn.Module):
                 n_alive = alive_counter.item()
             if n_alive <= 0:
                 break
-            n_step = max(min(N // n_alive, 8), 1)
+            F = int(slots_per_ray)
+            n_step = max(min(F * N // n_alive, 8 * F), F)
             xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], rays_o, rays_d, self.bound,
                                                         self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128, perturb, dt_gamma,
                                                         max_steps)
@@ -367,67 +381,130 @@ class Renderer(nn.Module):
         return image, depth, n_samples
 
     @torch.no_grad()
-    def render_infer_pipelined(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024):
+    def render_infer_pipelined(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024, slots_per_ray=1, parts=1):
         """The inference loop of run_cuda (nerf/renderer.py:436-487) without its per-iteration stall: the reference reads the alive count
         back (`alive_counter.item()`, :469) before it can size the next launches, so the device idles while the host wakes up and
         enqueues ~12 launches, 60 times per frame.  Here iteration i is launched with the count of iteration i-1 as an upper bound
         (alive rays never increase; that number was copied to pinned memory a whole iteration ago) and the kernels read the true count
-        from the device (nerftex_*_rays_dev).  Per ray the arithmetic is that of the reference loop: the image is the same."""
-        from collections import deque
+        from the device (nerftex_*_rays_dev).  Per ray the arithmetic is that of the reference loop: the image is the same.
 
-        from nerftex_hip import check, lib, ptr, stream
+        slots_per_ray: the reference sizes an iteration to N sample slots (n_step = clamp(N // n_alive, 1, 8), :470) because its buffers
+        are N rows; with F = slots_per_ray > 1 an iteration gets F N slots (n_step = clamp(F N // n_alive, F, 8 F)): F times fewer
+        iterations -- each pays a compaction, ~12 launches and the march kernel's slowest ray -- for at most n_step - 1 marched-but-unused
+        samples per ray, once, at the chunk where it terminates.  A ray's samples and the order they are composited in do not depend on how
+        they are cut into chunks, so the image does not change (tests/test_gpu_training.py).
 
+        parts: the rays are cut into `parts` contiguous ranges, each with its own loop on its own stream, enqueued turn by turn: the
+        marching, compaction and compositing of one range (one thread per ray, bound by the latency of its slowest ray) run under the
+        hash-grid gather of another (bound by cache bandwidth).  Rays do not interact, so the image does not change either."""
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
-        N, dev = rays_o.shape[0], rays_o.device
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
-        weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
-        depth = torch.zeros(N, dtype=torch.float32, device=dev)
-        image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
-        rays_alive = torch.zeros(2, N, dtype=torch.int32, device=dev)
-        rays_t = torch.zeros(2, N, dtype=torch.float32, device=dev)
-        counters = torch.tensor([N, 0], dtype=torch.int32, device=dev)
-        ring = 4
-        host = torch.empty(ring, dtype=torch.int32).pin_memory()
-        events = [torch.cuda.Event() for _ in range(ring)]
-        pending = deque()
-        torch.arange(N, out=rays_alive[0])
-        rays_t[0] = nears
-        bound, step, i, n_samples = N, 0, 0, 0
-        perturb_u32 = int(perturb)
-        while step < max_steps:
-            cur, old = i % 2, (i + 1) % 2
-            if i > 0:
-                check(lib.nerftex_compact_rays_dev(bound, ptr(counters[old:]), ptr(rays_alive[cur]), ptr(rays_alive[old]), ptr(rays_t[cur]), ptr(rays_t[old]),
-                                                   ptr(counters[cur:]), stream()))
-                slot = i % ring
-                host[slot:slot + 1].copy_(counters[cur:cur + 1], non_blocking=True)
-                events[slot].record()
-                pending.append(slot)
-                while len(pending) > 1:  # every count but the one just requested is (long) done: no stall
-                    s = pending.popleft()
-                    events[s].synchronize()
-                    bound = min(bound, int(host[s]))
-                if bound <= 0:
-                    break
-            n_step = max(min(N // bound, 8), 1)
-            M = bound * n_step
-            M += 128 - M % 128
-            xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-            dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-            deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
-            check(lib.nerftex_march_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(rays_o), ptr(rays_d), float(self.bound),
-                                             float(dt_gamma), int(max_steps), self.cascade, self.grid_size, ptr(self.density_bitfield), ptr(fars), ptr(xyzs),
-                                             ptr(dirs), ptr(deltas), perturb_u32, stream()))
-            sigmas, rgbs, _ = self.field(xyzs, dirs)
-            if self.density_scale != 1:
-                sigmas = self.density_scale * sigmas
-            sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
-            check(lib.nerftex_composite_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(sigmas), ptr(rgbs), ptr(deltas),
-                                                 ptr(weights_sum), ptr(depth), ptr(image), stream()))
-            n_samples += M
-            step += n_step
-            i += 1
-        self.last_iters = i
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        return image, depth, n_samples
+        N = rays_o.shape[0]
+        parts = max(1, min(int(parts), N))
+        if parts == 1:
+            part = _InferPart(self, rays_o, rays_d, dt_gamma, perturb, max_steps, slots_per_ray)
+            while part.step():
+                pass
+            self.last_iters = part.i
+            return part.image + (1 - part.weights_sum).unsqueeze(-1) * bg_color, part.depth, part.n_samples
+        main = torch.cuda.current_stream()
+        streams = getattr(self, "_infer_streams", [])
+        while len(streams) < parts:
+            streams.append(torch.cuda.Stream(device=rays_o.device))
+        self._infer_streams = streams
+        per = -(-N // parts)
+        jobs = []
+        for k in range(parts):
+            lo, hi = k * per, min(N, (k + 1) * per)
+            streams[k].wait_stream(main)
+            with torch.cuda.stream(streams[k]):
+                jobs.append(_InferPart(self, rays_o[lo:hi], rays_d[lo:hi], dt_gamma, perturb, max_steps, slots_per_ray, ray_base=lo))
+        active = list(range(parts))
+        while active:
+            for k in list(active):
+                with torch.cuda.stream(streams[k]):
+                    if not jobs[k].step():
+                        active.remove(k)
+        for k in range(parts):
+            main.wait_stream(streams[k])
+            for t in (jobs[k].image, jobs[k].depth, jobs[k].weights_sum):
+                t.record_stream(main)
+        image = torch.cat([j.image for j in jobs])
+        weights_sum = torch.cat([j.weights_sum for j in jobs])
+        depth = torch.cat([j.depth for j in jobs])
+        self.last_iters = max(j.i for j in jobs)
+        return image + (1 - weights_sum).unsqueeze(-1) * bg_color, depth, sum(j.n_samples for j in jobs)
+
+
+class _InferPart:
+    """One range of rays going through the sync-free inference loop (Renderer.render_infer_pipelined); step() enqueues one iteration
+    on the current stream and says whether there is another one."""
+
+    def __init__(self, renderer, rays_o, rays_d, dt_gamma, perturb, max_steps, slots_per_ray, ray_base=0):
+        from collections import deque
+
+        self.r, self.rays_o, self.rays_d = renderer, rays_o.contiguous(), rays_d.contiguous()
+        self.dt_gamma, self.max_steps, self.F = float(dt_gamma), int(max_steps), int(slots_per_ray)
+        N, dev = self.rays_o.shape[0], self.rays_o.device
+        self.N = N
+        self.nears, self.fars = raymarching.near_far_from_aabb(self.rays_o, self.rays_d, renderer.aabb_infer, renderer.min_near)
+        self.weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        self.rays_alive = torch.zeros(2, N, dtype=torch.int32, device=dev)
+        self.rays_t = torch.zeros(2, N, dtype=torch.float32, device=dev)
+        self.counters = torch.tensor([N, 0], dtype=torch.int32, device=dev)
+        self.ring = 4
+        self.host = torch.empty(self.ring, dtype=torch.int32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.ring)]
+        self.pending = deque()
+        torch.arange(N, out=self.rays_alive[0])
+        self.rays_t[0] = self.nears
+        self.bound, self.step_no, self.i, self.n_samples = N, 0, 0, 0
+        # the start jitter of the reference is seeded per ray by its index in the alive list, which for the first iteration is the ray id
+        assert not (perturb and ray_base), "perturbed inference: one part only (the jitter is seeded by the position in the alive list)"
+        self.perturb_u32 = int(perturb)
+
+    def step(self):
+        from nerftex_hip import check, lib, ptr, stream
+
+        r, N, dev = self.r, self.N, self.rays_o.device
+        if self.step_no >= self.max_steps:
+            return False
+        i = self.i
+        cur, old = i % 2, (i + 1) % 2
+        counters, rays_alive, rays_t = self.counters, self.rays_alive, self.rays_t
+        if i > 0:
+            check(lib.nerftex_compact_rays_dev(self.bound, ptr(counters[old:]), ptr(rays_alive[cur]), ptr(rays_alive[old]), ptr(rays_t[cur]), ptr(rays_t[old]),
+                                               ptr(counters[cur:]), stream()))
+            slot = i % self.ring
+            self.host[slot:slot + 1].copy_(counters[cur:cur + 1], non_blocking=True)
+            self.events[slot].record()
+            self.pending.append(slot)
+            while len(self.pending) > 1:  # every count but the one just requested is (long) done: no stall
+                s = self.pending.popleft()
+                self.events[s].synchronize()
+                self.bound = min(self.bound, int(self.host[s]))
+            if self.bound <= 0:
+                return False
+        bound, F = self.bound, self.F
+        n_step = max(min(F * N // bound, 8 * F), F)
+        M = bound * n_step
+        M += 128 - M % 128
+        buf = torch.zeros(M * 8, dtype=torch.float32, device=dev)  # the three zero-filled outputs of march_rays (raymarching.py:385-387), one fill
+        xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:].view(M, 2)
+        check(lib.nerftex_march_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(self.rays_o), ptr(self.rays_d),
+                                         float(r.bound), self.dt_gamma, self.max_steps, r.cascade, r.grid_size, ptr(r.density_bitfield), ptr(self.fars),
+                                         ptr(xyzs), ptr(dirs), ptr(deltas), self.perturb_u32, stream()))
+        # live: only the first counters[cur] * n_step rows carry samples; the fused field skips the rest (their outputs are never read)
+        live = (counters[cur:], n_step)
+        sigmas, rgbs = r.field.infer(xyzs, dirs, live) if hasattr(r.field, "infer") else r.field(xyzs, dirs, live=live)[:2]
+        if r.density_scale != 1:
+            sigmas = r.density_scale * sigmas
+        sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
+        check(lib.nerftex_composite_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                             ptr(self.weights_sum), ptr(self.depth), ptr(self.image), stream()))
+        self.n_samples += M
+        self.step_no += n_step
+        self.i += 1
+        return True

@@ -132,3 +132,50 @@ def test_pipelined_inference_loop_renders_the_same_image(dev):
     torch.testing.assert_close(img_b, img_a, rtol=0, atol=1e-5)
     torch.testing.assert_close(dep_b, dep_a, rtol=0, atol=1e-5)
     assert float((img_a - 1).abs().max()) > 0.05, "the view shows the scene"
+    # Bigger chunks (F N sample slots per iteration instead of the reference's N), the rays cut into ranges that run on their own streams,
+    # rows past the device-side alive count skipped by the field kernels: a ray's samples and the order they are composited in are
+    # untouched by any of it -- the SAME image, bit for bit, in a third of the iterations.
+    with torch.autocast("cuda", dtype=torch.float16):
+        for F, parts in ((4, 1), (3, 2), (4, 3)):
+            img_c, dep_c, _ = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128, slots_per_ray=F, parts=parts)
+            assert torch.equal(img_c, img_b) and torch.equal(dep_c, dep_b), (F, parts)
+            assert r.last_iters < iters_a // 2
+        img_d, dep_d, _ = r.render_infer(ro, rd, dt_gamma=1 / 128, slots_per_ray=4)  # the reference loop itself with the bigger chunks
+        assert torch.equal(img_d, img_a) and torch.equal(dep_d, dep_a)
+
+
+def test_field_kernels_skip_rows_past_the_device_count(dev):
+    """nerftex_grid_encode_forward_rows + nerftex_field_forward_rows: the first count * rows_per_unit rows equal the full evaluation, the
+    rest of the outputs is left alone."""
+    from ngp_harness import fused
+    from ngp_harness.model import NGPField
+
+    torch.manual_seed(1)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).eval()
+    field.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    B = 16384
+    x = (torch.rand(B, 3, device=dev) * 4 - 2).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1).contiguous()
+    count = torch.tensor([1500], dtype=torch.int32, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s_full, c_full = field.infer(x, d)
+        s_full, c_full = s_full.clone(), c_full.clone()
+        s_part, c_part = field.infer(x, d, live=(count, 4))
+    live = 1500 * 4
+    assert torch.equal(s_part[:live], s_full[:live]) and torch.equal(c_part[:live], c_full[:live])
+    # whole 32-row steps past the live rows are not computed at all: with the output buffer pre-filled, the tail keeps the fill
+    flat = torch.full((4 * B,), -7.0, dtype=torch.float32, device=dev)
+    from nerftex_hip import F16, LAYOUT_LBC, check, lib, ptr, stream
+    enc = field.encoder
+    feats = torch.zeros(16, B, 2, dtype=torch.float16, device=dev)
+    with torch.autocast("cuda", dtype=torch.float16):
+        table = enc._table() if enc._table().dtype == torch.float16 else enc.embeddings.detach().half()
+    check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table), ptr(enc.offsets), ptr(feats), B, 3, 2, 16, float(np.log2(enc.per_level_scale)),
+                                               int(enc.base_resolution), int(enc.gridtype_id), int(bool(enc.align_corners)), F16, LAYOUT_LBC, 2.0, 0.25,
+                                               ptr(count), 4, stream()))
+    assert float(feats[:, live + 256:].float().abs().max()) == 0.0 and float(feats[:, :live].float().abs().max()) > 0
+    ws, wc = field.sigma_net.weights.detach().half(), field.color_net.weights.detach().half()
+    check(lib.nerftex_field_forward_rows(ptr(feats), ptr(d), ptr(ws), ptr(wc), B, ptr(flat[:B]), ptr(flat[B:]), ptr(count), 4, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(flat[:live], s_full[:live])
+    assert float((flat[live + 128:B] + 7.0).abs().max()) == 0.0

@@ -35,12 +35,47 @@ with torch.autocast("cuda", dtype=torch.float16):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
 print(json.dumps({"pipelined_ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n2), "iters": r.last_iters, "max_abs_diff": float((img2 - img).abs().max())}))
+for F in (4,):
+    with torch.autocast("cuda", dtype=torch.float16):
+        img3, _, n3 = r.render_infer(ro, rd, dt_gamma=1 / 128, slots_per_ray=F)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            img3, _, n3 = r.render_infer(ro, rd, dt_gamma=1 / 128, slots_per_ray=F)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    print(json.dumps({"reference_loop_slots_per_ray": F, "ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n3), "iters": r.last_iters, "max_abs_diff": float((img3 - img).abs().max())}))
+for F in (3, 4):
+    with torch.autocast("cuda", dtype=torch.float16):
+        img3, _, n3 = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128, slots_per_ray=F)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            img3, _, n3 = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128, slots_per_ray=F)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    print(json.dumps({"slots_per_ray": F, "ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n3), "iters": r.last_iters, "max_abs_diff": float((img3 - img).abs().max())}))
+for F, P in ((3, 2), (4, 2), (4, 3), (4, 4), (6, 2)):
+    with torch.autocast("cuda", dtype=torch.float16):
+        img3, _, n3 = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128, slots_per_ray=F, parts=P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            img3, _, n3 = r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128, slots_per_ray=F, parts=P)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    print(json.dumps({"slots_per_ray": F, "parts": P, "ms_per_frame": (t1 - t0) / frames * 1e3, "samples": int(n3), "iters": r.last_iters, "max_abs_diff": float((img3 - img).abs().max())}))
 if len(sys.argv) > 2:  # per-kernel device time of one more frame (library kernels only)
     import nerftex_hip
     nerftex_hip.kernel_profile(1, reset=True)
+    F = int(sys.argv[2])
     with torch.autocast("cuda", dtype=torch.float16):
-        r.render_infer(ro, rd, dt_gamma=1 / 128)
+        if F > 0:
+            r.render_infer_pipelined(ro, rd, dt_gamma=1 / 128, slots_per_ray=F)
+        else:
+            r.render_infer(ro, rd, dt_gamma=1 / 128)
     torch.cuda.synchronize()
     nerftex_hip.kernel_profile(0)
     k = nerftex_hip.kernel_profile()
+    print(json.dumps({"profiled": "pipelined, slots_per_ray=%d" % F if F > 0 else "reference loop", "kernel_sum_us": round(sum(v["total_us"] for v in k.values()), 1)}))
     print(json.dumps(k))

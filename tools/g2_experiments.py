@@ -85,9 +85,11 @@ def main():
         return
     res["default"], base = measure()
     res["scale"] = float(base.float().abs().max())
-    for probe in (1, 2, 3):
+    for probe in (5, 4, 1, 2, 3):
         k, _ = measure(grid_bwd_probe=probe)
         res[f"probe_k3phase{probe}"] = k.get("bin_fill")
+    k, _ = measure(grid_bwd_probe=1, grid_bwd_nomerge=1)
+    res["probe_k3phase1_nomerge"] = k.get("bin_fill")
     k, out = measure(grid_bwd_nomerge=1)
     k["max_abs_diff_vs_default"] = float((out.float() - base.float()).abs().max())
     res["nomerge"] = k
