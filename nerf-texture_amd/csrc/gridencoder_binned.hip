@@ -13,8 +13,9 @@
 //   K4d sum    a workgroup per (tile, range of chunks): fp16: every half is an integer multiple of 2^-24 below 2^16, so
 //              value * 2^24 fits 41 bits and ds_add_u64 sums are EXACT and order-independent; the tile is rounded to fp16 once
 //              (round-to-nearest-even of the true sum) -- deterministic, and tighter than the reference's chain of fp16
-//              atomics.  fp32 tables keep float LDS atomics.  Tiles with one work item are written with plain stores (sole
-//              owner), split tiles with coalesced atomics.
+//              atomics.  A tile several work items share (coarse levels) is combined in integers too: the items publish their exact
+//              partial sums, the last to arrive adds them and rounds once -- the whole fp16 gradient is bit-reproducible.
+//              fp32 tables keep float LDS atomics (and float atomics for shared tiles).
 // Coarse dense levels first merge runs of consecutive samples that share a cell (wave64 segmented reduction), which
 // removes their same-row pile-ups before anything is written.
 // The level table lives on the device; its host copy (needed to size grids and buffers) is read back ONCE per
@@ -256,6 +257,8 @@ struct DirTable {
     uint32_t tile_base[kMaxLevels + 1];  // global tile index of each level's first tile
     uint32_t item_base[kMaxLevels + 1];  // first K4d work item of each level
     uint32_t slices[kMaxLevels];         // work items per tile of the level (each takes a range of chunks)
+    uint32_t split_base[kMaxLevels];     // levels with slices > 1: index of the level's first tile among the split tiles (ticket counters)
+    uint32_t part_base[kMaxLevels];      //                         index of the level's first partial tile in the partial-sum buffer
 };
 
 template <typename T, int D, bool BLC>
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     // caller handed over an uninitialised gradient table: the tiles of this level that several K4d work items will add into
     // (coarse levels only) start from zero -- this level's workgroups clear one slice of its rows each; sole-owner tiles are
     // written whole by K4d
-    if (zero_grid != nullptr && tab.slices[level] > 1) {
+    if (sizeof(T) == 4 && zero_grid != nullptr && tab.slices[level] > 1) {  // fp16: K4d's last work item of a shared tile writes all of it
         const uint32_t units = hashmap_size * 2, per = div_up(units, nchunks);  // elements (2 per row)
         T* base = zero_grid + (size_t)(uint32_t)tab.offsets[level] * 2;
         for (uint32_t i = chunk * per + threadIdx.x; i < min(units, (chunk + 1) * per); i += kBinSamples) base[i] = (T)0.0f;
@@ -408,7 +411,7 @@ __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
 }
 
 // which (tile, chunk range) a K4d workgroup owns
-struct SumItem { uint32_t level, t, slices, c_lo, c_hi, nrows; size_t dst_row; };
+struct SumItem { uint32_t level, t, slices, item, c_lo, c_hi, nrows; size_t dst_row; };
 __device__ __forceinline__ bool sum_item(const DirTable& tab, uint32_t L, uint32_t nchunks, uint32_t rows_per_tile, SumItem& it) {
     uint32_t level = 0;
     while (level + 1 < L && blockIdx.x >= tab.item_base[level + 1]) level++;
@@ -418,6 +421,7 @@ __device__ __forceinline__ bool sum_item(const DirTable& tab, uint32_t L, uint32
     const uint32_t local = blockIdx.x - tab.item_base[level];
     it.t = local / it.slices;
     const uint32_t item = local % it.slices, per = div_up(nchunks, it.slices);
+    it.item = item;
     it.c_lo = item * per;
     it.c_hi = min(nchunks, it.c_lo + per);
     const uint32_t rows_level = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]), row0 = it.t * rows_per_tile;
@@ -475,7 +479,7 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
 template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
-                                                                   const bool overwrite) {
+                                                                   const bool overwrite, unsigned long long* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SumItem it;
     if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it)) return;
@@ -516,7 +520,69 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
         }
     }
     __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+        // A tile shared by several work items (coarse levels): every item leaves its EXACT integer sums in the partial-sum buffer and
+        // combine_tiles_kernel adds them -- integer addition, any order, same result -- and rounds the tile to fp16 once.  No
+        // floating-point atomics on the table: the gradient is the correctly rounded sum, the same bits on every run.
+        if (it.slices > 1) {
+            constexpr size_t kTileElems = (size_t)rows_per_tile<T>() * 2;
+            const ulonglong2* acc = reinterpret_cast<const ulonglong2*>(smem);
+            ulonglong2* mine = reinterpret_cast<ulonglong2*>(partials + ((size_t)tab.part_base[it.level] + (size_t)it.t * it.slices + it.item) * kTileElems);
+            for (uint32_t i = threadIdx.x; i < it.nrows; i += kSumThreads) mine[i] = acc[i];
+            return;
+        }
+    }
     write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite);
+}
+
+// The tiles several K4d work items shared: one workgroup per (tile, 64 rows) adds the items' integer partial sums -- wave q takes the
+// items q, q + 4, ... (coalesced 1 KiB reads, several in flight), LDS joins the four -- and writes the rows, rounded to fp16 once
+// (or adds them to what the caller's buffer holds).
+constexpr uint32_t kCombineRows = kWave, kCombineWaves = 4, kCombineThreads = kCombineRows * kCombineWaves;
+__global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const unsigned long long* __restrict__ partials, const DirTable tab, uint32_t L,
+                                                                       half_t* __restrict__ grad_grid, const bool overwrite) {
+    __shared__ unsigned long long s_sum[kCombineWaves][kCombineRows][2];
+    constexpr uint32_t kRows = rows_per_tile<half_t>(), kSegs = kRows / kCombineRows;
+    const uint32_t split_tile = blockIdx.x / kSegs, seg = blockIdx.x % kSegs;
+    uint32_t level = 0;  // the split level this tile belongs to: split_base is non-decreasing and steps only at split levels
+    for (uint32_t l = 0; l < L; l++)
+        if (tab.slices[l] > 1 && tab.split_base[l] <= split_tile) level = l;
+    const uint32_t t = split_tile - tab.split_base[level], slices = tab.slices[level];
+    const uint32_t rows_level = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
+    const uint32_t lane = threadIdx.x % kCombineRows, q = threadIdx.x / kCombineRows;
+    const uint32_t local = seg * kCombineRows + lane, row = t * kRows + local;
+    if (t * kRows + seg * kCombineRows >= rows_level) return;  // whole segment past the level's last row
+    const ulonglong2* first = reinterpret_cast<const ulonglong2*>(partials + ((size_t)tab.part_base[level] + (size_t)t * slices) * kRows * 2);
+    unsigned long long s0 = 0, s1 = 0;
+    if (row < rows_level) {
+        uint32_t sl = q;
+        for (; sl + 3 * kCombineWaves < slices; sl += 4 * kCombineWaves) {  // four independent loads in flight
+            const ulonglong2 a = first[(size_t)sl * kRows + local], b = first[(size_t)(sl + kCombineWaves) * kRows + local];
+            const ulonglong2 c = first[(size_t)(sl + 2 * kCombineWaves) * kRows + local], d = first[(size_t)(sl + 3 * kCombineWaves) * kRows + local];
+            s0 += (a.x + b.x) + (c.x + d.x);
+            s1 += (a.y + b.y) + (c.y + d.y);
+        }
+        for (; sl < slices; sl += kCombineWaves) {
+            const ulonglong2 a = first[(size_t)sl * kRows + local];
+            s0 += a.x;
+            s1 += a.y;
+        }
+    }
+    s_sum[q][lane][0] = s0;
+    s_sum[q][lane][1] = s1;
+    __syncthreads();
+    if (q != 0 || row >= rows_level) return;
+#pragma unroll
+    for (uint32_t w = 1; w < kCombineWaves; w++) {
+        s0 += s_sum[w][lane][0];
+        s1 += s_sum[w][lane][1];
+    }
+    half2_t* dst = reinterpret_cast<half2_t*>(grad_grid) + (size_t)(uint32_t)tab.offsets[level];
+    if (overwrite) {
+        dst[row] = half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+    } else if ((s0 | s1) != 0) {
+        dst[row] = dst[row] + half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+    }
 }
 
 // ---- host: cached copy of the level table -----------------------------------------------------------------------------
@@ -565,7 +631,7 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     const uint32_t nchunks = div_up(B, kBinSamples);
     const uint32_t slice_records = knob(kKnobGridBwdSlice) >= 1024 ? (uint32_t)knob(kKnobGridBwdSlice) : kSliceRecords;
     DirTable dt{};
-    uint32_t tiles = 0, items = 0;
+    uint32_t tiles = 0, items = 0, split_tiles = 0, part_tiles = 0;
     for (uint32_t l = 0; l < L; l++) {
         dt.offsets[l] = off[l];
         dt.tile_base[l] = tiles;
@@ -578,15 +644,23 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         dt.slices[l] = sl;
         dt.item_base[l] = items;
         items += nt * sl;
+        dt.split_base[l] = split_tiles;
+        dt.part_base[l] = part_tiles;
+        if (sl > 1 && sizeof(T) == 2) {
+            split_tiles += nt;
+            part_tiles += nt * sl;
+        }
     }
     dt.offsets[L] = off[L];
     dt.tile_base[L] = tiles;
     dt.item_base[L] = items;
     const size_t dir_bytes = (sizeof(uint32_t) * (size_t)L * kMaxTilesPerLevel * nchunks + 255) / 256 * 256;
-    char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
+    const size_t part_bytes = (size_t)part_tiles * kTileBytes;  // exact integer partial sums of the tiles several work items share
+    char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + part_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
     if (!dbase) return NERFTEX_ERR_HIP;
     uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
-    Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes);
+    unsigned long long* partials = reinterpret_cast<unsigned long long*>(dbase + dir_bytes);
+    Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes + part_bytes);
     const bool merge = !knob(kKnobGridBwdNoMerge);
     const uint32_t probe = (uint32_t)knob(kKnobGridBwdProbe);
     {
@@ -602,9 +676,18 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         auto kernel = sum_tiles_dir_kernel<T>;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
         KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite);
+        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials);
     }
-    return check_launch("grid_encode_backward(sum)");
+    if ((rc = check_launch("grid_encode_backward(sum)")) != NERFTEX_OK) return rc;
+    if constexpr (sizeof(T) == 2) {
+        if (split_tiles) {
+            KernelTimer kt("combine_tiles_kernel", st, kTimeGrid);
+            hipLaunchKernelGGL(combine_tiles_kernel, dim3(split_tiles * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
+                               reinterpret_cast<half_t*>(grad_grid), overwrite);
+        }
+        return check_launch("grid_encode_backward(combine)");
+    }
+    return NERFTEX_OK;
 }
 
 template int grid_backward_binned<float, 2>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, bool, hipStream_t);

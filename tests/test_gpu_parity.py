@@ -209,6 +209,40 @@ def test_grid_backward_large_batch_fp16_is_tight_per_row(oracle, dev):
     assert (hits.max(axis=1) >= 8).sum() > 1000, "rows with many hits are covered"
 
 
+def test_grid_backward_large_batch_fp16_is_bit_reproducible(oracle, dev, knobs):
+    """The fp16 table gradient of the binned path is the correctly rounded EXACT sum of its (rounded) shares -- integer accumulation
+    inside a tile, integer combination of the tiles several work items share -- so it does not depend on the order anything ran in:
+    repeated launches give the same bits, in both accumulate and overwrite mode, also when coarse tiles are cut into many work items
+    (the reference's chain of fp16 atomics gives a different table every run)."""
+    from nerftex_hip import F16, LAYOUT_GRAD_OVERWRITE, check, lib, ptr, stream
+
+    s = _grid_setup(oracle, GRID_CASES[0], 60013, 51, np.float16)
+    rng = np.random.default_rng(52)
+    B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
+    g = (rng.standard_normal((B, L * C)) * 1e-2).astype(np.float16)
+    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    dummy = torch.zeros(1, dtype=torch.float16, device=dev)
+
+    def run(overwrite):
+        ge = torch.full((s["rows"], C), float("nan"), dtype=torch.float16, device=dev) if overwrite else torch.zeros(s["rows"], C, dtype=torch.float16, device=dev)
+        check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), B, D, C, L, s["S"], s["base"], 0, ptr(dummy), ptr(dummy),
+                                               s["gridtype"], int(s["align"]), F16, 1 | (LAYOUT_GRAD_OVERWRITE if overwrite else 0), stream()))
+        torch.cuda.synchronize()
+        return ge
+
+    for slice_records in (0, 4096, 1024):  # default, and coarse tiles cut into 8x / 32x more work items
+        knobs(grid_bwd_slice=slice_records)
+        runs = [run(False) for _ in range(4)] + [run(True) for _ in range(3)]
+        assert not torch.isnan(runs[-1]).any(), "overwrite mode writes every row"
+        for other in runs[1:]:
+            assert torch.equal(other, runs[0]), slice_records
+        if slice_records == 0:
+            base = runs[0]
+        else:  # how the tiles are cut does not matter either
+            assert torch.equal(runs[0], base), slice_records
+    assert float(base.float().abs().max()) > 0
+
+
 def test_grid_backward_run_merge_is_a_regrouping(oracle, dev, knobs):
     """Merging runs of consecutive samples that share a cell (before the records are emitted) only regroups the sum: with the
     merge switched off the fp16 table is the same up to the rounding of the individual shares, and identical on the fine hashed
