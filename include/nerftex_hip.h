@@ -419,6 +419,14 @@ int nerftex_render_tail_backward(const float* grad_loss, const float* scale, flo
                                  const float* target, float bg, uint32_t N, float* grad_image, float* grad_weights_sum,
                                  void* stream);
 
+/* nerftex_render_tail_backward followed by nerftex_composite_rays_train_backward as ONE launch: the wave that walks a ray backwards
+ * first forms its grad_image / grad_weights_sum from image_out, target and the loss gradient (never stored).  Same gradients, bit for
+ * bit.  (image_out: what nerftex_render_tail_forward wrote; weights_sum, image: what nerftex_composite_rays_train_forward wrote.) */
+int nerftex_composite_tail_backward(const float* grad_loss, const float* scale, float loss_mul, const float* image_out,
+                                    const float* target, float bg, const float* sigmas, const float* rgbs, const float* deltas,
+                                    const int32_t* rays, const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                    float* grad_sigmas, float* grad_rgbs, void* stream);
+
 /* One Adam step (main_nerf.py:128: betas (0.9, 0.99), eps 1e-15, no weight decay) of an fp32 master table from the
  * fp16 gradient the encoder backward produced, writing the fp16 copy the next forward reads: param, exp_avg,
  * exp_avg_sq [n] fp32 in place, grad_half [n] fp16 in, param_half [n] fp16 out.  step: device float, already

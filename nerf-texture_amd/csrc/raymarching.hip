@@ -366,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t* __restrict
 //   phase 3  one lane per ray follows the jumps through LDS and logs the members it lands on as samples.
 // Same floating-point expressions on the same values as the serial loop: the samples are bit-identical.
 constexpr uint32_t kMcRays = 32;      // rays per workgroup
+static_assert(kRayBlock % kMcRays == 0, "the expand pass adds whole count-pass totals per 64-ray block");
 constexpr uint32_t kMcSeg = 128;      // sequence members per segment (jump distances fit a byte)
 constexpr uint32_t kMcSub = 32;       // threads per ray in phases 2 and 4 (two waves per SIMD: the phases are latency-bound)
 constexpr uint32_t kMcThreads = kMcRays * kMcSub;
@@ -547,11 +548,12 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
     }
 
     if (owner) rays[3 * (size_t)n_own + 2] = (int)num;
-    // sample totals per 64-ray block (what the expand pass scans), integer atomics into the pre-zeroed ws[1..]
+    // sample totals per workgroup of kMcRays rays, plain stores (nothing to pre-zero): the expand pass adds kRayBlock / kMcRays of them per
+    // 64-ray block
     if (tid < kWave) {
         const uint32_t wsum = wave_sum(tid < kMcRays ? num : 0u);
         if (tid == 0) {
-            if (wsum) atomicAdd(&ws[1 + (blockIdx.x * kMcRays) / kRayBlock], wsum);
+            ws[1 + blockIdx.x] = wsum;
             if (blockIdx.x == 0) ws[0] = (uint32_t)counter[0];
         }
     }
@@ -672,13 +674,13 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
                                                            const float* __restrict__ nears, float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas, float* __restrict__ rays_ts, int* __restrict__ rays,
                                                            int* __restrict__ counter, const uint32_t* __restrict__ ws, uint32_t perturb,
-                                                           const float* __restrict__ tlog) {
+                                                           const float* __restrict__ tlog, uint32_t ws_per_block) {
     __shared__ uint32_t red[kExpandThreads / kWave];
     __shared__ uint32_t s_off[kRayBlock], s_cnt[kRayBlock];
     const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
     uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kExpandThreads) part += ws[1 + j];
+    for (uint32_t j = threadIdx.x; j < blockIdx.x * ws_per_block; j += kExpandThreads) part += ws[1 + j];  // totals of the rays in front of this block
     part = wave_sum(part);
     if (lane == 0) red[wid] = part;
     __syncthreads();
@@ -789,6 +791,16 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // running sums the backward needs from additive scans.  Same quantities, tree instead of serial summation order.
 constexpr uint32_t kCompBlock = 256;
 
+// The backward half of the render tail (harness level, trainstep.hip: nerf/renderer.py:417-425 + the MSE of nerf/utils.py:602-640)
+// riding on the compositing backward: the wave about to walk a ray backwards first forms the gradient of the mean squared error with
+// respect to its raw image and opacity sum -- the expressions of render_tail_backward_kernel; grad_image / grad_weights_sum are never
+// stored.  (The forward pair was tried as one kernel too: the loss reduction puts two dependent device-scope atomics at the end of each
+// of 2048 four-ray blocks -- 20 us against 10 + 8 for the two launches -- and was dropped.)
+struct TailBackward {
+    const float *grad_loss, *scale, *image_out, *target;
+    float bg, loss_mul;
+};
+
 __global__ __launch_bounds__(kCompBlock) void composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                                         const float* __restrict__ deltas, const int* __restrict__ rays,
                                                                         uint32_t M, uint32_t N, float* __restrict__ weights_sum,
@@ -838,21 +850,35 @@ __global__ __launch_bounds__(kCompBlock) void composite_train_fwd_kernel(const f
     }
 }
 
+template <bool TAIL>
 __global__ __launch_bounds__(kCompBlock) void composite_train_bwd_kernel(const float* __restrict__ grad_weights_sum,
                                                                         const float* __restrict__ grad_image,
                                                                         const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                                         const float* __restrict__ deltas, const int* __restrict__ rays,
                                                                         const float* __restrict__ weights_sum, const float* __restrict__ image,
                                                                         uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
-                                                                        float* __restrict__ grad_rgbs) {
+                                                                        float* __restrict__ grad_rgbs, const TailBackward tail) {
     const uint32_t n = blockIdx.x * (kCompBlock / kWave) + threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
                    num_steps = (uint32_t)rays[3 * (size_t)n + 2];
     if (num_steps == 0 || offset + num_steps >= M) return;
-    const float gws = grad_weights_sum[index];
-    const float gi0 = grad_image[3 * (size_t)index], gi1 = grad_image[3 * (size_t)index + 1], gi2 = grad_image[3 * (size_t)index + 2];
+    float gws, gi0, gi1, gi2;
+    if constexpr (TAIL) {
+        // grad_image = (2 / 3N) (image_out - target) g,  grad_ws = -(sum_c grad_image) bg   (render_tail_backward_kernel)
+        const float gl = (tail.scale ? *tail.grad_loss * *tail.scale : *tail.grad_loss) * tail.loss_mul;
+        const float norm = (float)(2.0 / (double)((size_t)N * 3));
+        gi0 = norm * (tail.image_out[(size_t)index * 3] - tail.target[(size_t)index * 3]) * gl;
+        gi1 = norm * (tail.image_out[(size_t)index * 3 + 1] - tail.target[(size_t)index * 3 + 1]) * gl;
+        gi2 = norm * (tail.image_out[(size_t)index * 3 + 2] - tail.target[(size_t)index * 3 + 2]) * gl;
+        float sum = 0.0f;
+        sum += gi0; sum += gi1; sum += gi2;
+        gws = -(sum * tail.bg);
+    } else {
+        gws = grad_weights_sum[index];
+        gi0 = grad_image[3 * (size_t)index]; gi1 = grad_image[3 * (size_t)index + 1]; gi2 = grad_image[3 * (size_t)index + 2];
+    }
     const float r_final = image[3 * (size_t)index], g_final = image[3 * (size_t)index + 1], b_final = image[3 * (size_t)index + 2];
     const float ws_final = weights_sum[index];
     float T_carry = 1.0f, r_c = 0, g_c = 0, b_c = 0, ws_c = 0;
@@ -1037,8 +1063,9 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
         return NERFTEX_ERR_INVALID;
     }
     const uint32_t nblocks = div_up(N, kRayBlock);
-    // scratch: [0] base, [1..nblocks] workgroup totals, then (optionally) the per-ray log of accepted t's [N, max_steps]
-    const size_t head = (sizeof(uint32_t) * (1 + (size_t)nblocks) + 255) / 256 * 256;
+    // scratch: [0] base, [1..] workgroup totals of the count pass (per 64 or per kMcRays rays), then (optionally) the per-ray log of
+    // accepted t's [N, max_steps]
+    const size_t head = (sizeof(uint32_t) * (1 + (size_t)div_up(N, kMcRays)) + 255) / 256 * 256;
     const size_t log_bytes = sizeof(float) * (size_t)N * max_steps;
     const long force = knob(kKnobMarch);  // 1 replay | 2 log: A/B switch for profiling
     const bool use_log = force ? force == 2 : (log_bytes <= ((size_t)1 << 30));
@@ -1047,12 +1074,8 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     uint32_t* ws = reinterpret_cast<uint32_t*>(base);
     float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
     hipStream_t st = as_stream(stream);
-    if (use_log && H <= 256 && !knob(kKnobMarchSerial)) {  // march_serial = 1: the one-ray-per-lane DDA (A/B switch)  // (the packed voxel of the parallel pass holds 8-bit coordinates)
-        {   // a kernel, not hipMemsetAsync: the memset node did not re-zero the buffer when the launch sequence is replayed from a
-            // captured HIP graph (ROCm 7.2; the block sums then accumulate garbage on the second replay)
-            KernelTimer kt("zero_words_kernel", st);
-            hipLaunchKernelGGL(zero_words_kernel, grid_for(1 + nblocks), dim3(kBlock), 0, st, ws, 1 + nblocks);
-        }
+    const bool parallel_count = use_log && H <= 256 && !knob(kKnobMarchSerial);  // march_serial = 1: the one-ray-per-lane DDA (A/B switch); the packed voxel of the parallel pass holds 8-bit coordinates
+    if (parallel_count) {
         KernelTimer kt("march_count_parallel_kernel", st);
         hipLaunchKernelGGL(march_count_parallel_kernel, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
                            max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog);
@@ -1067,7 +1090,7 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
         {
             KernelTimer kt("march_expand_kernel", st);
             hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(kExpandThreads), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
-                               nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog);
+                               nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog, parallel_count ? kRayBlock / kMcRays : 1u);
         }
         return check_launch("march_rays_train(expand)");
     }
@@ -1173,10 +1196,26 @@ extern "C" int nerftex_composite_rays_train_backward(const float* grad_weights_s
     if (N == 0) return NERFTEX_OK;
     {
         KernelTimer kt("composite_train_bwd_kernel", as_stream(stream));
-        hipLaunchKernelGGL(composite_train_bwd_kernel, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
-                           sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+        hipLaunchKernelGGL(composite_train_bwd_kernel<false>, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), grad_weights_sum, grad_image,
+                           sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, TailBackward{});
     }
     return check_launch("composite_rays_train_backward");
+}
+
+// Extension (harness level): nerftex_render_tail_backward + nerftex_composite_rays_train_backward as one launch (TailBackward above).
+extern "C" int nerftex_composite_tail_backward(const float* grad_loss, const float* scale, float loss_mul, const float* image_out, const float* target,
+                                               float bg, const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                               const float* weights_sum, const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
+                                               float* grad_rgbs, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    const TailBackward tail{grad_loss, scale, image_out, target, bg, loss_mul};
+    {
+        KernelTimer kt("composite_tail_bwd_kernel", as_stream(stream));
+        hipLaunchKernelGGL(composite_train_bwd_kernel<true>, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), nullptr, nullptr,
+                           sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, tail);
+    }
+    return check_launch("composite_tail_backward");
 }
 
 static int march_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,

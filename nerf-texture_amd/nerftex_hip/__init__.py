@@ -34,6 +34,7 @@ _SIGNATURES = {
     "nerftex_field_out_backward": [_vp, _vp, _u32, _vp, _vp],
     "nerftex_render_tail_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_render_tail_backward": [_vp, _vp, _f32, _vp, _vp, _f32, _u32, _vp, _vp, _vp],
+    "nerftex_composite_tail_backward": [_vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "nerftex_adam_half_step": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "nerftex_amp_check_half": [_i, _vp, _vp, _vp, _vp],
     "nerftex_adam_half_step_amp": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],

@@ -233,6 +233,56 @@ class _render_tail(Function):
         return grad_ws, None, grad_image, None, None, None, None, None, None
 
 
+class _composite_tail(Function):
+    """raymarching.composite_rays_train + render_tail as ONE autograd node: two launches forward (the two kernels as they are), one
+    launch backward (nerftex_composite_tail_backward: the render tail's backward rides on the compositing backward).
+    -> (image_out, depth_out, loss * loss_mul, that times `scale`); backward through the last one reaches sigmas and rgbs."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale):
+        sigmas, rgbs, deltas = sigmas.contiguous().float(), rgbs.contiguous().float(), deltas.contiguous().float()
+        nears, fars, target = nears.contiguous().float(), fars.contiguous().float(), target.contiguous().float()
+        rays = rays.contiguous()
+        M, N, dev = sigmas.shape[0], rays.shape[0], sigmas.device
+        assert target.shape == (N, 3) and rays.dtype == torch.int32
+        assert scale is None or (scale.dtype == torch.float32 and scale.numel() == 1 and scale.device == dev)
+        per_ray = torch.empty(9, N, dtype=torch.float32, device=dev)  # weights_sum, depth, depth_out | image [N,3] | image_out [N,3]
+        weights_sum, depth, depth_out = per_ray[0], per_ray[1], per_ray[2]
+        image, image_out = per_ray[3:6].view(N, 3), per_ray[6:9].view(N, 3)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        scratch = _tail_scratch(dev, (N + 255) // 256)
+        check(lib.nerftex_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(weights_sum), ptr(depth), ptr(image), stream()))
+        check(lib.nerftex_render_tail_forward(ptr(weights_sum), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(target), float(bg), float(loss_mul), N,
+                                              ptr(image_out), ptr(depth_out), ptr(scratch[1]), ptr(scratch[0]), ptr(losses), ptr(scale),
+                                              losses.data_ptr() + 4, stream()))
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, image_out, target, scale)
+        ctx.consts = (float(bg), float(loss_mul))
+        loss, scaled = losses[0], losses[1]
+        ctx.mark_non_differentiable(image_out, depth_out, loss)
+        ctx.set_materialize_grads(False)
+        return image_out, depth_out, loss, scaled
+
+    @staticmethod
+    def backward(ctx, _gi, _gd, _gl, grad_scaled):
+        sigmas, rgbs, deltas, rays, weights_sum, image, image_out, target, scale = ctx.saved_tensors
+        if grad_scaled is None:
+            return (None,) * 10
+        bg, loss_mul = ctx.consts
+        M, N = sigmas.shape[0], rays.shape[0]
+        grad_scaled = grad_scaled.contiguous().float()
+        # rows the rays do not cover (the tail of a buffer sized by the mean count) get no gradient: zeros, like the reference's buffers
+        grads = torch.zeros(4 * M, dtype=torch.float32, device=sigmas.device)
+        grad_sigmas, grad_rgbs = grads[:M], grads[M:].view(M, 3)
+        check(lib.nerftex_composite_tail_backward(ptr(grad_scaled), ptr(scale), loss_mul, ptr(image_out), ptr(target), bg, ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                                  ptr(rays), ptr(weights_sum), ptr(image), M, N, ptr(grad_sigmas), ptr(grad_rgbs), stream()))
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None
+
+
+def composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, bg=1.0, loss_mul=1.0, scale=None):
+    """-> (image_out, depth_out, loss, scaled_loss): compositing, background blend, depth normalisation and MSE; one backward launch."""
+    return _composite_tail.apply(sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale)
+
+
 _SCRATCH = {}
 
 

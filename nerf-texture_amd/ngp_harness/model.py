@@ -328,11 +328,14 @@ class Renderer(nn.Module):
         sigmas, rgbs, _ = self.field(xyzs, dirs)
         if self.density_scale != 1:  # x * 1.0 is x: not launched
             sigmas = self.density_scale * sigmas
-        weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
         if target is not None:
             from . import fused
 
+            if getattr(self, "fused_composite_tail", True):  # compositing + blend + depth + MSE: one launch per direction
+                return fused.composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, float(bg_color), loss_mul, scale)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
             return fused.render_tail(weights_sum, depth, image, nears, fars, target, float(bg_color), loss_mul, scale)
+        weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth

@@ -113,6 +113,46 @@ def test_render_tail_matches_framework_ops(dev, N):
     assert torch.equal(im3.grad, im2.grad) and torch.equal(ws3.grad, ws2.grad)
 
 
+@pytest.mark.parametrize("N", [3, 1000, 8192])
+def test_composite_tail_equals_compositing_then_render_tail(dev, N):
+    """fused.composite_tail (compositing + background blend + depth normalisation + MSE as one autograd node whose backward is ONE
+    launch, nerftex_composite_tail_backward) against raymarching.composite_rays_train followed by fused.render_tail: images, depths,
+    loss and BOTH gradients identical, bit for bit.  Ragged rays, an empty ray, a ray past the buffer's end."""
+    import raymarching
+    from ngp_harness import fused
+
+    g = torch.Generator(device="cpu").manual_seed(N)
+    counts = torch.randint(0, 150, (N,), generator=g)
+    counts[0] = 0
+    offsets = torch.cumsum(counts, 0) - counts
+    M = int(counts.sum()) + 8
+    if N > 2:
+        counts[-1] = counts[-1] + 9  # runs past the end of the buffers: dropped (raymarching.cu:727-733)
+    rays = torch.stack([torch.arange(N), offsets, counts], dim=1).to(torch.int32).to(dev)
+    sigmas = (torch.rand(M, generator=g) * 30).to(dev)
+    rgbs = torch.rand(M, 3, generator=g).to(dev)
+    deltas = torch.stack([torch.rand(M, generator=g) * 0.02 + 0.003, torch.rand(M, generator=g) * 0.03 + 0.003], dim=1).to(dev)
+    nears = (torch.rand(N, generator=g) + 0.2).to(dev)
+    fars = nears + (torch.rand(N, generator=g) * 3 + 0.1).to(dev)
+    target = torch.rand(N, 3, generator=g).to(dev)
+    scale = torch.full((), 1024.0, device=dev)
+    bg, mul = 1.0, 0.5
+
+    s1, c1 = sigmas.clone().requires_grad_(True), rgbs.clone().requires_grad_(True)
+    ws, depth, image = raymarching.composite_rays_train(s1, c1, deltas, rays)
+    img1, dep1, loss1, scaled1 = fused.render_tail(ws, depth, image, nears, fars, target, bg, mul, scale)
+    scaled1.backward()
+    s2, c2 = sigmas.clone().requires_grad_(True), rgbs.clone().requires_grad_(True)
+    img2, dep2, loss2, scaled2 = fused.composite_tail(s2, c2, deltas, rays, nears, fars, target, bg, mul, scale)
+    scaled2.backward()
+    assert torch.equal(img2, img1) and torch.equal(dep2, dep1)
+    assert loss2.item() == loss1.item() and scaled2.item() == loss2.item() * 1024.0
+    assert torch.equal(s2.grad, s1.grad) and torch.equal(c2.grad, c1.grad)
+    assert float(s1.grad.abs().max()) > 0
+    _, _, loss3, _ = fused.composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, bg, mul, scale)  # the ticket is back at zero
+    assert loss3.item() == loss2.item()
+
+
 @pytest.mark.parametrize("amp", ["gradscaler", "fused"])
 def test_half_leaf_adam_trains_like_torch_adam(dev, knobs, amp):
     """A small hash grid + FFMLP trained for a few steps under autocast with loss scaling: HalfLeafAdam (fp16 leaves, fp16 gradients
