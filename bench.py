@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 # passes (FETCH_SIZE, WRITE_SIZE; profiles/r02_pmc_grid.txt).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
 # MI355X_MICROARCH.md for wide coalesced streams: here the 8-B record stream) + WRITE_SIZE.  Forward: FETCH_SIZE as reported
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
-TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 550.0e6}
+TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 578.0e6}
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),

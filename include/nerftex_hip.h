@@ -216,8 +216,9 @@ int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* r
  *   nerftex_grid_encode_forward: what the XCD-pinned gather kernel writes; no transpose);
  *   dirs [B, 3] fp32; sigma_weights / color_weights: the two FFMLP weight vectors (half);
  *   sigma [B] fp32, rgbs [B, 3] fp32 (half-valued, as the unfused sequence gives them).
- * Training additionally gets what the backward entry points read (all four or none):
- *   x_rows [B, 32] (the features as rows), h [B, 16], cin [B, 32], hc [B, 16], half.
+ * Training additionally gets what the backward entry points read (all three or none; hc, the colour net's raw outputs, is
+ * optional on top -- nothing downstream needs it):
+ *   x_rows [B, 32] (the features as rows), h [B, 16], cin [B, 32], hc [B, 16] or NULL, half.
  * B % 128 == 0.  Same values, bit for bit, as grid rows -> nerftex_ffmlp_forward ->
  * nerftex_field_mid_forward -> nerftex_ffmlp_forward -> nerftex_field_out_forward.
  * ------------------------------------------------------------------------- */

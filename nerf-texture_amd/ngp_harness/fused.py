@@ -106,8 +106,7 @@ class _ngp_field(Function):
             x_rows = torch.empty(B, 32, dtype=torch.float16, device=dev)
             h = torch.empty(B, 16, dtype=torch.float16, device=dev)
             cin = torch.empty(B, 32, dtype=torch.float16, device=dev)
-            hc = torch.empty(B, 16, dtype=torch.float16, device=dev)
-            check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), ptr(hc),
+            check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), None,
                                             stream()))
             ctx.save_for_backward(x, table_h, offsets, ws_h, wc_h, x_rows, h, cin, rgbs)
             ctx.meta = (S, H, gridtype, align, affine, table.dtype, ws.dtype, wc.dtype)

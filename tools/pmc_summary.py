@@ -8,7 +8,7 @@ import glob
 import re
 import sys
 
-KERNELS = ("bin_fill_dir_kernel", "sum_tiles_dir_kernel", "grid_forward_level_kernel", "level_major_to_rows_kernel", "bin_fill_kernel",
+KERNELS = ("bin_fill_dir_kernel", "sum_tiles_dir_kernel", "combine_tiles_kernel", "grid_forward_level_kernel", "level_major_to_rows_kernel", "bin_fill_kernel",
            "sum_tiles_kernel", "bin_count_kernel", "grid_forward_kernel", "grid_backward_kernel")
 rows = collections.defaultdict(list)
 for d in sys.argv[1:]:
