@@ -12,7 +12,7 @@ import math
 import torch
 import torch.nn as nn
 from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
+from nerftex_hip.amp import custom_bwd, custom_fwd  # torch.amp's pair, leaner on the host
 
 import os
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
+from nerftex_hip.amp import custom_bwd, custom_fwd  # torch.amp's pair, leaner on the host
 
 from nerftex_hip import F16, F32, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, check, lib, ptr, stream, timer
 

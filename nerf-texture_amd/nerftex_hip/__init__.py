@@ -137,10 +137,11 @@ def ptr(t):
 
 
 def stream():
-    """torch's current HIP stream as the void* the C ABI expects."""
+    """torch's current HIP stream as the void* the C ABI expects (the raw handle: `torch.cuda.current_stream()` builds a Stream object,
+    ~11 us a call, seven calls per eager training step)."""
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_cuda(t, name):

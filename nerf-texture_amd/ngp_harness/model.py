@@ -13,7 +13,7 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.amp import custom_bwd, custom_fwd
+from nerftex_hip.amp import custom_bwd, custom_fwd  # torch.amp's pair, leaner on the host
 
 import raymarching
 from ffmlp import FFMLP

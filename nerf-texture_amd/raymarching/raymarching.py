@@ -10,7 +10,7 @@ epochs (:218-226).  The kernels run on torch's CURRENT stream (the reference use
 """
 import torch
 from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
+from nerftex_hip.amp import custom_bwd, custom_fwd  # torch.amp's pair, leaner on the host
 
 from nerftex_hip import check, lib, ptr, stream, timer
 
