@@ -72,6 +72,7 @@ def parse():
                     "a sharded run and a single-rank run of the same global batch only see the same samples without it)")
     ap.add_argument("--bound", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-march-ahead", action="store_true", help="1 GPU: march inside the step's one graph instead of one step ahead on a second stream")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
     ap.add_argument("--infer-parts", type=int, default=3, help="ray ranges of the rendered frame, each on its own stream")
@@ -198,6 +199,9 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # is two graphs (forward + backward | optimizer) with the gradient all-reduce launched eagerly between them.
     use_graph = graph
     split_graph = use_graph and (world > 1 or args.graph_split)
+    # 1 GPU: the march of step k+1 needs nothing from step k (rays and the occupancy grid, not the weights): it is its own graph, replayed
+    # on a second stream while step k shades, goes backward and updates -- latency-bound work on otherwise idle issue slots
+    march_ahead = use_graph and not split_graph and not args.no_march_ahead
     use_amp = dtype in ("fp16", "bf16")
     amp_dtype = torch.bfloat16 if dtype == "bf16" else torch.float16
     fused_opt = dtype == "fp16" and mlp == "ffmlp" and not (args.no_fused_opt or no_ext)
@@ -275,6 +279,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # ring's mean rounded up to 4096 + 4096); all graphs share one memory pool (they never run concurrently).
     RING = 16  # = the renderer's step-counter ring: graph g is step g of a 16-step cycle
     gstate = {"graphs": None, "M": 0, "marched": -1}
+    side_stream = torch.cuda.Stream(device=dev, priority=-1) if march_ahead else None  # high priority: its few, fat workgroups go first when slots free up
 
     def body_march(g):
         renderer.local_step = g  # the step's counter is ring slot g, exactly as in the eager loop
@@ -301,21 +306,27 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         torch.cuda.current_stream().wait_stream(side)
         graphs, mem, marches = [], None, [None] * RING
         # thread_local: only this thread's calls can invalidate a capture (an RCCL watchdog thread may query events meanwhile)
-        if split_graph:  # N > 1: the march of a step is its own graph, replayed while the PREVIOUS step's gradients are on the wire
+        if split_graph or march_ahead:  # the march of a step is its own graph: replayed while the PREVIOUS step's gradients are on the wire
+            mem_m = None                # (N > 1) or while the previous step runs (1 GPU: own memory pool, the two graphs run concurrently)
             for g in range(RING):
                 gm = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gm, pool=mem, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gm, pool=mem_m if march_ahead else mem, capture_error_mode="thread_local"):
                     out = body_march(g)
-                mem = gm.pool()
+                if march_ahead:
+                    mem_m = gm.pool()
+                else:
+                    mem = gm.pool()
                 marches[g] = (gm, out)  # the sample tensors stay alive: graph A of the slot reads them
         for g in range(RING):  # one graph per ring slot: static ray batch, static counter slot -> nothing to select or copy per step
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
-                body_fb(g, marches[g][1] if split_graph else None)
+                body_fb(g, marches[g][1] if (split_graph or march_ahead) else None)
                 if not split_graph:
                     body_opt()
             mem = ga.pool()
             gm, gb, grads = None, None, None
+            if march_ahead:
+                gm = marches[g][0]
             if split_graph:
                 gm = marches[g][0]
                 grads = reducer.big_grads()  # this graph's gradient tensors: A writes them, the all-reduce and B read them -- kept alive
@@ -332,7 +343,19 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     def graph_step(k):
         g = renderer.local_step
         gm, ga, gb, grads = gstate["graphs"][g]
-        if gb is None:
+        if march_ahead:  # march(g + 1) on the side stream under shade + backward + optimizer(g) on this one
+            main = torch.cuda.current_stream()
+            if gstate["marched"] != g:  # first step of a ring: nothing marched ahead
+                gm.replay()
+                side_stream.wait_stream(main)  # the marches share scratch: in order
+            else:
+                main.wait_stream(side_stream)
+            if g + 1 < RING:  # not across the ring's end: the mean_count read-back (and a possible re-capture) comes first there
+                with torch.cuda.stream(side_stream):
+                    gstate["graphs"][g + 1][0].replay()
+                gstate["marched"] = g + 1
+            ga.replay()
+        elif gb is None:
             ga.replay()
         else:  # march(g) | shade + backward(g) | all-reduce(g) overlapped with march(g + 1) | optimizer(g)
             if gstate["marched"] != g:
@@ -365,7 +388,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 graph_step(k)
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            use_graph = split_graph = False
+            use_graph = split_graph = march_ahead = False
     total_samples.zero_()
 
     if time_grid_kernels and not use_graph:
@@ -434,6 +457,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     res = dict(replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
+                      "two replayed HIP graphs per step: shade + backward + optimizer of step k, and on a second stream the march of step k + 1 (it needs the rays and the occupancy grid, not the weights)" if march_ahead else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
 

@@ -62,3 +62,22 @@ def test_two_ranks_train_like_one_rank_on_the_global_batch(wire):
     a, b = two["config"]["param_l1_after_run"], one["config"]["param_l1_after_run"]
     assert abs(a - b) <= 1.5e-2 * abs(b), (a, b)
     assert abs(two["config"]["samples_per_step_per_gpu"] * 2 - one["config"]["samples_per_step_per_gpu"]) <= 0.02 * one["config"]["samples_per_step_per_gpu"]
+
+
+def test_march_one_step_ahead_trains_bit_identically():
+    """bench.py's default single-GPU step (march of step k + 1 replayed on a second, high-priority stream under shade + backward +
+    optimizer of step k) against the one-graph step (`--no-march-ahead`): the march needs the rays and the occupancy grid, not the
+    weights, so the parameters after the run are the same bits."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = []
+    for extra in ([], ["--no-march-ahead"]):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "4", "--rays", "2048", "--no-cpu-baseline", "--no-other",
+               "--no-infer", "--no-kernel-timing"] + extra
+        run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        out.append(json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1]))
+    ahead, single = out
+    assert "second stream" in ahead["config"]["launch"] and "one replayed HIP graph" in single["config"]["launch"]
+    assert ahead["config"]["param_l1_after_run"] == single["config"]["param_l1_after_run"]
+    assert ahead["config"]["samples_per_step_per_gpu"] == single["config"]["samples_per_step_per_gpu"]
