@@ -61,6 +61,12 @@ sigma_geo_dir = _sigma_geo_dir.apply
 color_out = _color_out.apply
 
 
+import os
+
+# False (NERFTEX_FIELD_BACKWARD=split): the four launches (glue, MLP, glue, MLP) the two fused ones replace -- same gradients, for A/B
+FIELD_BACKWARD_FUSED = os.environ.get("NERFTEX_FIELD_BACKWARD", "fused") != "split"
+
+
 class _ngp_field(Function):
     """The whole --ff field (nerf/network_ff.py:85-101) as two launches forward: the hash-grid gather writing level-major features and
     nerftex_field_forward (both MLPs, trunc_exp, SH, concat, sigmoid in one kernel; no transpose, no intermediate read-backs).  The
@@ -125,14 +131,18 @@ class _ngp_field(Function):
         half = dict(dtype=torch.float16, device=dev)
         grad_sigma = torch.zeros(B, dtype=torch.float32, device=dev) if grad_sigma is None else grad_sigma.contiguous().float()
         grad_rgbs = torch.zeros(B, 3, dtype=torch.float32, device=dev) if grad_rgbs is None else grad_rgbs.contiguous().float()
-        grad_hc = torch.empty(B, 16, **half)
-        check(lib.nerftex_field_out_backward(ptr(grad_rgbs), ptr(rgbs), B, ptr(grad_hc), stream()))
         grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc_h)
-        check(lib.nerftex_ffmlp_backward(ptr(grad_hc), ptr(cin), ptr(wc_h), None, B, 32, 16, 64, 3, 0, 6, 1, None, ptr(grad_cin), ptr(grad_wc), stream()))
-        grad_h = torch.empty(B, 16, **half)
-        check(lib.nerftex_field_mid_backward(ptr(grad_sigma), ptr(grad_cin), ptr(h), B, ptr(grad_h), stream()))
         grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)
-        check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws_h), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
+        if FIELD_BACKWARD_FUSED:  # the two glue kernels ride on the MLP backward kernels' load stage
+            check(lib.nerftex_field_backward_color(ptr(grad_rgbs), ptr(rgbs), ptr(cin), ptr(wc_h), B, ptr(grad_cin), ptr(grad_wc), stream()))
+            check(lib.nerftex_field_backward_sigma(ptr(grad_sigma), ptr(h), ptr(grad_cin), ptr(x_rows), ptr(ws_h), B, ptr(grad_x), ptr(grad_ws), stream()))
+        else:
+            grad_hc = torch.empty(B, 16, **half)
+            check(lib.nerftex_field_out_backward(ptr(grad_rgbs), ptr(rgbs), B, ptr(grad_hc), stream()))
+            check(lib.nerftex_ffmlp_backward(ptr(grad_hc), ptr(cin), ptr(wc_h), None, B, 32, 16, 64, 3, 0, 6, 1, None, ptr(grad_cin), ptr(grad_wc), stream()))
+            grad_h = torch.empty(B, 16, **half)
+            check(lib.nerftex_field_mid_backward(ptr(grad_sigma), ptr(grad_cin), ptr(h), B, ptr(grad_h), stream()))
+            check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws_h), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
         grad_table = torch.empty_like(table_h)
         dummy = torch.empty(1, **half)
         check(lib.nerftex_grid_encode_backward_affine(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, 0,

@@ -140,3 +140,50 @@ def test_one_kernel_field_equals_the_glue_kernel_sequence_bit_for_bit(dev, B):
         s2, c2, _ = f2(x, d)
     assert torch.equal(s1, s2.float()) and torch.equal(c1, c2.float())
     assert torch.equal(s1, f1.out[0]) and torch.equal(c1, f1.out[1]), "inference variant == training variant"
+
+
+def test_field_backward_entries_equal_glue_plus_mlp_backward(dev):
+    """nerftex_field_backward_color / _sigma (the glue kernels folded into the load stage of the recomputing MLP backward) against
+    nerftex_field_out_backward + nerftex_ffmlp_backward and nerftex_field_mid_backward + nerftex_ffmlp_backward: every output half
+    identical -- including logits outside the trunc_exp clamp, zero / huge / non-finite incoming gradients and colours at 0 and 1."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    torch.manual_seed(11)
+    B = 4096
+    half = dict(dtype=torch.float16, device=dev)
+    wc = ((torch.rand(64 * (32 + 128 + 16), device=dev) * 2 - 1) * 0.2).half()
+    ws = ((torch.rand(64 * (32 + 64 + 16), device=dev) * 2 - 1) * 0.2).half()
+    cin = torch.randn(B, 32, device=dev).half()
+    x_rows = torch.randn(B, 32, device=dev).half()
+    rgbs = torch.sigmoid(torch.randn(B, 3, device=dev) * 3).half().float()
+    rgbs[:16] = 0.0
+    rgbs[16:32] = 1.0
+    grad_rgbs = torch.randn(B, 3, device=dev) * 10
+    grad_rgbs[32:48] = 0.0
+    grad_rgbs[48:56] = 1e6      # overflows half: inf, as the glue kernel gives it
+    grad_rgbs[56:60] = float("nan")
+    h = (torch.randn(B, 16, device=dev) * 6).half()
+    h[:8, 0] = 30.0             # beyond the clamp of trunc_exp's backward
+    h[8:16, 0] = -30.0
+    grad_sigma = torch.randn(B, device=dev) * 1e-2
+    grad_sigma[64:72] = 0.0
+    grad_sigma[72:76] = 1e30
+
+    def run(fused):
+        grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc)
+        grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws)
+        if fused:
+            check(lib.nerftex_field_backward_color(ptr(grad_rgbs), ptr(rgbs), ptr(cin), ptr(wc), B, ptr(grad_cin), ptr(grad_wc), stream()))
+            check(lib.nerftex_field_backward_sigma(ptr(grad_sigma), ptr(h), ptr(grad_cin), ptr(x_rows), ptr(ws), B, ptr(grad_x), ptr(grad_ws), stream()))
+        else:
+            grad_hc, grad_h = torch.empty(B, 16, **half), torch.empty(B, 16, **half)
+            check(lib.nerftex_field_out_backward(ptr(grad_rgbs), ptr(rgbs), B, ptr(grad_hc), stream()))
+            check(lib.nerftex_ffmlp_backward(ptr(grad_hc), ptr(cin), ptr(wc), None, B, 32, 16, 64, 3, 0, 6, 1, None, ptr(grad_cin), ptr(grad_wc), stream()))
+            check(lib.nerftex_field_mid_backward(ptr(grad_sigma), ptr(grad_cin), ptr(h), B, ptr(grad_h), stream()))
+            check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
+        torch.cuda.synchronize()
+        return grad_cin, grad_wc, grad_x, grad_ws
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert lib.nerftex_field_backward_color(ptr(grad_rgbs), ptr(rgbs), ptr(cin), ptr(wc), 100, ptr(cin), ptr(wc), stream()) != 0  # B % 128
