@@ -60,6 +60,12 @@ const char* nerftex_version(void);
 int nerftex_tune_set(const char* name, long value);
 long nerftex_tune_get(const char* name);
 
+/* The library's scratch (INTEGRATION.md "Scratch memory and streams": one grow-only buffer per device, stream and purpose -- the march's
+ * accepted-t log alone is N * max_steps floats, capped at 1 GiB) is kept for the life of the process.  After a one-off oversized call
+ * (a force_all_rays march of a whole image, say) this frees all of it, on every device; the next calls allocate again at their own size.
+ * Synchronises the devices first.  NOT while a captured graph that uses the library may still be replayed: its kernels hold the addresses. */
+int nerftex_release_workspaces(void);
+
 /* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every kernel the
  * library launches).  on = 0 off (default), 1 every kernel, 2 hash-grid kernels only; bench.py uses 2 over its timed
  * region to report the roofline kernel's average launch duration.  report() synchronises the device and writes a JSON object

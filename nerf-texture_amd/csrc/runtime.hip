@@ -193,6 +193,18 @@ int nerftex_tune_set(const char* name, long value) {
     return NERFTEX_OK;
 }
 
+int nerftex_release_workspaces(void) {
+    nerftex::clear_error();
+    int n = 0, cur = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return NERFTEX_OK;  // no device: nothing was allocated
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < n; d++)
+        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+    nerftex::release_workspaces();
+    return NERFTEX_OK;
+}
+
 long nerftex_tune_get(const char* name) {
     const int k = name ? nerftex::knob_index(name, strlen(name)) : -1;
     return k < 0 ? -1 : nerftex::g_knobs[k];

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "nerftex_field_forward": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_field_backward_color": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
     "nerftex_field_backward_sigma": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
+    "nerftex_release_workspaces": [],
     "nerftex_field_forward_rows": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "nerftex_grid_encode_forward_rows": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _u32, _vp],
     "nerftex_field_mid_forward": [_vp, _vp, _u32, _vp, _vp, _vp],

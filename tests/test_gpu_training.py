@@ -179,3 +179,30 @@ def test_field_kernels_skip_rows_past_the_device_count(dev):
     torch.cuda.synchronize()
     assert torch.equal(flat[:live], s_full[:live])
     assert float((flat[live + 128:B] + 7.0).abs().max()) == 0.0
+
+
+def test_release_workspaces_then_keep_working(dev):
+    """nerftex_release_workspaces frees the library's scratch (march log, binning records, ...); the next calls allocate again and give
+    the same results."""
+    import raymarching
+    from nerftex_hip import check, lib
+    from ngp_harness import scene
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    _, _, bits = sc.bitfield()
+    o, d = scene.train_batch(2048, seed=5, n_views=2)
+    ro, rd, bt = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.from_numpy(bits).to(dev)
+    aabb = torch.tensor([-2, -2, -2, 2, 2, 2.0], device=dev)
+
+    def march():
+        nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        return raymarching.march_rays_train(ro, rd, 2.0, bt, sc.cascade, 128, nears, fars, counter, -1, False, 128, False, 1 / 128, 1024)
+
+    before = march()
+    free0 = torch.cuda.mem_get_info()[0]
+    check(lib.nerftex_release_workspaces())
+    assert torch.cuda.mem_get_info()[0] > free0, "the march's accepted-t log (2048 x 1024 floats) went back to the driver"
+    after = march()
+    for a, b in zip(before, after):
+        assert torch.equal(a, b)
