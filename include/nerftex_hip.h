@@ -232,21 +232,25 @@ int nerftex_field_forward(const void* feats_lbc, const float* dirs, const void* 
                           uint32_t B, float* sigma, float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream);
 
 /* ------------------------------------------------------------------------- *
- * Extension (backward): the two MLP backward passes of the ngp field with
- * its glue folded into their load stage -- no grad_hc / grad_h tensors, two launches fewer:
- *   nerftex_field_backward_color == nerftex_field_out_backward + nerftex_ffmlp_backward of the
- *     colour net (forward_buffer NULL: recomputing): grad_rgbs [B,3] fp32, rgbs [B,3] fp32 (what
- *     nerftex_field_forward returned), cin [B,32] half -> grad_cin [B,32] half, grad_weights;
- *   nerftex_field_backward_sigma == nerftex_field_mid_backward + nerftex_ffmlp_backward of the
- *     sigma net: grad_sigma [B] fp32, h [B,16], grad_cin [B,32], x_rows [B,32] half -> grad_x
- *     [B,32] half (dL/dfeatures, rows), grad_weights.
- * Bit-identical gradients (the fused kernel forms the same halfs the glue kernels stored).
- * B % 128 == 0; fp16 only.
+ * Extension (backward): the backward of the ngp field behind the gather in
+ * THREE launches -- the two recomputing MLP backward kernels with the field's glue folded into
+ * their load stage (the colour net's output gradient is formed from grad_rgbs and rgbs:
+ * nerftex_field_out_backward; the sigma net's from grad_sigma, h and the colour net's input
+ * gradient: nerftex_field_mid_backward) and ONE reduction of both networks' weight-gradient
+ * partials -- for nerftex_field_out_backward + nerftex_ffmlp_backward + nerftex_field_mid_backward
+ * + nerftex_ffmlp_backward (six launches); no grad_hc / grad_h tensors.
+ *   in:  grad_sigma [B] fp32, grad_rgbs [B,3] fp32, rgbs [B,3] fp32 (as nerftex_field_forward
+ *        returned them), h [B,16], cin [B,32], x_rows [B,32] half (its training side outputs),
+ *        the two weight vectors;
+ *   out: grad_cin [B,32] half (the colour net's input gradient: scratch for the caller),
+ *        grad_x [B,32] half (dL/dfeatures, rows -> nerftex_grid_encode_backward),
+ *        grad_sigma_weights, grad_color_weights (half, overwritten).
+ * Bit-identical gradients.  B % 128 == 0; fp16 only.
  * ------------------------------------------------------------------------- */
-int nerftex_field_backward_color(const float* grad_rgbs, const float* rgbs, const void* cin, const void* color_weights, uint32_t B,
-                                 void* grad_cin, void* grad_weights, void* stream);
-int nerftex_field_backward_sigma(const float* grad_sigma, const void* h, const void* grad_cin, const void* x_rows,
-                                 const void* sigma_weights, uint32_t B, void* grad_x, void* grad_weights, void* stream);
+int nerftex_field_backward(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                           const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                           void* grad_x, void* grad_sigma_weights, void* grad_color_weights, void* stream);
+
 
 /* ------------------------------------------------------------------------- *
  * Extension (the sync-free inference loop): the two field launches of

@@ -8,7 +8,7 @@
 
 namespace nerftex {
 
-enum WorkspaceSlot { kWsMarch = 0, kWsCompact = 1, kWsMlp = 2, kWsGrid = 3, kWsGridFwd = 4, kWsGridBins = 5, kWsOccupancy = 6, kWsOccupancyList = 7, kWsSlots = 8 };
+enum WorkspaceSlot { kWsMarch = 0, kWsCompact = 1, kWsMlp = 2, kWsGrid = 3, kWsGridFwd = 4, kWsGridBins = 5, kWsOccupancy = 6, kWsOccupancyList = 7, kWsMlpB = 8, kWsSlots = 9 };
 
 // returns nullptr (and sets the error text) on allocation failure
 void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream);

@@ -63,7 +63,8 @@ color_out = _color_out.apply
 
 import os
 
-# False (NERFTEX_FIELD_BACKWARD=split): the four launches (glue, MLP, glue, MLP) the two fused ones replace -- same gradients, for A/B
+# False (NERFTEX_FIELD_BACKWARD=split): the six launches (glue, MLP + reduce, glue, MLP + reduce) nerftex_field_backward's three replace --
+# same gradients, for A/B
 FIELD_BACKWARD_FUSED = os.environ.get("NERFTEX_FIELD_BACKWARD", "fused") != "split"
 
 
@@ -133,9 +134,9 @@ class _ngp_field(Function):
         grad_rgbs = torch.zeros(B, 3, dtype=torch.float32, device=dev) if grad_rgbs is None else grad_rgbs.contiguous().float()
         grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc_h)
         grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)
-        if FIELD_BACKWARD_FUSED:  # the two glue kernels ride on the MLP backward kernels' load stage
-            check(lib.nerftex_field_backward_color(ptr(grad_rgbs), ptr(rgbs), ptr(cin), ptr(wc_h), B, ptr(grad_cin), ptr(grad_wc), stream()))
-            check(lib.nerftex_field_backward_sigma(ptr(grad_sigma), ptr(h), ptr(grad_cin), ptr(x_rows), ptr(ws_h), B, ptr(grad_x), ptr(grad_ws), stream()))
+        if FIELD_BACKWARD_FUSED:  # the two glue kernels ride on the MLP backward kernels' load stage, one reduction for both networks
+            check(lib.nerftex_field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin),
+                                             ptr(grad_x), ptr(grad_ws), ptr(grad_wc), stream()))
         else:
             grad_hc = torch.empty(B, 16, **half)
             check(lib.nerftex_field_out_backward(ptr(grad_rgbs), ptr(rgbs), B, ptr(grad_hc), stream()))

@@ -142,9 +142,10 @@ def test_one_kernel_field_equals_the_glue_kernel_sequence_bit_for_bit(dev, B):
     assert torch.equal(s1, f1.out[0]) and torch.equal(c1, f1.out[1]), "inference variant == training variant"
 
 
-def test_field_backward_entries_equal_glue_plus_mlp_backward(dev):
-    """nerftex_field_backward_color / _sigma (the glue kernels folded into the load stage of the recomputing MLP backward) against
-    nerftex_field_out_backward + nerftex_ffmlp_backward and nerftex_field_mid_backward + nerftex_ffmlp_backward: every output half
+def test_field_backward_entry_equals_glue_plus_mlp_backward(dev):
+    """nerftex_field_backward (the glue kernels folded into the load stage of the two recomputing MLP backward kernels, one reduction
+    launch for both networks) against nerftex_field_out_backward + nerftex_ffmlp_backward + nerftex_field_mid_backward +
+    nerftex_ffmlp_backward: every output half
     identical -- including logits outside the trunc_exp clamp, zero / huge / non-finite incoming gradients and colours at 0 and 1."""
     from nerftex_hip import check, lib, ptr, stream
 
@@ -173,8 +174,8 @@ def test_field_backward_entries_equal_glue_plus_mlp_backward(dev):
         grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc)
         grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws)
         if fused:
-            check(lib.nerftex_field_backward_color(ptr(grad_rgbs), ptr(rgbs), ptr(cin), ptr(wc), B, ptr(grad_cin), ptr(grad_wc), stream()))
-            check(lib.nerftex_field_backward_sigma(ptr(grad_sigma), ptr(h), ptr(grad_cin), ptr(x_rows), ptr(ws), B, ptr(grad_x), ptr(grad_ws), stream()))
+            check(lib.nerftex_field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws), ptr(wc), B, ptr(grad_cin),
+                                             ptr(grad_x), ptr(grad_ws), ptr(grad_wc), stream()))
         else:
             grad_hc, grad_h = torch.empty(B, 16, **half), torch.empty(B, 16, **half)
             check(lib.nerftex_field_out_backward(ptr(grad_rgbs), ptr(rgbs), B, ptr(grad_hc), stream()))
@@ -186,4 +187,5 @@ def test_field_backward_entries_equal_glue_plus_mlp_backward(dev):
 
     for a, b in zip(run(True), run(False)):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
-    assert lib.nerftex_field_backward_color(ptr(grad_rgbs), ptr(rgbs), ptr(cin), ptr(wc), 100, ptr(cin), ptr(wc), stream()) != 0  # B % 128
+    assert lib.nerftex_field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws), ptr(wc), 100, ptr(cin), ptr(cin),
+                                      ptr(ws), ptr(wc), stream()) != 0  # B % 128
