@@ -462,6 +462,53 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     return res, field, renderer
 
 
+def measure_curved(dev, n_points=262144, reps=10):
+    """BASELINE.json configs[3], the curved-field texture lookup on a star_flower-shaped synthetic mesh (~20 k faces, query
+    points within the height threshold of the surface and beyond it): per batch of sample points the projector (normal from the K nearest
+    vertices, two BVH closest-hit traces along +-normal, select, mask, frame, FreqEncoder -- one kernel; the neighbour search is the
+    caller's, as with the reference's frnn) and the curved field's hash lookup (GridEncoder_clustering L = 8, 512 -> 1024, tools/map.py:563)
+    forward + table-gradient backward.  Device time from events; points/s = points / (projector + lookup forward + backward)."""
+    from ngp_harness.curved import CurvedFieldLookup, MeshProjector, knn_bruteforce, star_flower_mesh
+
+    v, f = star_flower_mesh()
+    proj = MeshProjector(v, f, h_threshold=0.05).to(dev)
+    look = CurvedFieldLookup(v, f, bound=1.0, h_threshold=0.05).to(dev)
+    g = torch.Generator().manual_seed(7)
+    vt = torch.as_tensor(v, dtype=torch.float32)
+    base = vt[torch.randint(0, vt.shape[0], (n_points,), generator=g)]
+    xyz = (base * (1 + (torch.rand(n_points, 1, generator=g) - 0.5) * 0.12) + (torch.rand(n_points, 3, generator=g) - 0.5) * 0.01).to(dev)
+    neighbours = knn_bruteforce(xyz, proj.mesh_vertices, proj.K)  # outside the timed region: not this library's job
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3, out
+
+    t_proj, out = timed(lambda: proj.project(xyz, neighbours=neighbours))
+    p_sur, mask = out[0], out[2]
+    look.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    with torch.autocast("cuda", dtype=torch.float16):
+        t_fwd, feat = timed(lambda: look.encoder(p_sur, bound=1.0))
+        go = torch.randn_like(feat) * 1e-3
+
+        def fb():
+            look.encoder.embeddings.grad = None
+            look.encoder(p_sur, bound=1.0).backward(go)
+        t_fb, _ = timed(fb)
+    total = t_proj + t_fb
+    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces): projector (K-neighbour normal + two BVH traces + "
+                        "select + frame + FreqEncoder, one kernel) + GridEncoder_clustering L=8 hash lookup forward and table-gradient backward, 1 GPU" % len(f),
+            "points_per_batch": n_points, "inside_height_threshold": float(mask.float().mean()), "value": n_points / (total * 1e-6), "unit": "sample points/s",
+            "projector_us": t_proj, "lookup_forward_us": t_fwd, "lookup_forward_backward_us": t_fb, "neighbour_search": "outside the timed region (the reference: frnn)",
+            "dtype": "f32 geometry, f16 table under autocast"}
+
+
 WORKLOADS = {
     "ffmlp": "configs[2] (1 GPU) / configs[4] (8 GPUs, 65536 rays/step): fox-style scene, hashgrid L=16 F=2 T=2^19, FFMLP 2x64 + 3x64 on MFMA, "
              "HIP gridencoder+raymarching+shencoder+ffmlp, 800x800 random-pose pixels",
@@ -566,6 +613,10 @@ def main():
             other.append({"workload": label if "configs[2]" in label and len(label) > 12 else WORKLOADS[mlp_k], "rays_per_batch": rays_k, "dtype": dt_k,
                           "value": r2["value"], "unit": "ray-samples/s", "ms_per_step": r2["ms_per_step"], "steps": 16,
                           "launch": r2["graph"] if r2["graph"] else "eager launches"})
+        try:
+            other.append(measure_curved(dev))
+        except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
+            print(f"[bench] configs[3] measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

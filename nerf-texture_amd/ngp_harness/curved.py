@@ -109,13 +109,14 @@ class MeshProjector(torch.nn.Module):
         return p_sur, sdf, h_mask, normal, self.tbn[face_idx], face_idx
 
     @torch.no_grad()
-    def project(self, xyz, multires=12):
-        """-> p_sur [N,3], sdf [N,1], h_mask [N] bool, normal [N,3], tbn [N,3,3], face_idx [N], z_embed [N, 1 + 2 multires]."""
+    def project(self, xyz, multires=12, neighbours=None):
+        """-> p_sur [N,3], sdf [N,1], h_mask [N] bool, normal [N,3], tbn [N,3,3], face_idx [N], z_embed [N, 1 + 2 multires].
+        neighbours: (idx [N,K] int32, dis [N,K]) of a neighbour search done elsewhere (the reference: frnn); default = brute force here."""
         from nerftex_hip import check, lib, ptr, stream
 
         xyz = xyz.float().contiguous()
         N, dev = xyz.shape[0], xyz.device
-        idx, dis = knn_bruteforce(xyz, self.mesh_vertices, self.K)
+        idx, dis = knn_bruteforce(xyz, self.mesh_vertices, self.K) if neighbours is None else neighbours
         p_sur = torch.empty(N, 3, device=dev)
         sdf = torch.empty(N, device=dev)
         mask = torch.empty(N, dtype=torch.uint8, device=dev)
