@@ -140,18 +140,28 @@ __device__ __forceinline__ float tri_hit(const Tri& tr, const V3& ro, const V3& 
     return t;
 }
 
-// bounding_box.cuh:151-198: entry distance of the slab test, FLT_MAX on a miss
-__device__ __forceinline__ float box_entry(const Node& n, const V3& o, const V3& d) {
-    constexpr float kMiss = 3.402823466e+38f;
-    float tmin = (n.lo[0] - o.x) / d.x, tmax = (n.hi[0] - o.x) / d.x, s;
+// bounding_box.cuh:151-198: entry distance of the slab test, FLT_MAX on a miss.  The reference divides by the direction six times per
+// box; a box test only STEERS the traversal (which nodes are visited, in which order) -- the hit distance comes from the triangle test
+// -- so here the three reciprocals are taken once per ray (IEEE divisions: the inf / nan cases of an axis-parallel ray stay what they
+// are) and every slab interval is widened by 2^-21 of its ends: whatever the exact-division test accepts or orders in front of the
+// current hit, this one does too (a superset of the reference's visits, the same closest hit), at a dozen multiplies and selects per box
+// instead of 6 divisions of ~10 instructions each.  (Widening by a FACTOR keeps an infinite end infinite; a subtraction would make it nan.)
+__device__ __forceinline__ float box_entry(const Node& n, const V3& o, const V3& rinv) {
+    constexpr float kMiss = 3.402823466e+38f, kDown = 1.0f - 4.76837158e-7f, kUp = 1.0f + 4.76837158e-7f;
+    auto lower = [](float t) { return t * (t >= 0.0f ? kDown : kUp); };  // towards -inf
+    auto upper = [](float t) { return t * (t >= 0.0f ? kUp : kDown); };   // towards +inf
+    float tmin = (n.lo[0] - o.x) * rinv.x, tmax = (n.hi[0] - o.x) * rinv.x, s;
     if (tmin > tmax) { s = tmin; tmin = tmax; tmax = s; }
-    float tymin = (n.lo[1] - o.y) / d.y, tymax = (n.hi[1] - o.y) / d.y;
+    tmin = lower(tmin); tmax = upper(tmax);
+    float tymin = (n.lo[1] - o.y) * rinv.y, tymax = (n.hi[1] - o.y) * rinv.y;
     if (tymin > tymax) { s = tymin; tymin = tymax; tymax = s; }
+    tymin = lower(tymin); tymax = upper(tymax);
     if (tmin > tymax || tymin > tmax) return kMiss;
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
-    float tzmin = (n.lo[2] - o.z) / d.z, tzmax = (n.hi[2] - o.z) / d.z;
+    float tzmin = (n.lo[2] - o.z) * rinv.z, tzmax = (n.hi[2] - o.z) * rinv.z;
     if (tzmin > tzmax) { s = tzmin; tzmin = tzmax; tzmax = s; }
+    tzmin = lower(tzmin); tzmax = upper(tzmax);
     if (tmin > tzmax || tzmin > tmax) return kMiss;
     if (tzmin > tmin) tmin = tzmin;
     return tmin;
@@ -164,6 +174,7 @@ __device__ __forceinline__ float closest_hit(const V3& ro, const V3& rd, const N
     stack[sp++] = 0;
     float mint = kMaxDist;
     best = -1;
+    const V3 rinv{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
     while (sp > 0) {
         const Node node = nodes[stack[--sp]];
         if (node.left < 0) {
@@ -178,7 +189,7 @@ __device__ __forceinline__ float closest_hit(const V3& ro, const V3& rd, const N
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 idx[c] = node.left + c;
-                dist[c] = box_entry(nodes[idx[c]], ro, rd);
+                dist[c] = box_entry(nodes[idx[c]], ro, rinv);
             }
             // sort descending so that the nearest child is pushed last and popped first (bvh.cu:169-174)
 #define NERFTEX_CAS(a, b)                                                                       \
@@ -238,10 +249,13 @@ __global__ __launch_bounds__(64) void curved_project_kernel(uint32_t N, const fl
                                                             const float* __restrict__ tbn, uint32_t n_freqs, float* __restrict__ p_sur,
                                                             float* __restrict__ sdf_out, uint8_t* __restrict__ h_mask, float* __restrict__ normal_out,
                                                             int64_t* __restrict__ face_idx, float* __restrict__ tbn_out, float* __restrict__ z_embed) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    // TWO lanes per point, one per trace direction: the kernel is bound by the latency of its dependent node loads, and a batch of a few
+    // hundred thousand points with two traversals back to back per thread does not even fill the chip's wave slots once
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = tid >> 1, side = tid & 1u;
+    if (i >= N) return;  // N odd: the partner of the last point's lane 0 exists (same i), nobody is left alone in a pair
     const V3 x = load3(xyz + 3 * (size_t)i);
-    // ---- knn(): weighted normal
+    // ---- knn(): weighted normal (both lanes of a pair: the same loads, served once)
     V3 mean_dir{0, 0, 0}, nsum{0, 0, 0}, acc{0, 0, 0};
     float wsum = 0;
     for (uint32_t k = 0; k < K; k++) {
@@ -272,10 +286,14 @@ __global__ __launch_bounds__(64) void curved_project_kernel(uint32_t N, const fl
         nrm = {nrm.x / l, nrm.y / l, nrm.z / l};
     }
     // ---- project(): two closest hits, the nearer wins
-    int b1, b2;
-    const float d1 = closest_hit(x, nrm, nodes, tris, b1);
     const V3 neg{-nrm.x, -nrm.y, -nrm.z};
-    const float d2 = closest_hit(x, neg, nodes, tris, b2);
+    int b_mine;
+    const float d_mine = closest_hit(x, side ? neg : nrm, nodes, tris, b_mine);
+    const float d_other = __shfl_xor(d_mine, 1, kWave);
+    const int b_other = __shfl_xor(b_mine, 1, kWave);
+    if (side) return;  // lane 0 of the pair (the +normal trace) writes the point's outputs
+    const float d1 = d_mine, d2 = d_other;
+    const int b1 = b_mine, b2 = b_other;
     const bool inner = d1 < d2;
     const float d = inner ? d1 : d2;
     const V3 dir = inner ? nrm : neg;
@@ -407,7 +425,7 @@ extern "C" int nerftex_curved_project(const nerftex_raytracer* rt, const float* 
     const float h_limit = fminf(9.5f, h_threshold);  // depth_threshold of tools/map.py:407
     {
         KernelTimer kt("curved_project_kernel", as_stream(stream));
-        hipLaunchKernelGGL(curved_project_kernel, dim3(div_up(N, 64u)), dim3(64), 0, as_stream(stream), N, xyz, knn_idx, knn_dist, K, mesh_vertices, vertex_normals,
+        hipLaunchKernelGGL(curved_project_kernel, dim3(div_up(2 * N, 64u)), dim3(64), 0, as_stream(stream), N, xyz, knn_idx, knn_dist, K, mesh_vertices, vertex_normals,
                            dir_vec_wdist, h_limit, static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles), tbn, n_freqs, p_sur, sdf, h_mask,
                            normal, face_idx, tbn_out, z_embed);
     }
