@@ -52,11 +52,10 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(const float* __restri
 
     float x[D];
     bool oob = false;
+    load_coords<D>(lc, inputs, (size_t)b, x);
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-        x[d] = load_coord(lc, inputs, (size_t)b * D + d);
+    for (int d = 0; d < D; d++)
         if (x[d] < 0 || x[d] > 1) oob = true;
-    }
 
     for (uint32_t level = 0; level < L; level++) {
         T* out = BLC ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
@@ -180,11 +179,10 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
 
     float x[D];
     bool oob = false;
+    load_coords<D>(lc, inputs, (size_t)b, x);
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-        x[d] = load_coord(lc, inputs, (size_t)b * D + d);
+    for (int d = 0; d < D; d++)
         if (x[d] < 0 || x[d] > 1) oob = true;
-    }
     T* out = out_lbc + ((size_t)level * B + b) * C;
     T* dyd = dy_dx + ((size_t)b * L + level) * (D * C);
     if (oob) {
@@ -369,10 +367,11 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
     bool valid = b < B;
     float x[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-        x[d] = valid ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
+    for (int d = 0; d < D; d++) x[d] = 0.0f;
+    if (valid) load_coords<D>(lc, inputs, (size_t)b, x);
+#pragma unroll
+    for (int d = 0; d < D; d++)
         if (x[d] < 0 || x[d] > 1) valid = false;  // gridencoder.cu:248-253: out-of-range points add nothing
-    }
 
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
@@ -612,8 +611,7 @@ __global__ __launch_bounds__(kOwnerThreads) void grid_backward_owner_kernel(cons
         float gn[C];
         auto fetch = [&](uint32_t b) {
             if (b < hi) {
-#pragma unroll
-                for (int d = 0; d < D; d++) xn[d] = load_coord(lc, inputs, (size_t)b * D + d);
+                load_coords<D>(lc, inputs, (size_t)b, xn);
                 load_row<T, C>(g_level + (size_t)b * C, gn);
             } else {
 #pragma unroll

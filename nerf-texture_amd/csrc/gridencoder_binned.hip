@@ -294,7 +294,8 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     const bool in_batch = b < B;
     float xs[D], g[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int d = 0; d < D; d++) xs[d] = in_batch ? load_coord(lc, inputs, (size_t)b * D + d) : 0.0f;
+    for (int d = 0; d < D; d++) xs[d] = 0.0f;
+    if (in_batch) load_coords<D>(lc, inputs, (size_t)b, xs);
     if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
     if (probe == 4) {  // ablation: launch + loads only
         if (xs[0] == 1234.5f && xs[D - 1] == 77.0f && g[1] == 3.0f && g[0] == 2.0f) dir[0] = 1;
