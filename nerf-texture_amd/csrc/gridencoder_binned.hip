@@ -361,8 +361,15 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     __syncthreads();
     if (probe == 3) return;  // ablation: + placement in LDS
     const uint32_t total = min(lbase[kMaxTilesPerLevel], kStageRecords);
-#pragma unroll 5
-    for (uint32_t i = threadIdx.x; i < total; i += kBinSamples) reinterpret_cast<Bits*>(region)[i] = stage[i];  // one contiguous block, tile order preserved
+    // one contiguous block, tile order preserved; 16 bytes per lane (two fp16 records / one fp32 record) while they last
+    constexpr uint32_t kPer = 16 / sizeof(Bits);
+    typedef u32x4_t __attribute__((address_space(3))) LdsQuad;
+    const LdsQuad* stage4 = (const LdsQuad*)smem;
+    u32x4_t* region4 = reinterpret_cast<u32x4_t*>(region);
+    const uint32_t quads = total / kPer;
+#pragma unroll 3
+    for (uint32_t i = threadIdx.x; i < quads; i += kBinSamples) region4[i] = stage4[i];
+    if (threadIdx.x < total - quads * kPer) reinterpret_cast<Bits*>(region)[quads * kPer + threadIdx.x] = stage[quads * kPer + threadIdx.x];
 }
 
 // K4d: one record into the tile's accumulators.  fp16: value * 2^24 in 64-bit integers -- every half is an integer multiple of
