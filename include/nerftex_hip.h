@@ -105,10 +105,19 @@ int nerftex_grid_encode_backward(const void* grad, const float* inputs, const vo
                                  void* stream);
 
 /* Install the host copy of a level table (offsets_host [L+1]) for the device table at offsets_dev.  The large-batch backward
- * plans its launch from a host copy, which it otherwise reads back once per (pointer, L, device) and keeps: a caller that may
- * pass a NEW table at a recycled address must register it (the kernels trap on a host/device mismatch).  The Python wrapper
- * registers every offsets tensor it sees for the first time.                                                             */
+ * plans its launch from a host copy.  A table it has not been told about is learnt WITHOUT blocking: an asynchronous copy into
+ * pinned memory is started on the call's stream and the launches that arrive before it has landed run the path that needs no
+ * host copy (slower, same results); under stream capture an unknown table is NERFTEX_ERR_INVALID.  A caller that may pass a NEW
+ * table at a recycled address must register it: the kernels compare the device table with the host copy, and on a mismatch the
+ * launch writes NO gradient and raises a deferred error (below) -- nothing traps, nothing synchronises.  The Python wrapper
+ * registers every offsets tensor it sees for the first time.  [extension: the reference reads offsets on the device only]   */
 int nerftex_grid_register_offsets(const int32_t* offsets_dev, uint32_t L, const int32_t* offsets_host);
+
+/* Deferred (asynchronous) error of an earlier launch, reported once: NERFTEX_ERR_INVALID + nerftex_last_error() text if a
+ * hash-grid backward launch found its device offsets table different from the registered host copy, else NERFTEX_OK.  Meaningful
+ * after the stream has been synchronised; the next nerftex_grid_encode_backward* call reports (and clears) it as well.
+ * [extension]                                                                                                             */
+int nerftex_deferred_error(void);
 
 /* The same two calls with the caller's coordinate normalisation folded in: every kernel reads x = (inputs + in_add) * in_mul
  * (two fp32 roundings, as the framework's add and multiply before the call: gridencoder/grid.py:141 with in_add = bound,
@@ -277,16 +286,33 @@ int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const v
  * height / face id / tangent frame, the height mask, and FreqEncoder(height)
  * (tools/encoding.py:5-43, tools/map.py:635).  The neighbour search itself (frnn,
  * un-vendored) stays with the caller: knn_idx / knn_dist are its output.
- *   xyz [N,3]; knn_idx [N,K] int32; knn_dist [N,K] (euclidean, ascending);
- *   mesh_vertices, vertex_normals [V,3]; tbn [F,9] or NULL; n_freqs = multires;
+ *   xyz [N,3]; knn_idx [N,K] int32 (a negative index counts from the end, as the framework's vertex_normals[idx] does with frnn's
+ *   -1 padding; anything else outside [0, n_verts) is clamped into it); knn_dist [N,K] (euclidean, ascending);
+ *   mesh_vertices, vertex_normals [n_verts,3]; tbn [F,9] or NULL; n_freqs = multires;
  *   p_sur [N,3]; sdf [N]; h_mask [N] uint8; normal [N,3]; face_idx [N] int64
  *   (-1: no hit within 10); tbn_out [N,9] or NULL; z_embed [N, 1 + 2 n_freqs] or NULL.
  * ------------------------------------------------------------------------- */
 int nerftex_curved_project(const nerftex_raytracer* rt, const float* xyz, const int32_t* knn_idx, const float* knn_dist,
-                           uint32_t N, uint32_t K, const float* mesh_vertices, const float* vertex_normals,
+                           uint32_t N, uint32_t K, const float* mesh_vertices, const float* vertex_normals, uint32_t n_verts,
                            float dir_vec_wdist, float h_threshold, const float* tbn, uint32_t n_freqs, float* p_sur,
                            float* sdf, uint8_t* h_mask, float* normal, int64_t* face_idx, float* tbn_out,
                            float* z_embed, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Extension: the neighbour search of the curved-field projector --
+ * the role of frnn.frnn_grid_points (un-vendored FRNN) at tools/map.py:396 (grid over the
+ * mesh vertices, built once) and :456 (K nearest vertices per sample point, sorted, with a
+ * radius that never binds).  EXACT K nearest: a uniform grid built on the host from
+ * host_points [V,3], searched ring by ring on the device until the K-th best distance
+ * cannot be beaten by an unvisited cell.
+ *   idx [N,K] int32 ascending by distance (equal distances inside one cell: by index),
+ *   dist [N,K] EUCLIDEAN distances (what MeshProjector.knn() computes with dis.sqrt()).
+ * 1 <= K <= min(16, V).
+ * ------------------------------------------------------------------------- */
+typedef struct nerftex_knn nerftex_knn;
+int nerftex_knn_create(const float* host_points, uint32_t n_points, nerftex_knn** out);
+int nerftex_knn_destroy(nerftex_knn* knn);
+int nerftex_knn_query(const nerftex_knn* knn, const float* xyz, uint32_t N, uint32_t K, int32_t* idx, float* dist, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Extension: the inference loop without a host stall.

@@ -69,7 +69,8 @@ struct IndexFn {
     uint32_t ndense;     // number of dimensions the dense loop covers
     bool hashed;
     bool pow2;
-    bool modulo;  // a real `% size` is needed: only a tiled (never hashed) level whose dense index range exceeds its table
+    bool modulo;  // a real `% size` is needed: the index range exceeds the table (a hashed level, or a tiled one that wraps) and the
+                  // table size is not a power of two
     uint32_t size;
 
     __device__ IndexFn(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
@@ -88,7 +89,9 @@ struct IndexFn {
         pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
         // a dense level has f^D <= size (f = points per axis), and a corner coordinate is at most f, so its index stays below
         // f + f^2 + ... + f^D < 2 size: the reference's `index % hashmap_size` (gridencoder.cu:69) is one conditional subtraction there
-        modulo = !hashed && s > hashmap_size;
+        // (a HASHED level's index is a full 32-bit value: with a table size that is not a power of two -- any offsets table may come in
+        // through the C ABI -- it needs the real modulo as well)
+        modulo = s > hashmap_size;
     }
 
     // The same index, factored: every corner coordinate is pg[d] or pg[d] + 1, so the per-dimension terms are computed once (one

@@ -18,8 +18,11 @@
 //              fp32 tables keep float LDS atomics (and float atomics for shared tiles).
 // Coarse dense levels first merge runs of consecutive samples that share a cell (wave64 segmented reduction), which
 // removes their same-row pile-ups before anything is written.
-// The level table lives on the device; its host copy (needed to size grids and buffers) is read back ONCE per
-// (pointer, L) and every launch re-validates it on the device, trapping on a mismatch.
+// The level table lives on the device; its host copy (needed to size grids and buffers) is either registered by the caller
+// (nerftex_grid_register_offsets) or learnt WITHOUT blocking: the first launches that see an unknown table take another path while an
+// asynchronous copy into pinned memory completes.  Every workgroup re-validates the host copy against the device table; on a
+// mismatch (a stale registration) the launch does nothing and raises a deferred error that the next grid call -- or
+// nerftex_deferred_error() -- returns as NERFTEX_ERR_INVALID.  Nothing here synchronises or traps.
 #include "common.hpp"
 #include "grid_common.hpp"
 #include "workspace.hpp"
@@ -45,6 +48,9 @@ constexpr uint32_t kSumThreads = 1024;
 // whole (pairs that straddle a tile edge, and runs of samples merged before emission, whose two sums no longer share one p).
 //   fp16:  word = local row a | kcode << 12 | p16 << 16 (p in 2^-16 units), g' as half2                      ->  8 bytes
 //   fp32:  word = local row a | kcode << 14, p and g' as floats                                                -> 16 bytes
+// deferred error word in pinned, device-visible host memory (gridencoder_binned.hip owns it; runtime reads it)
+__device__ __forceinline__ void raise_stale(uint32_t* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 template <typename T> struct Rec;
 template <> struct Rec<half_t> { uint32_t word; half2_t g; };
 template <> struct Rec<float> { uint32_t word; float p, g0, g1; };
@@ -254,7 +260,15 @@ struct DirTable {
     uint32_t slices[kMaxLevels];         // work items per tile of the level (each takes a range of chunks)
     uint32_t split_base[kMaxLevels];     // levels with slices > 1: index of the level's first tile among the split tiles (ticket counters)
     uint32_t part_base[kMaxLevels];      //                         index of the level's first partial tile in the partial-sum buffer
+    uint32_t* stale_flag;                // deferred error word (pinned host memory): set when the device table differs from `offsets`
 };
+
+// host copy vs device table, for the level a workgroup works on: a stale registration must not size or address anything
+__device__ __forceinline__ bool table_matches(const DirTable& tab, const int* __restrict__ offsets, uint32_t level) {
+    const bool ok = offsets[level] == tab.offsets[level] && offsets[level + 1] == tab.offsets[level + 1];
+    if (!ok && threadIdx.x == 0) raise_stale(tab.stale_flag);
+    return ok;
+}
 
 template <typename T, int D, bool BLC>
 __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
@@ -272,10 +286,10 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     static_assert(sizeof(Bits) == sizeof(Rec<T>), "record size");
     typedef Bits __attribute__((address_space(3))) LdsBits;
     LdsBits* stage = (LdsBits*)smem;
-    if (blockIdx.x == 0 && threadIdx.x <= L && offsets[threadIdx.x] != tab.offsets[threadIdx.x]) __builtin_trap();  // host copy vs device table
     const uint32_t group = blockIdx.x / (kXcds * L), rem = blockIdx.x % (kXcds * L);
     const uint32_t level = rem / kXcds, chunk = group * kXcds + rem % kXcds;  // id % 8 = chunk % 8 = the XCD that runs it
     if (chunk >= nchunks || probe == 5) return;  // ablation 5: launch only
+    if (!table_matches(tab, offsets, level)) return;  // stale host copy: deferred error, nothing written
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
     // caller handed over an uninitialised gradient table: the tiles of this level that several K4d work items will add into
@@ -482,10 +496,12 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
 template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
-                                                                   const bool overwrite, unsigned long long* __restrict__ partials) {
+                                                                   const bool overwrite, unsigned long long* __restrict__ partials,
+                                                                   const int* __restrict__ offsets) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SumItem it;
     if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it)) return;
+    if (!table_matches(tab, offsets, it.level)) return;  // K3d wrote no directory for this level either
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     constexpr uint32_t kWaves = kSumThreads / kWave;
     zero_tile<T>(smem, it.nrows);
@@ -543,7 +559,8 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
 // (or adds them to what the caller's buffer holds).
 constexpr uint32_t kCombineRows = kWave, kCombineWaves = 4, kCombineThreads = kCombineRows * kCombineWaves;
 __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const unsigned long long* __restrict__ partials, const DirTable tab, uint32_t L,
-                                                                       half_t* __restrict__ grad_grid, const bool overwrite) {
+                                                                       half_t* __restrict__ grad_grid, const bool overwrite,
+                                                                       const int* __restrict__ offsets) {
     __shared__ unsigned long long s_sum[kCombineWaves][kCombineRows][2];
     constexpr uint32_t kRows = rows_per_tile<half_t>(), kSegs = kRows / kCombineRows;
     const uint32_t split_tile = blockIdx.x / kSegs, seg = blockIdx.x % kSegs;
@@ -551,6 +568,7 @@ __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const un
     for (uint32_t l = 0; l < L; l++)
         if (tab.slices[l] > 1 && tab.split_base[l] <= split_tile) level = l;
     const uint32_t t = split_tile - tab.split_base[level], slices = tab.slices[level];
+    if (!table_matches(tab, offsets, level)) return;
     const uint32_t rows_level = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
     const uint32_t lane = threadIdx.x % kCombineRows, q = threadIdx.x / kCombineRows;
     const uint32_t local = seg * kCombineRows + lane, row = t * kRows + local;
@@ -593,32 +611,79 @@ struct TableKey {
     const void* ptr; uint32_t L; int dev;
     bool operator<(const TableKey& o) const { return ptr != o.ptr ? ptr < o.ptr : (L != o.L ? L < o.L : dev < o.dev); }
 };
-std::map<TableKey, std::vector<int32_t>> g_tables;
+// a table seen for the first time is copied into pinned memory asynchronously; until that copy has completed (hipEventQuery, never a
+// wait) the launches that need the host copy take another path
+struct TableEntry {
+    std::vector<int32_t> host;     // valid once `known`
+    bool known = false;
+    int32_t* pinned = nullptr;     // in-flight read-back
+    hipEvent_t done = nullptr;
+};
+std::map<TableKey, TableEntry> g_tables;
 std::mutex g_tables_mutex;
 
-// The host copy sizes the launch.  A table the caller registered (nerftex_grid_register_offsets) costs nothing; an unknown one is
-// read back once -- a blocking copy, which a stream under capture cannot do: that caller gets NERFTEX_ERR_INVALID and is told to
-// register the table first.
+// deferred error word: pinned host memory every device can write (a kernel found its device table different from the host copy)
+uint32_t* g_stale_host = nullptr;
+uint32_t* stale_flag() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+            g_stale_host = static_cast<uint32_t*>(p);
+            *g_stale_host = 0;
+        }
+    });
+    return g_stale_host;
+}
+
+// NERFTEX_OK + out filled | -1: not known yet (learning it in the background; take a path that needs no host copy) | an error
 int host_offsets(const int* offsets_dev, uint32_t L, hipStream_t st, std::vector<int32_t>& out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const TableKey key{offsets_dev, L, dev};
     std::lock_guard<std::mutex> lock(g_tables_mutex);
-    auto it = g_tables.find(key);
-    if (it == g_tables.end()) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-            set_error("grid_encode_backward: this offsets table is not known yet and the stream is being captured; call "
-                      "nerftex_grid_register_offsets() first (or run one launch outside the capture)");
-            return NERFTEX_ERR_INVALID;
-        }
-        std::vector<int32_t> h(L + 1);
-        NERFTEX_HIP_TRY(hipMemcpyAsync(h.data(), offsets_dev, sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost, st), "offsets read-back");
-        NERFTEX_HIP_TRY(hipStreamSynchronize(st), "offsets read-back");
-        it = g_tables.emplace(key, std::move(h)).first;
+    TableEntry& e = g_tables[key];
+    if (!e.known && e.done && hipEventQuery(e.done) == hipSuccess) {  // the background copy has landed
+        e.host.assign(e.pinned, e.pinned + L + 1);
+        e.known = true;
+        (void)hipEventDestroy(e.done);
+        (void)hipHostFree(e.pinned);
+        e.done = nullptr;
+        e.pinned = nullptr;
     }
-    out = it->second;
-    return NERFTEX_OK;
+    if (e.known) {
+        out = e.host;
+        return NERFTEX_OK;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("grid_encode_backward: this offsets table is not known yet and the stream is being captured; call "
+                  "nerftex_grid_register_offsets() first (or run a few launches outside the capture)");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (!e.done) {  // first sight: start the read-back, do not wait for it
+        void* p = nullptr;
+        NERFTEX_HIP_TRY(hipHostMalloc(&p, sizeof(int32_t) * (L + 1), hipHostMallocDefault), "offsets read-back buffer");
+        e.pinned = static_cast<int32_t*>(p);
+        NERFTEX_HIP_TRY(hipEventCreateWithFlags(&e.done, hipEventDisableTiming), "offsets read-back event");
+        NERFTEX_HIP_TRY(hipMemcpyAsync(e.pinned, offsets_dev, sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost, st), "offsets read-back");
+        NERFTEX_HIP_TRY(hipEventRecord(e.done, st), "offsets read-back event");
+    }
+    return -1;
+}
+
+// a stale registration found by an earlier launch: reported once, and every cached table is dropped (re-learnt or re-registered)
+int take_deferred_error() {
+    uint32_t* flag = stale_flag();
+    if (!flag || __atomic_load_n(flag, __ATOMIC_RELAXED) == 0u) return NERFTEX_OK;
+    __atomic_store_n(flag, 0u, __ATOMIC_RELAXED);
+    {
+        std::lock_guard<std::mutex> lock(g_tables_mutex);
+        for (auto it = g_tables.begin(); it != g_tables.end();) it = it->second.known ? g_tables.erase(it) : std::next(it);
+    }
+    set_error("grid_encode_backward: an earlier launch found the device offsets table different from its registered host copy "
+              "(stale nerftex_grid_register_offsets?); that launch wrote no gradient.  The cached tables were dropped: register again");
+    return NERFTEX_ERR_INVALID;
 }
 
 }  // namespace
@@ -627,8 +692,10 @@ template <typename T, int D>
 int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
                          const LevelConsts& lc, uint32_t gridtype, bool align_corners, bool overwrite, hipStream_t st) {
     std::vector<int32_t> off;
-    int rc = host_offsets(offsets_dev, L, st, off);
+    int rc = take_deferred_error();
     if (rc != NERFTEX_OK) return rc;
+    rc = host_offsets(offsets_dev, L, st, off);
+    if (rc != NERFTEX_OK) return rc;  // -1: table still being learnt -> the caller's other path
     constexpr uint32_t kRows = rows_per_tile<T>();
     constexpr uint32_t NP = 1u << (D - 1);
     const uint32_t nchunks = div_up(B, kBinSamples);
@@ -657,6 +724,8 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     dt.offsets[L] = off[L];
     dt.tile_base[L] = tiles;
     dt.item_base[L] = items;
+    dt.stale_flag = stale_flag();
+    if (!dt.stale_flag) { set_error("grid_encode_backward: no pinned memory for the deferred error word"); return NERFTEX_ERR_HIP; }
     const size_t dir_bytes = (sizeof(uint32_t) * (size_t)L * kMaxTilesPerLevel * nchunks + 255) / 256 * 256;
     const size_t part_bytes = (size_t)part_tiles * kTileBytes;  // exact integer partial sums of the tiles several work items share
     char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + part_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
@@ -679,14 +748,14 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         auto kernel = sum_tiles_dir_kernel<T>;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
         KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials);
+        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials, offsets_dev);
     }
     if ((rc = check_launch("grid_encode_backward(sum)")) != NERFTEX_OK) return rc;
     if constexpr (sizeof(T) == 2) {
         if (split_tiles) {
             KernelTimer kt("combine_tiles_kernel", st, kTimeGrid);
             hipLaunchKernelGGL(combine_tiles_kernel, dim3(split_tiles * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
-                               reinterpret_cast<half_t*>(grad_grid), overwrite);
+                               reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev);
         }
         return check_launch("grid_encode_backward(combine)");
     }
@@ -703,7 +772,8 @@ template int grid_backward_binned<half_t, 3>(const half_t*, bool, const float*, 
 
 // The host copy of a level table is cached per (device pointer, L, device): a caller that knows the table can install it up front --
 // and must, when it may hand over a NEW table at an address the allocator has recycled from an old one (the kernels compare the
-// device table with the host copy and trap on a mismatch rather than scatter out of bounds).
+// device table with the host copy; on a mismatch they write nothing and raise the deferred error below rather than scatter out of
+// bounds).
 extern "C" int nerftex_grid_register_offsets(const int32_t* offsets_dev, uint32_t L, const int32_t* offsets_host) {
     using namespace nerftex;
     using namespace nerftex::gridenc;
@@ -715,6 +785,13 @@ extern "C" int nerftex_grid_register_offsets(const int32_t* offsets_dev, uint32_
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_tables_mutex);
-    g_tables[TableKey{offsets_dev, L, dev}] = std::vector<int32_t>(offsets_host, offsets_host + L + 1);
+    TableEntry& e = g_tables[TableKey{offsets_dev, L, dev}];
+    e.host.assign(offsets_host, offsets_host + L + 1);
+    e.known = true;  // (a read-back still in flight for this key is simply never consumed)
     return NERFTEX_OK;
+}
+
+extern "C" int nerftex_deferred_error(void) {
+    nerftex::clear_error();
+    return nerftex::gridenc::take_deferred_error();
 }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void raytrace_kernel(uint32_t N, const float* r
 constexpr int kMaxK = 16;
 __global__ __launch_bounds__(64) void curved_project_kernel(uint32_t N, const float* __restrict__ xyz, const int32_t* __restrict__ knn_idx,
                                                             const float* __restrict__ knn_dist, uint32_t K, const float* __restrict__ verts,
-                                                            const float* __restrict__ vnormals, float dir_vec_wdist, float h_limit,
+                                                            const float* __restrict__ vnormals, int n_verts, float dir_vec_wdist, float h_limit,
                                                             const Node* __restrict__ nodes, const Tri* __restrict__ tris,
                                                             const float* __restrict__ tbn, uint32_t n_freqs, float* __restrict__ p_sur,
                                                             float* __restrict__ sdf_out, uint8_t* __restrict__ h_mask, float* __restrict__ normal_out,
@@ -259,7 +259,11 @@ __global__ __launch_bounds__(64) void curved_project_kernel(uint32_t N, const fl
     V3 mean_dir{0, 0, 0}, nsum{0, 0, 0}, acc{0, 0, 0};
     float wsum = 0;
     for (uint32_t k = 0; k < K; k++) {
-        const int v = knn_idx[(size_t)i * K + k];
+        // a neighbour list from elsewhere may pad with -1 (frnn): the framework's vertex_normals[-1] is the LAST row, so is it here; anything
+        // still outside the mesh is clamped -- the loads below must stay inside the two vertex arrays whatever the list holds
+        int v = knn_idx[(size_t)i * K + k];
+        v = v < 0 ? v + n_verts : v;
+        v = min(max(v, 0), n_verts - 1);
         const float dis = knn_dist[(size_t)i * K + k];
         const V3 n = load3(vnormals + 3 * (size_t)v);
         const V3 d = sub(x, load3(verts + 3 * (size_t)v));
@@ -413,12 +417,12 @@ extern "C" int nerftex_raytracer_trace(const nerftex_raytracer* rt, const float*
 }
 
 extern "C" int nerftex_curved_project(const nerftex_raytracer* rt, const float* xyz, const int32_t* knn_idx, const float* knn_dist, uint32_t N, uint32_t K,
-                                      const float* mesh_vertices, const float* vertex_normals, float dir_vec_wdist, float h_threshold, const float* tbn,
+                                      const float* mesh_vertices, const float* vertex_normals, uint32_t n_verts, float dir_vec_wdist, float h_threshold, const float* tbn,
                                       uint32_t n_freqs, float* p_sur, float* sdf, uint8_t* h_mask, float* normal, int64_t* face_idx, float* tbn_out,
                                       float* z_embed, void* stream) {
     clear_error();
-    if (!rt || K == 0 || K > (uint32_t)kMaxK || (tbn_out && !tbn)) {
-        set_error("curved_project: need a raytracer, 1 <= K <= %d neighbours per point, and the per-face frames when tbn_out is requested", kMaxK);
+    if (!rt || K == 0 || K > (uint32_t)kMaxK || (tbn_out && !tbn) || n_verts == 0 || n_verts > 0x7fffffffu) {
+        set_error("curved_project: need a raytracer, 1 <= K <= %d neighbours per point, a non-empty vertex array, and the per-face frames when tbn_out is requested", kMaxK);
         return NERFTEX_ERR_INVALID;
     }
     if (N == 0) return NERFTEX_OK;
@@ -426,7 +430,7 @@ extern "C" int nerftex_curved_project(const nerftex_raytracer* rt, const float* 
     {
         KernelTimer kt("curved_project_kernel", as_stream(stream));
         hipLaunchKernelGGL(curved_project_kernel, dim3(div_up(2 * N, 64u)), dim3(64), 0, as_stream(stream), N, xyz, knn_idx, knn_dist, K, mesh_vertices, vertex_normals,
-                           dir_vec_wdist, h_limit, static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles), tbn, n_freqs, p_sur, sdf, h_mask,
+                           (int)n_verts, dir_vec_wdist, h_limit, static_cast<const Node*>(rt->nodes), static_cast<const Tri*>(rt->triangles), tbn, n_freqs, p_sur, sdf, h_mask,
                            normal, face_idx, tbn_out, z_embed);
     }
     return check_launch("curved_project");

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "nerftex_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _u32, _i, _i, _i, _vp],
     "nerftex_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _vp],
     "nerftex_grid_register_offsets": [_vp, _u32, _vp],
+    "nerftex_deferred_error": [],
     "nerftex_grid_encode_forward_affine": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _u32, _i, _i, _i, _f32, _f32, _vp],
     "nerftex_grid_encode_backward_affine": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _f32, _f32, _vp],
     "nerftex_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _i, _vp, _vp],
@@ -81,7 +82,10 @@ _SIGNATURES = {
     "nerftex_ffmlp_free_splitk": [],
     "nerftex_create_raytracer": [_vp, _u32, _vp, _u32, C.POINTER(_vp)],
     "nerftex_destroy_raytracer": [_vp],
-    "nerftex_curved_project": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _f32, _f32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_curved_project": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _u32, _f32, _f32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_knn_create": [_vp, _u32, C.POINTER(_vp)],
+    "nerftex_knn_destroy": [_vp],
+    "nerftex_knn_query": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "nerftex_raytracer_trace": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
 }
 EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get"] + list(_SIGNATURES)

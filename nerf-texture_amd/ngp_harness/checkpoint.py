@@ -21,7 +21,9 @@ def model_state(renderer):
 def save_checkpoint(path, renderer, epoch=0, global_step=0, stats=None, optimizer=None, scaler=None):
     """Write what Trainer.save_checkpoint(full=optimizer is not None) writes (nerf/utils.py:1485-1523)."""
     state = {"epoch": epoch, "global_step": global_step, "stats": stats or {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None},
-             "mean_count": renderer.mean_count, "mean_density": renderer.mean_density, "model": model_state(renderer)}
+             # plain Python numbers, as nerf/utils.py:1496-1497 stores them (the device-side occupancy update keeps mean_density as a view of
+             # a buffer every later update overwrites: never pickle that)
+             "mean_count": int(renderer.mean_count), "mean_density": float(renderer.mean_density), "model": model_state(renderer)}
     if optimizer is not None:
         state["optimizer"] = optimizer.state_dict()
     if scaler is not None:
@@ -58,12 +60,14 @@ def load_checkpoint(path, renderer, optimizer=None, scaler=None, model_only=Fals
     ckpt = torch.load(path, map_location=map_location, weights_only=False)
     if "model" not in ckpt:
         load_model_state(renderer, ckpt, strict=True)
+        if optimizer is not None and hasattr(optimizer, "resync"):
+            optimizer.resync()  # the masters changed under it
         return ckpt
     load_model_state(renderer, ckpt["model"], strict=False)
     if "mean_count" in ckpt:
-        renderer.mean_count = ckpt["mean_count"]
+        renderer.mean_count = int(ckpt["mean_count"])
     if "mean_density" in ckpt:
-        renderer.mean_density = ckpt["mean_density"]
+        renderer.mean_density = float(ckpt["mean_density"])
     if optimizer is not None and hasattr(optimizer, "resync"):
         optimizer.resync()  # the masters changed under it
     if model_only:

@@ -1,12 +1,18 @@
-"""Config 4 harness: the lookup chain of the curved-field texture (`tools/map.py:414-433, 620-641` of the reference).
+"""Config 4 harness: the curved-field texture of the reference without its six un-vendored packages (frnn, pytorch3d, tinycudann,
+xatlas, open3d, trimesh).
 
-The reference's MeshFeatureField needs six un-vendored packages (frnn, pytorch3d, tinycudann, xatlas, open3d,
-trimesh), so the module itself is out of scope; what IS on the hot path is the chain
-    sample point x, local normal n  ->  two BVH closest-hit traces (x, +n) and (x, -n)  ->  nearer hit:
-    surface point p_sur, signed height sdf = +-depth, face id  ->  hash-grid encode of p_sur
-    (GridEncoder_clustering, L=8, F=2, base 512 -> 1024, align_corners=True)  ->  mask |sdf| < h_threshold
-which this module reproduces on a synthetic "star_flower"-shaped mesh (a sphere with a 5-lobe radial
-modulation) with analytic normals standing in for the frnn KNN normal estimate.
+  MeshProjector      tools/map.py:340-502: K nearest mesh vertices (the role of frnn: csrc/knn.hip) -> Shepard-weighted coarse normal
+                     -> two BVH closest-hit traces along +-normal -> nearer hit = surface point, signed height, face, frame, mask;
+                     `project` is the fused kernel (nerftex_curved_project), `project_reference` the reference's op sequence;
+  CurvedField        MeshFeatureField.forward (tools/map.py:620-641, 717-737) + network_curvedfield.NeRFNetwork.forward / density
+                     (nerf/network_curvedfield.py:229-243, 283-300, 382-409) with the static light model: projector ->
+                     GridEncoder_clustering(p_sur) ++ FreqEncoder(height) (16 + 25 = 41, padded to 48 with ones the way tcnn pads)
+                     -> FFMLP 48-32-16 -> trunc_exp / geo features; reflection of the view direction about the coarse normal -> SH(4)
+                     ++ geo (31, padded to 32) -> FFMLP 32-64-64-3 -> sigmoid; both masked by the height mask.  A field
+                     `ngp_harness.model.Renderer` can march.  The tcnn networks are served by the in-tree FFMLP (the reference's own
+                     transplant of the same fully-fused kernel): tests/golden/ref_python_curvedfield.npz pins the chain against the
+                     reference's modules executed with exactly that substitution;
+  CurvedFieldLookup  round 1's minimal chain (analytic normals -> traces -> hash lookup), kept for its test.
 """
 import numpy as np
 import torch
@@ -48,7 +54,7 @@ def vertex_normals(vertices, faces):
 
 
 def knn_bruteforce(xyz, vertices, K=8, chunk=8192):
-    """K nearest mesh vertices per point, ascending (distances euclidean) -- stands in for frnn.frnn_grid_points (tools/map.py:456)."""
+    """K nearest mesh vertices per point, ascending (distances euclidean), by cdist + topk: the test reference of MeshProjector.knn."""
     idx, dist = [], []
     for a in range(0, xyz.shape[0], chunk):
         d = torch.cdist(xyz[a:a + chunk], vertices)
@@ -63,19 +69,53 @@ class MeshProjector(torch.nn.Module):
     forms: `project_reference` restates the reference's framework-op sequence over RayTracer.trace, `project` is the fused kernel
     (nerftex_curved_project), which also returns FreqEncoder(height)."""
 
-    def __init__(self, vertices, faces, h_threshold=0.05, K=8):
+    def __init__(self, vertices, faces, h_threshold=0.05, K=8, vertex_normals=None, tbn=None):
+        """vertex_normals / tbn: the mesh's own (the reference takes them from open3d and from its UV map, tools/map.py:365-366,396);
+        default: area-weighted normals and an edge-aligned per-face frame."""
         super().__init__()
+        import ctypes
+
+        from nerftex_hip import check, lib
+
         self.tracer = RayTracer(vertices, faces)
-        v = torch.as_tensor(vertices, dtype=torch.float32)
+        v = torch.as_tensor(np.asarray(vertices), dtype=torch.float32)
         f = torch.as_tensor(np.asarray(faces, dtype=np.int64))
         self.register_buffer("mesh_vertices", v.contiguous())
-        self.register_buffer("vertex_normals", vertex_normals(vertices, faces).contiguous())
-        e1, e2 = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
-        t = e1 / (e1.norm(dim=-1, keepdim=True) + 1e-12)
-        n = torch.cross(e1, e2, dim=-1)
-        n = n / (n.norm(dim=-1, keepdim=True) + 1e-12)
-        self.register_buffer("tbn", torch.stack([t, torch.cross(n, t, dim=-1), n], dim=1).contiguous())  # a per-face frame (rows t, b, n)
-        self.h_threshold, self.K, self.depth_threshold = h_threshold, K, 9.5
+        vn = globals()["vertex_normals"](vertices, faces) if vertex_normals is None else torch.as_tensor(np.asarray(vertex_normals), dtype=torch.float32)
+        self.register_buffer("vertex_normals", vn.contiguous())
+        if tbn is None:
+            e1, e2 = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+            t = e1 / (e1.norm(dim=-1, keepdim=True) + 1e-12)
+            n = torch.cross(e1, e2, dim=-1)
+            n = n / (n.norm(dim=-1, keepdim=True) + 1e-12)
+            tbn = torch.stack([t, torch.cross(n, t, dim=-1), n], dim=1)  # a per-face frame (rows t, b, n)
+        self.register_buffer("tbn", torch.as_tensor(np.asarray(tbn), dtype=torch.float32).contiguous())
+        self.h_threshold, self.K, self.depth_threshold = h_threshold, min(K, v.shape[0]), 9.5
+        # the vertex grid of the neighbour search (tools/map.py:396 builds frnn's once, too)
+        self._knn = ctypes.c_void_p()
+        host = np.ascontiguousarray(v.numpy(), dtype=np.float32)
+        check(lib.nerftex_knn_create(host.ctypes.data, host.shape[0], ctypes.byref(self._knn)))
+
+    def __del__(self):
+        h = getattr(self, "_knn", None)
+        if h is not None and h.value:
+            from nerftex_hip import lib
+
+            lib.nerftex_knn_destroy(h)
+            self._knn = None
+
+    @torch.no_grad()
+    def knn(self, xyz, K=None):
+        """(idx [N,K] int32, dis [N,K]) -- the K nearest mesh vertices, ascending, euclidean: what knn() holds after
+        `dis.sqrt()` (tools/map.py:456-458).  Exact (csrc/knn.hip)."""
+        from nerftex_hip import check, lib, ptr, stream
+
+        K = self.K if K is None else min(K, self.mesh_vertices.shape[0])
+        xyz = xyz.float().contiguous()
+        idx = torch.empty(xyz.shape[0], K, dtype=torch.int32, device=xyz.device)
+        dis = torch.empty(xyz.shape[0], K, dtype=torch.float32, device=xyz.device)
+        check(lib.nerftex_knn_query(self._knn, ptr(xyz), xyz.shape[0], K, ptr(idx), ptr(dis), stream()))
+        return idx, dis
 
     def knn_normal(self, xyz, idx, dis, dir_vec_wdist=0.05):
         """knn() with use_dir_vec=True, weighting='Shepard' (tools/map.py:454-501), op for op."""
@@ -96,8 +136,8 @@ class MeshProjector(torch.nn.Module):
         return normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)
 
     @torch.no_grad()
-    def project_reference(self, xyz):
-        idx, dis = knn_bruteforce(xyz, self.mesh_vertices, self.K)
+    def project_reference(self, xyz, neighbours=None):
+        idx, dis = self.knn(xyz) if neighbours is None else neighbours
         normal = self.knn_normal(xyz, idx, dis)
         p1, _, d1, f1 = self.tracer.trace(xyz, normal)
         p2, _, d2, f2 = self.tracer.trace(xyz, -normal)
@@ -111,12 +151,13 @@ class MeshProjector(torch.nn.Module):
     @torch.no_grad()
     def project(self, xyz, multires=12, neighbours=None):
         """-> p_sur [N,3], sdf [N,1], h_mask [N] bool, normal [N,3], tbn [N,3,3], face_idx [N], z_embed [N, 1 + 2 multires].
-        neighbours: (idx [N,K] int32, dis [N,K]) of a neighbour search done elsewhere (the reference: frnn); default = brute force here."""
+        neighbours: (idx [N,K] int32, dis [N,K]) of a neighbour search done elsewhere; default = the library's own (self.knn)."""
         from nerftex_hip import check, lib, ptr, stream
 
         xyz = xyz.float().contiguous()
         N, dev = xyz.shape[0], xyz.device
-        idx, dis = knn_bruteforce(xyz, self.mesh_vertices, self.K) if neighbours is None else neighbours
+        idx, dis = self.knn(xyz) if neighbours is None else neighbours
+        idx, dis = idx.int().contiguous(), dis.float().contiguous()
         p_sur = torch.empty(N, 3, device=dev)
         sdf = torch.empty(N, device=dev)
         mask = torch.empty(N, dtype=torch.uint8, device=dev)
@@ -124,7 +165,7 @@ class MeshProjector(torch.nn.Module):
         face_idx = torch.empty(N, dtype=torch.int64, device=dev)
         tbn = torch.empty(N, 9, device=dev)
         z = torch.empty(N, 1 + 2 * multires, device=dev)
-        check(lib.nerftex_curved_project(self.tracer._handle, ptr(xyz), ptr(idx), ptr(dis), N, self.K, ptr(self.mesh_vertices), ptr(self.vertex_normals), 0.05,
+        check(lib.nerftex_curved_project(self.tracer._handle, ptr(xyz), ptr(idx), ptr(dis), N, idx.shape[1], ptr(self.mesh_vertices), ptr(self.vertex_normals), self.mesh_vertices.shape[0], 0.05,
                                          float(self.h_threshold), ptr(self.tbn), multires, ptr(p_sur), ptr(sdf), ptr(mask), ptr(normal), ptr(face_idx), ptr(tbn),
                                          ptr(z), stream()))
         return p_sur, sdf.unsqueeze(-1), mask.bool(), normal, tbn.view(N, 3, 3), face_idx, z
@@ -145,7 +186,7 @@ class CurvedFieldLookup(torch.nn.Module):
         """Nearest surface point along +-normal (tools/map.py:419-430)."""
         p_pos, _, d_pos, f_pos = self.tracer.trace(x, normals)
         p_neg, _, d_neg, f_neg = self.tracer.trace(x, -normals)
-        use_pos = d_pos <= d_neg
+        use_pos = d_pos < d_neg  # tools/map.py:421: strict, a tie (double miss) takes the -normal record
         p_sur = torch.where(use_pos.unsqueeze(-1), p_pos, p_neg)
         sdf = torch.where(use_pos, -d_pos, d_neg)  # outside the surface (hit along -n) is positive height
         face = torch.where(use_pos, f_pos, f_neg)
@@ -156,3 +197,91 @@ class CurvedFieldLookup(torch.nn.Module):
         h_mask = sdf.abs() < self.h_threshold
         feat = self.encoder(p_sur, bound=self.bound)
         return feat, sdf, face, h_mask
+
+
+class _TruncExp(torch.autograd.Function):  # tools/activation.py:5-17
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+class CurvedField(torch.nn.Module):
+    """The curved-field network with the static light model (see the module docstring), over a MeshProjector.
+
+    forward(x, d) -> (sigma [N], rgb [N,3], {}) and density(x) -> {"sigma", "geo_feat"}: the interface Renderer marches.
+    prob_model: the reference's second table of log-variances (tools/map.py:564-566, 627-630); its noise is drawn with torch.randn
+    unless no_noise."""
+
+    def __init__(self, vertices, faces, bound=1.0, h_threshold=0.05, K=8, num_level=8, hidden_dim=32, geo_feat_dim=15, hidden_dim_color=64,
+                 num_layers=2, num_layers_color=3, dir_degree=4, prob_model=False, vertex_normals=None, tbn=None):
+        super().__init__()
+        from ffmlp import FFMLP
+        from gridencoder import GridEncoder
+        from shencoder import SHEncoder
+
+        self.bound, self.h_threshold, self.geo_feat_dim, self.multires, self.fc_weight = bound, h_threshold, geo_feat_dim, 12, 1.0
+        self.projector = MeshProjector(vertices, faces, h_threshold=h_threshold, K=K, vertex_normals=vertex_normals, tbn=tbn)
+        kw = dict(input_dim=3, num_levels=num_level, level_dim=2, base_resolution=512, log2_hashmap_size=19, desired_resolution=1024, gridtype="hash",
+                  align_corners=True)
+        self.encoder = GridEncoder_clustering(**kw)  # tools/map.py:563
+        self.encoder_var = GridEncoder(**kw) if prob_model else None
+        if prob_model:
+            torch.nn.init.normal_(self.encoder_var.embeddings, std=1e-5)  # reset_parameters(std=1e-5), tools/map.py:566
+        self.in_dim = self.encoder.output_dim + 1 + 2 * self.multires  # 16 + 25
+        self.in_pad = (self.in_dim + 15) // 16 * 16
+        self.sigma_net = FFMLP(input_dim=self.in_pad, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
+        self.encoder_dir = SHEncoder(input_dim=3, degree=dir_degree)
+        self.color_in = self.encoder_dir.output_dim + geo_feat_dim
+        self.color_pad = (self.color_in + 15) // 16 * 16
+        self.color_net = FFMLP(input_dim=self.color_pad, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
+
+    def embed(self, x, no_noise=False):
+        """MeshFeatureField.forward (no import): -> embed [N,41], normal_coarse [N,3], h_mask [N]."""
+        p_sur, sdf, h_mask, normal, _, _, z_embed = self.projector.project(x, multires=self.multires)
+        x_embed = self.encoder(p_sur, bound=self.bound)
+        if self.encoder_var is not None:
+            var = self.encoder_var(p_sur, bound=self.bound)
+            noise = torch.zeros_like(var) if no_noise else torch.randn_like(var)
+            x_embed = x_embed + noise * torch.exp(var)
+        embed = torch.cat([x_embed, z_embed.to(x_embed.dtype)], dim=-1)
+        normal = normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)  # tools/map.py:720
+        return embed, normal, h_mask
+
+    def _sigma(self, embed):
+        ones = torch.ones(embed.shape[0], self.in_pad - self.in_dim, dtype=embed.dtype, device=embed.device)  # tcnn pads its inputs with ones
+        h = self.sigma_net(torch.cat([embed, ones], dim=-1))
+        return _TruncExp.apply(h[..., 0]), h[..., 1:]
+
+    def density(self, x):
+        embed, _, h_mask = self.embed(x)
+        sigma, geo = self._sigma(embed)
+        return {"sigma": torch.where(h_mask, sigma, torch.zeros_like(sigma)), "geo_feat": geo}
+
+    def forward(self, x, d, **kwargs):
+        embed, normal_coarse, h_mask = self.embed(x)
+        sigma, geo = self._sigma(embed)
+        normal = normal_coarse / (normal_coarse.norm(dim=-1, keepdim=True) + 1e-5)  # network_curvedfield.py:283-285 (normal = normal_coarse)
+        if not self.training:  # :289-291 with the coarse normal on both sides
+            normal = self.fc_weight * normal + (1 - self.fc_weight) * normal
+            normal = normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)
+        dn = d / (d.norm(dim=-1, keepdim=True) + 1e-5)
+        wr = 2 * (-dn * normal).sum(-1, keepdim=True) * normal + dn  # the view direction reflected about the normal (:305-306)
+        wr = (wr + 1) / 2  # tcnn's SH takes [0, 1] ...
+        dir_embed = self.encoder_dir(wr * 2 - 1)  # ... and maps it back
+        pad = torch.ones(x.shape[0], self.color_pad - self.color_in, dtype=geo.dtype, device=x.device)
+        h = self.color_net(torch.cat([dir_embed.to(geo.dtype), geo, pad], dim=-1))
+        color = torch.sigmoid(h)
+        return torch.where(h_mask, sigma, torch.zeros_like(sigma)), torch.where(h_mask.unsqueeze(-1), color, torch.zeros_like(color)), {}
+
+    def regular_loss(self):
+        return 1e-8 * self.encoder.clustering_loss()  # tools/map.py:770-774
+
+    def get_params(self, lr):
+        return [{"params": self.parameters(), "lr": lr}]

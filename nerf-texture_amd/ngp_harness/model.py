@@ -223,6 +223,7 @@ class Renderer(nn.Module):
                             tmp_grid[cas, indices] = query(coords, cas)
         else:
             N = H ** 3 // 4
+            self.last_partial_indices = []  # per cascade, the cells this update names (with repeats): tests separate the cells named once
             for cas in range(self.cascade):
                 coords = torch.randint(0, H, (N, 3), device=rdev).to(dev)
                 indices = raymarching.morton3D(coords).long()
@@ -232,6 +233,7 @@ class Renderer(nn.Module):
                     occ = occ[pick]
                     indices = torch.cat([indices, occ], dim=0)
                     coords = torch.cat([coords, raymarching.morton3D_invert(occ)], dim=0)
+                self.last_partial_indices.append(indices)
                 tmp_grid[cas, indices] = query(coords, cas)
         valid = (self.density_grid >= 0) & (tmp_grid >= 0)
         if force_full_grid:

@@ -24,8 +24,13 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                            decoupled_weight_decay=False)
+
+
 class HalfLeafAdam(torch.optim.Optimizer):
     _step_supports_amp_scaling = True
+    _needs_device = True  # the update is a HIP kernel; tests of the host-side / wire logic subclass this with a torch stand-in for _launch
 
     def __init__(self, owners, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
         """owners: [(module, attribute name)] of fp32 parameters, e.g. (encoder, "embeddings"), (sigma_net, "weights"); each module gets
@@ -34,7 +39,7 @@ class HalfLeafAdam(torch.optim.Optimizer):
         self.masters, self.leaves = [], []
         for mod, name in owners:
             master = getattr(mod, name)
-            assert master.is_cuda and master.dtype == torch.float32 and master.is_contiguous()
+            assert (master.is_cuda or not self._needs_device) and master.dtype == torch.float32 and master.is_contiguous()
             leaf = master.detach().to(torch.half).requires_grad_(True)
             mod.half_leaf = leaf
             self.masters.append(master)
@@ -59,13 +64,21 @@ class HalfLeafAdam(torch.optim.Optimizer):
         """torch.optim.Adam's layout (state: {index: {step, exp_avg, exp_avg_sq}}, param_groups), so that a checkpoint written here
         loads into `torch.optim.Adam` over the fp32 parameters and vice versa (nerf/utils.py:1505, 1581-1586)."""
         step = self.step_count.detach().clone()
+        # the full key set of torch.optim.Adam's param_group: Adam.__setstate__ fills in amsgrad / maximize / ... when they are missing but
+        # NOT weight_decay, and its step() reads every one of them
+        group = dict(_ADAM_GROUP_DEFAULTS)
+        group.update({k: v for k, v in self.param_groups[0].items() if k != "params"})
+        group["params"] = list(range(len(self.masters)))
         return {"state": {i: {"step": step.clone(), "exp_avg": self.exp_avg[i].detach().clone(), "exp_avg_sq": self.exp_avg_sq[i].detach().clone()}
                           for i in range(len(self.masters))},
-                "param_groups": [{**{k: v for k, v in self.param_groups[0].items() if k != "params"}, "params": list(range(len(self.masters)))}]}
+                "param_groups": [group]}
 
     @torch.no_grad()
     def load_state_dict(self, sd):
         state = sd["state"]
+        grp = sd["param_groups"][0]
+        if grp.get("weight_decay", 0) or grp.get("amsgrad", False) or grp.get("maximize", False):
+            raise ValueError("HalfLeafAdam implements plain Adam: weight_decay / amsgrad / maximize of the loaded state are not supported")
         if len(state) not in (0, len(self.masters)):
             raise ValueError(f"loaded state has {len(state)} parameters, this optimizer {len(self.masters)}")
         for i in range(len(self.masters)):
@@ -79,8 +92,8 @@ class HalfLeafAdam(torch.optim.Optimizer):
             self.step_count.fill_(float(st["step"]))
         if not state:
             self.step_count.zero_()
-        for k, v in sd["param_groups"][0].items():
-            if k != "params":
+        for k, v in grp.items():
+            if k in ("lr", "betas", "eps", "initial_lr"):
                 self.param_groups[0][k] = v
         self.resync()
 
@@ -155,11 +168,14 @@ class FusedAmp:
     def get_scale(self):
         return float(self.scale.item())
 
+    def _check(self, grads):
+        n = (ctypes.c_uint64 * len(grads))(*[g.numel() for g in grads])
+        check(lib.nerftex_amp_check_half(len(grads), _ptr_array(grads), n, ptr(self.found_inf), stream()))
+
     @torch.no_grad()
     def step(self):
         grads = [leaf.grad for leaf in self.opt.leaves if leaf.grad is not None]
         if grads:
-            n = (ctypes.c_uint64 * len(grads))(*[g.numel() for g in grads])
-            check(lib.nerftex_amp_check_half(len(grads), _ptr_array(grads), n, ptr(self.found_inf), stream()))
+            self._check(grads)
         # Adam (skipped on overflow) and the scale / step-counter update in one launch
         self.opt._launch(1.0, self.scale, self.found_inf, (self.scale, self.growth_tracker, self.found_inf, self.ticket, *self.consts))

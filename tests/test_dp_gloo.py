@@ -102,6 +102,95 @@ def test_two_rank_gloo_matches_single_process(comm_dtype):
     assert torch.allclose(w0, ref, atol=1e-6 if comm_dtype is None else 2e-3), "2-rank DP == single-process training on the global batch"
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The step the benchmark actually runs at N > 1: fp16 LEAVES (HalfLeafAdam) whose fp16 gradients are exchanged in place, fp16 or
+# fp32 on the wire, the loss scaler (FusedAmp) deciding skip / back-off from the EXCHANGED gradients -- so every rank decides alike.
+# The two HIP launches are replaced by torch stand-ins (tests/cpu_half_adam.py); everything around them is the product code.
+class _Owner(torch.nn.Module):
+    def __init__(self, shape, seed):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.weights = torch.nn.Parameter(torch.randn(shape, generator=gen) * 0.3)
+
+
+def _half_leaf_setup(seed_shift):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_half_adam import CpuFusedAmp, CpuHalfLeafAdam
+
+    a, b = _Owner((16, 8), 1 + seed_shift), _Owner((3, 16), 2 + seed_shift)
+    opt = CpuHalfLeafAdam([(a, "weights"), (b, "weights")], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    amp = CpuFusedAmp(opt, init_scale=2.0 ** 14, growth_interval=2)
+    return a, b, opt, amp
+
+
+def _half_leaf_steps(a, b, opt, amp, x, y, n_steps, loss_mul, exchange, poison_step=None, poison=False):
+    for k in range(n_steps):
+        for leaf in opt.leaves:
+            leaf.grad = None
+        h = torch.relu(x @ a.half_leaf.float().t()) @ b.half_leaf.float().t()
+        loss = torch.nn.functional.mse_loss(h, y) * loss_mul
+        amp.scale_loss(loss).backward()
+        assert all(leaf.grad.dtype == torch.float16 for leaf in opt.leaves)
+        if poison and k == poison_step:
+            opt.leaves[0].grad[0, 0] = float("inf")  # ONE rank overflows: after the exchange every rank must see it and skip
+        exchange()
+        amp.step()
+
+
+def _half_leaf_worker(rank, world, port, q, wire):
+    sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ngp_harness import dp
+
+    dp.init_from_env(backend="gloo")
+    a, b, opt, amp = _half_leaf_setup(seed_shift=10 * rank)  # different init per rank: the broadcast must fix it
+    dp.broadcast([a.weights.data, b.weights.data])
+    opt.resync()
+    red = dp.FlatGradAllReduce(opt.trainable(), average=False, big_numel=0, big_comm_dtype=wire)  # bench.py's construction for the fused optimizer
+    assert len(red.big) == 2 and not red.small
+    torch.manual_seed(123)
+    x, y = torch.randn(64, 8), torch.randn(64, 3)
+    lo, hi = dp.shard(64, rank, world)
+    _half_leaf_steps(a, b, opt, amp, x[lo:hi], y[lo:hi], 5, 1.0 / world, red.all_reduce, poison_step=2, poison=rank == 1)
+    q.put((rank, torch.cat([a.weights.detach().reshape(-1), b.weights.detach().reshape(-1)]).numpy().copy(),
+           torch.cat([l.detach().float().reshape(-1) for l in opt.leaves]).numpy().copy(), amp.get_scale(), float(opt.step_count)))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("wire", [torch.float32, None], ids=["fp32-wire", "fp16-wire"])
+def test_two_rank_half_leaf_adam_matches_single_process(wire):
+    world = 2
+    port = 29950 + os.getpid() % 300 + (23 if wire is None else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_half_leaf_worker, args=(r, world, port, q, wire)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, m0, l0, s0, c0), (_, m1, l1, s1, c1) = results
+    assert (m0 == m1).all() and (l0 == l1).all(), "replicas stay bit-identical (masters and fp16 leaves)"
+    assert s0 == s1 and c0 == c1 == 4.0, "one of five steps overflowed on ONE rank: every rank skipped it and backed the scale off alike"
+    # single process on the global batch, same overflow step
+    sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
+    a, b, opt, amp = _half_leaf_setup(seed_shift=0)
+    torch.manual_seed(123)
+    x, y = torch.randn(64, 8), torch.randn(64, 3)
+    _half_leaf_steps(a, b, opt, amp, x, y, 5, 1.0, lambda: None, poison_step=2, poison=True)
+    ref = torch.cat([a.weights.detach().reshape(-1), b.weights.detach().reshape(-1)]).numpy()
+    assert amp.get_scale() == s0 and float(opt.step_count) == 4.0
+    # fp32 wire: the two shard gradients (each rounded to fp16) are summed in fp32 and rounded once -- within 1.5 fp16 ulps of the
+    # single-process gradient, i.e. 2^-10 relative on Adam's normalised step: 4 steps x lr x 2e-3.  fp16 wire: one more rounding.
+    import numpy as np
+
+    bar = 4 * 1e-2 * (2e-3 if wire is not None else 4e-3)
+    assert np.abs(m0 - ref).max() <= bar, (float(np.abs(m0 - ref).max()), bar)
+
+
 def test_shard_covers_batch():
     sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
     from ngp_harness import dp

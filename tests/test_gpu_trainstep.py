@@ -298,3 +298,14 @@ def test_half_leaf_adam_checkpoint_resume_is_bit_identical(dev, knobs):
     ref = torch.optim.Adam([b[0].embeddings, b[1].weights], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
     ref.load_state_dict(saved["optimizer"])
     assert torch.equal(ref.state[b[0].embeddings]["exp_avg"], saved["optimizer"]["state"][0]["exp_avg"])
+    # ... and the reference's optimizer can STEP on it: Adam.step() reads weight_decay / amsgrad / maximize / ... from the loaded param_group
+    # (Adam.__setstate__ fills in every default but weight_decay)
+    assert {"weight_decay", "amsgrad", "maximize", "foreach", "capturable", "differentiable", "fused"} <= set(saved["optimizer"]["param_groups"][0])
+    for p in (b[0].embeddings, b[1].weights):
+        p.grad = torch.zeros_like(p)
+    before = float(ref.state[b[0].embeddings]["step"])
+    ref.step()
+    assert float(ref.state[b[0].embeddings]["step"]) == before + 1
+    bad = {"state": saved["optimizer"]["state"], "param_groups": [dict(saved["optimizer"]["param_groups"][0], weight_decay=1e-2)]}
+    with pytest.raises(ValueError, match="weight_decay"):
+        c[2].load_state_dict(bad)
