@@ -66,6 +66,7 @@ enum Knob {
     kKnobMarchSerial,    // 1: one-ray-per-lane DDA for the counting pass
     kKnobFfmlpWgPerCu,   // forward: workgroups per CU (0 = default)
     kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
+    kKnobMarchInferSerial,  // 1: one-ray-per-lane DDA for march_rays (inference) instead of the data-parallel form
     kKnobCount
 };
 extern long g_knobs[kKnobCount];

@@ -37,6 +37,10 @@ namespace {
 
 constexpr int kMaxK = 16;
 
+// a vertex as the kernel loads it: one 16-byte load (NOT a float4 with the index bit_cast out of lane 3: element-wise bit_casts of an
+// ext_vector come back as element 0 with this compiler, csrc/gridencoder_binned.hip has the same note)
+struct alignas(16) P4 { float x, y, z; int32_t id; };
+
 struct GridDesc {
     int dims[3];
     float lo[3], cell, inv_cell, eps;
@@ -58,7 +62,7 @@ __device__ __forceinline__ void insert_sorted(float (&best)[K], int (&ids)[K], f
 
 template <int K>
 __global__ __launch_bounds__(256) void knn_query_kernel(uint32_t N, const float* __restrict__ xyz, const GridDesc g, const uint32_t* __restrict__ cell_start,
-                                                        const float4_t* __restrict__ points, uint32_t k_out, int32_t* __restrict__ idx,
+                                                        const P4* __restrict__ points, uint32_t k_out, int32_t* __restrict__ idx,
                                                         float* __restrict__ dist) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -82,10 +86,10 @@ __global__ __launch_bounds__(256) void knn_query_kernel(uint32_t N, const float*
             const uint32_t cell = ((uint32_t)z * (uint32_t)g.dims[1] + (uint32_t)y) * (uint32_t)g.dims[0] + (uint32_t)x;
             const uint32_t a = cell_start[cell], b = cell_start[cell + 1];
             for (uint32_t p = a; p < b; p++) {
-                const float4_t v = points[p];
-                const float dx = q[0] - v[0], dy = q[1] - v[1], dz = q[2] - v[2];
+                const P4 v = points[p];
+                const float dx = q[0] - v.x, dy = q[1] - v.y, dz = q[2] - v.z;
                 const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                if (d2 < best[K - 1]) insert_sorted<K>(best, ids, d2, __builtin_bit_cast(int, v[3]));
+                if (d2 < best[K - 1]) insert_sorted<K>(best, ids, d2, v.id);
             }
         };
         // the shell of the block only: whole x rows on its z and y faces, the two end cells of a row elsewhere (faces that fall outside
@@ -170,7 +174,6 @@ extern "C" int nerftex_knn_create(const float* host_points, uint32_t n_points, n
     for (uint32_t v = 0; v < n_points; v++) start[cell_of(host_points + 3 * (size_t)v) + 1]++;
     for (size_t c = 0; c < ncells; c++) start[c + 1] += start[c];
     std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-    struct P4 { float x, y, z; int32_t id; };
     std::vector<P4> sorted(n_points);
     for (uint32_t v = 0; v < n_points; v++) {  // ascending v inside a cell: equal distances come out in index order
         const float* p = host_points + 3 * (size_t)v;
@@ -213,7 +216,7 @@ extern "C" int nerftex_knn_query(const nerftex_knn* kn, const float* xyz, uint32
     g.eps = kn->eps;
     const dim3 grid(div_up(N, 256u)), block(256);
     const uint32_t* cs = static_cast<const uint32_t*>(kn->cell_start);
-    const float4_t* pts = static_cast<const float4_t*>(kn->points);
+    const P4* pts = static_cast<const P4*>(kn->points);
     {
         KernelTimer kt("knn_query_kernel", as_stream(stream));
         if (K <= 4) hipLaunchKernelGGL(knn_query_kernel<4>, grid, block, 0, as_stream(stream), N, xyz, g, cs, pts, K, idx, dist);

@@ -950,6 +950,220 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
     }
 }
 
+// R10, data-parallel form: the count pass's scheme (sequence generation / parallel classification / jump walk, see
+// march_count_parallel_kernel) applied to the inference march.  A call of the serial kernel above takes as long as its slowest ray --
+// a ray that leaves the object walks ~150 empty voxels one dependent DDA iteration (~1200 clocks) at a time, ~100 us whatever else
+// the call does, and every call of a frame has such rays.  Here a workgroup of 32 alive rays generates each ray's parameter sequence
+// from rays_t (3 dependent instructions per member), classifies all members with 32 threads per ray, follows the byte-sized jumps
+// through LDS until n_step samples are marked, and writes the marked members as samples -- position, dt and the distance between
+// consecutive step ends recomputed from the member's parameter with the serial kernel's expressions: the same bits.
+// The first segment is short (`first_seg` members: a ray inside the object needs n_step of them), later ones kMcSeg.
+__global__ __launch_bounds__(kMcThreads) void march_rays_parallel_kernel(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+                                                                        const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                                        const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                                        uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                                        const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                                        float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb,
+                                                                        const int* __restrict__ n_alive_dev, uint32_t first_seg) {
+    constexpr uint32_t kSPitch = kMcSeg + 1;
+    __shared__ float s_T[kMcSeg * kMcTPitch];
+    __shared__ uint8_t s_jump[kMcRays * kMcJPitch];
+    __shared__ uint8_t s_vis[kMcRays * kMcJPitch];
+    __shared__ float s_S[kMcRays * kSPitch];   // the segment's samples of each ray, in order (their parameters)
+    __shared__ float s_carry[kMcRays];         // end of the ray's last sample so far (the call's start parameter before the first)
+    __shared__ uint32_t s_cnt[kMcRays], s_full[kMcRays], s_base[kMcRays], s_nseg[kMcRays];
+    __shared__ uint32_t s_live;
+
+    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
+    if (blockIdx.x * kMcRays >= n_alive) return;  // uniform for the workgroup
+    const uint32_t tid = threadIdx.x;
+    const uint32_t own = tid, n_own = blockIdx.x * kMcRays + own;
+    const bool owner = tid < kMcRays && n_own < n_alive;
+    const uint32_t r2 = tid / kMcSub, sub = tid % kMcSub, n2 = blockIdx.x * kMcRays + r2;
+    const bool has2 = n2 < n_alive;
+    const int index2 = rays_alive[has2 ? n2 : blockIdx.x * kMcRays];
+    const Dda s2(rays_o + 3 * (size_t)index2, rays_d + 3 * (size_t)index2, bound, dt_gamma, max_steps, C, H, grid, fars[index2]);
+    const float dt_min = s2.dt_min, dt_max = s2.dt_max;
+
+    float t_next = 0.0f, far = 0.0f, pending_tt = 0.0f;
+    bool pending = false, done = true;
+    uint32_t num = 0;
+    int index_own = 0;
+    if (owner) {
+        index_own = rays_alive[n_own];
+        far = fars[index_own];
+        t_next = ray_t0(s2, rays_t[n_own], perturb, n_own, (uint64_t)perturb);  // s2.dt_min is all ray_t0 reads
+        s_carry[own] = t_next;
+        done = !(t_next < far) || n_step == 0;
+    }
+    uint32_t seg = first_seg;  // % 4 == 0, <= kMcSeg
+
+    for (;;) {
+        if (tid == 0) s_live = 0;
+        for (uint32_t i = tid; i < kMcRays * kMcJPitch / 4; i += kMcThreads) reinterpret_cast<uint32_t*>(s_vis)[i] = 0u;
+        __syncthreads();
+        // ---- phase 1: the next `seg` members of each ray's sequence
+        if (tid < kMcRays) {
+            uint32_t cnt = 0;
+            if (owner && !done) {
+                float t = t_next;
+                while (cnt < seg) {
+                    const float t0 = t;
+                    const float t1 = t0 + __builtin_amdgcn_fmed3f(t0 * dt_gamma, dt_min, dt_max);
+                    const float t2 = t1 + __builtin_amdgcn_fmed3f(t1 * dt_gamma, dt_min, dt_max);
+                    const float t3 = t2 + __builtin_amdgcn_fmed3f(t2 * dt_gamma, dt_min, dt_max);
+                    s_T[(cnt + 0) * kMcTPitch + own] = t0;
+                    s_T[(cnt + 1) * kMcTPitch + own] = t1;
+                    s_T[(cnt + 2) * kMcTPitch + own] = t2;
+                    s_T[(cnt + 3) * kMcTPitch + own] = t3;
+                    if (!(t3 < far)) {
+                        cnt += (t0 < far ? 1u : 0u) + (t1 < far ? 1u : 0u) + (t2 < far ? 1u : 0u);
+                        t = far;
+                        break;
+                    }
+                    cnt += 4;
+                    t = t3 + __builtin_amdgcn_fmed3f(t3 * dt_gamma, dt_min, dt_max);
+                }
+                t_next = t;
+                atomicOr(&s_live, 1u);
+            }
+            s_cnt[own] = cnt;
+            s_full[own] = (owner && !done && cnt == seg && t_next < far) ? 1u : 0u;
+            s_base[own] = num;
+            s_nseg[own] = 0;
+        }
+        __syncthreads();
+        if (s_live == 0) break;
+
+        // ---- phase 2: classify every member (march_count_parallel_kernel's phase 2)
+        {
+            const uint32_t cnt = s_cnt[r2];
+            Dda::Cell cell[kMcPer];
+            uint8_t occ_byte[kMcPer];
+#pragma unroll
+            for (uint32_t i = 0; i < kMcPer; i++) {
+                const uint32_t k = sub + kMcSub * i;
+                occ_byte[i] = 0;
+                cell[i] = Dda::Cell{};
+                if (k < cnt) {
+                    const uint32_t index = s2.locate(s_T[k * kMcTPitch + r2], cell[i]);
+                    occ_byte[i] = grid[index >> 3];
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kMcPer; i++) {
+                const uint32_t k = sub + kMcSub * i;
+                if (k < cnt) {
+                    uint32_t jump = 0;
+                    if (!((occ_byte[i] >> (cell[i].packed >> 29)) & 1u)) {
+                        const float t = s_T[k * kMcTPitch + r2];
+                        const float tt = s2.exit_of(t, cell[i]);
+                        uint32_t j = k + 1;
+                        for (;;) {
+                            uint32_t c = 0;
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; q++) c += (j + q < cnt && s_T[(j + q) * kMcTPitch + r2] < tt) ? 1u : 0u;
+                            j += c;
+                            if (c < 4) break;
+                        }
+                        jump = j - k;
+                    }
+                    s_jump[r2 * kMcJPitch + k] = (uint8_t)jump;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: follow the jumps until n_step samples are marked
+        if (owner && !done) {
+            const uint32_t cnt = s_cnt[own];
+            const bool full = s_full[own] != 0;
+            const uint8_t* jr = s_jump + own * kMcJPitch;
+            uint8_t* vr = s_vis + own * kMcJPitch;
+            uint32_t k = 0;
+            if (pending) {
+                while (k < cnt && s_T[k * kMcTPitch + own] < pending_tt) k++;
+                pending = k == cnt && full;
+            }
+            uint32_t last_skip = 0xffffffffu;
+            const uint32_t before = num;
+            while (k < cnt && num < n_step) {
+                const uint32_t j = jr[k];
+                const uint32_t sample = j == 0 ? 1u : 0u;
+                vr[k] = (uint8_t)sample;
+                num += sample;
+                last_skip = (j != 0 && k + j == cnt) ? k : last_skip;
+                k += j + sample;
+            }
+            s_nseg[own] = num - before;
+            if (full && last_skip != 0xffffffffu && k == cnt && num < n_step) {
+                Dda::Cell c;
+                const float t = s_T[last_skip * kMcTPitch + own];
+                const Dda so(rays_o + 3 * (size_t)index_own, rays_d + 3 * (size_t)index_own, bound, dt_gamma, max_steps, C, H, grid, far);
+                (void)so.locate(t, c);
+                pending_tt = so.exit_of(t, c);
+                pending = true;
+            }
+            if (!full || num >= n_step) done = true;
+        }
+        __syncthreads();
+
+        // ---- phase 4a: the marked members of each ray, compacted in order
+        {
+            uint32_t mine = 0, flags = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kMcPer; i++) {
+                const uint32_t v = s_vis[r2 * kMcJPitch + sub * kMcPer + i];  // consecutive members per thread
+                flags |= v << i;
+                mine += v;
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < (int)kMcSub; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, kMcSub);
+                if ((int)sub >= off) incl += o;
+            }
+            uint32_t at = incl - mine;
+            if (flags) {
+#pragma unroll
+                for (uint32_t i = 0; i < kMcPer; i++)
+                    if ((flags >> i) & 1u) s_S[r2 * kSPitch + at++] = s_T[(sub * kMcPer + i) * kMcTPitch + r2];
+            }
+        }
+        __syncthreads();
+        // ---- phase 4b: a thread per sample writes it (the serial kernel's expressions on the same parameter)
+        {
+            const uint32_t nseg = has2 ? s_nseg[r2] : 0u;
+            for (uint32_t j = sub; j < nseg; j += kMcSub) {
+                const float t = s_S[r2 * kSPitch + j];
+                float last_t;
+                if (j == 0) {
+                    last_t = s_carry[r2];
+                } else {
+                    const float tp = s_S[r2 * kSPitch + j - 1];
+                    last_t = tp + clampf(tp * dt_gamma, dt_min, dt_max);
+                }
+                const float x = clampf(fmaf(t, s2.dx, s2.ox), -bound, bound);
+                const float y = clampf(fmaf(t, s2.dy, s2.oy), -bound, bound);
+                const float z = clampf(fmaf(t, s2.dz, s2.oz), -bound, bound);
+                const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+                const float end = t + dt;
+                const size_t row = (size_t)n2 * n_step + s_base[r2] + j;
+                xyzs[3 * row] = x; xyzs[3 * row + 1] = y; xyzs[3 * row + 2] = z;
+                dirs[3 * row] = s2.dx; dirs[3 * row + 1] = s2.dy; dirs[3 * row + 2] = s2.dz;
+                deltas[2 * row] = dt;
+                deltas[2 * row + 1] = end - last_t;
+            }
+        }
+        __syncthreads();
+        if (tid < kMcRays && s_nseg[own] > 0) {
+            const float tl = s_S[own * kSPitch + s_nseg[own] - 1];
+            s_carry[own] = tl + clampf(tl * dt_gamma, dt_min, dt_max);
+        }
+        seg = kMcSeg;
+    }
+}
+
 __global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
                                                                 float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                                 const float* __restrict__ rgbs, const float* __restrict__ deltas,
@@ -1223,6 +1437,13 @@ static int march_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, uint32_
                            const uint8_t* grid, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
+    if (H <= 256 && !knob(kKnobMarchInferSerial)) {  // the data-parallel form (8-bit voxel coordinates in its packed cell)
+        const uint32_t first_seg = n_step <= 8 ? 32u : (n_step <= 24 ? 64u : kMcSeg);
+        KernelTimer kt("march_rays_parallel_kernel", as_stream(stream));
+        hipLaunchKernelGGL(march_rays_parallel_kernel, dim3(div_up(n_alive, kMcRays)), dim3(kMcThreads), 0, as_stream(stream), n_alive, n_step, rays_alive,
+                           rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb, n_alive_dev, first_seg);
+        return check_launch("march_rays");
+    }
     {
         KernelTimer kt("march_rays_kernel", as_stream(stream));
         hipLaunchKernelGGL(march_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,

@@ -25,6 +25,18 @@ def t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def offsets_dev(s, dev):
+    """The level table on the device, REGISTERED with the library the way the Python wrapper registers every table it sees (the
+    large-batch backward plans its launch from the host copy; an unregistered table is learnt in the background and the first launches
+    run the slower, looser path: tests/test_gpu_round3.py covers that)."""
+    from nerftex_hip import check, lib, ptr
+
+    off = t(s["offsets"], dev)
+    host = np.ascontiguousarray(s["offsets"], dtype=np.int32)
+    check(lib.nerftex_grid_register_offsets(ptr(off), int(s["L"]), host.ctypes.data))
+    return off
+
+
 # =================================================================================================== gridencoder
 GRID_CASES = [
     # name, D, L, C, base, log2T, per_level_scale, gridtype, align
@@ -59,7 +71,7 @@ def _hip_grid_forward(s, dev, calc_grad, layout):
 
     emb = t(s["emb"], dev)
     x = t(s["x"], dev)
-    off = t(s["offsets"], dev)
+    off = offsets_dev(s, dev)
     B, D, L, C = x.shape[0], s["D"], s["L"], s["C"]
     out = torch.full((L, B, C) if layout == 0 else (B, L * C), 7.0, dtype=emb.dtype, device=dev)
     dyd = torch.full((B, L * D * C), 7.0, dtype=emb.dtype, device=dev) if calc_grad else torch.empty(1, dtype=emb.dtype, device=dev)
@@ -127,7 +139,7 @@ def test_grid_backward(oracle, dev, case, dtype):
     B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
     grad_lbc = (rng.standard_normal((L, B, C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)
     want = oracle.grid_encode_backward(grad_lbc, s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
-    x, off = t(s["x"], dev), t(s["offsets"], dev)
+    x, off = t(s["x"], dev), offsets_dev(s, dev)
     tag = F16 if dtype == np.float16 else F32
     for layout, g in ((0, grad_lbc), (1, np.ascontiguousarray(grad_lbc.transpose(1, 0, 2).reshape(B, L * C)))):
         ge = torch.zeros(s["rows"], C, dtype=torch.float16 if dtype == np.float16 else torch.float32, device=dev)
@@ -157,7 +169,7 @@ def test_grid_backward_large_batch_owner_path(oracle, dev, case, dtype):
     s["x"][5000:15000] = np.clip(np.repeat(s["x"][5000:5100], 100, axis=0) + np.tile(np.linspace(0, 0.02, 100, dtype=np.float32)[:, None], (100, D)), 0, 1)
     grad_lbc = (rng.standard_normal((L, B, C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)
     want = oracle.grid_encode_backward(grad_lbc, s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
-    x, off = t(s["x"], dev), t(s["offsets"], dev)
+    x, off = t(s["x"], dev), offsets_dev(s, dev)
     tag = F16 if dtype == np.float16 else F32
     tdt = torch.float16 if dtype == np.float16 else torch.float32
     for layout, g in ((0, grad_lbc), (1, np.ascontiguousarray(grad_lbc.transpose(1, 0, 2).reshape(B, L * C)))):
@@ -195,7 +207,7 @@ def test_grid_backward_large_batch_fp16_is_tight_per_row(oracle, dev):
     true = oracle.grid_encode_backward(g_lbc.astype(np.float32), s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
     mass = oracle.grid_encode_backward(np.abs(g_lbc).astype(np.float32), s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
     hits = oracle.grid_encode_backward(np.ones_like(g_lbc, dtype=np.float32), s["x"], s["rows"], s["offsets"], s["S"], s["base"], s["gridtype"], s["align"])
-    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    x, off, gt = t(s["x"], dev), offsets_dev(s, dev), t(g, dev)
     ge = torch.zeros(s["rows"], C, dtype=torch.float16, device=dev)
     dummy = torch.zeros(1, dtype=torch.float16, device=dev)
     check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(x), None, ptr(off), ptr(ge), B, D, C, L, s["S"], s["base"], 0, ptr(dummy), ptr(dummy), s["gridtype"],
@@ -220,7 +232,7 @@ def test_grid_backward_large_batch_fp16_is_bit_reproducible(oracle, dev, knobs):
     rng = np.random.default_rng(52)
     B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
     g = (rng.standard_normal((B, L * C)) * 1e-2).astype(np.float16)
-    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    x, off, gt = t(s["x"], dev), offsets_dev(s, dev), t(g, dev)
     dummy = torch.zeros(1, dtype=torch.float16, device=dev)
 
     def run(overwrite):
@@ -254,7 +266,7 @@ def test_grid_backward_run_merge_is_a_regrouping(oracle, dev, knobs):
     B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
     s["x"][9000:29000] = np.clip(np.repeat(s["x"][9000:9200], 100, axis=0) + np.tile(np.linspace(0, 0.03, 100, dtype=np.float32)[:, None], (200, D)), 0, 1)
     g = (rng.standard_normal((B, L * C)) * 1e-2).astype(np.float16)
-    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    x, off, gt = t(s["x"], dev), offsets_dev(s, dev), t(g, dev)
     dummy = torch.zeros(1, dtype=torch.float16, device=dev)
 
     def run():
@@ -288,7 +300,7 @@ def test_grid_backward_overwrites_uninitialised_table(oracle, dev, dtype, path, 
     rng = np.random.default_rng(24)
     B, D, L, C = s["x"].shape[0], s["D"], s["L"], s["C"]
     g = (rng.standard_normal((B, L * C)) * (1e-2 if dtype == np.float16 else 1.0)).astype(dtype)
-    x, off, gt = t(s["x"], dev), t(s["offsets"], dev), t(g, dev)
+    x, off, gt = t(s["x"], dev), offsets_dev(s, dev), t(g, dev)
     tag = F16 if dtype == np.float16 else F32
     tdt = torch.float16 if dtype == np.float16 else torch.float32
     dummy = torch.zeros(1, dtype=tdt, device=dev)
@@ -321,7 +333,7 @@ def test_grid_input_backward_fp32_bit_exact(oracle, dev):
     want = oracle.grid_input_backward(grad, dyd, D)
     ge = torch.zeros(s["rows"], C, device=dev)
     gi = torch.zeros(B, D, device=dev)
-    gt, xt, ot, dt_ = t(grad, dev), t(s["x"], dev), t(s["offsets"], dev), t(dyd, dev)  # keep alive across the launch
+    gt, xt, ot, dt_ = t(grad, dev), t(s["x"], dev), offsets_dev(s, dev), t(dyd, dev)  # keep alive across the launch
     check(lib.nerftex_grid_encode_backward(ptr(gt), ptr(xt), None, ptr(ot), ptr(ge), B, D, C, L,
                                            s["S"], s["base"], 1, ptr(dt_), ptr(gi), s["gridtype"], int(s["align"]), F32, 0, stream()))
     torch.cuda.synchronize()

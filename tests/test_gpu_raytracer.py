@@ -156,4 +156,4 @@ def test_fused_curved_projector_matches_the_reference_op_sequence(dev):
     with pytest.raises(RuntimeError, match="1 <= K"):
         from nerftex_hip import check, lib
 
-        check(lib.nerftex_curved_project(proj.tracer._handle, None, None, None, 4, 99, None, None, 0.05, 0.05, None, 12, None, None, None, None, None, None, None, None))
+        check(lib.nerftex_curved_project(proj.tracer._handle, None, None, None, 4, 99, None, None, 100, 0.05, 0.05, None, 12, None, None, None, None, None, None, None, None))

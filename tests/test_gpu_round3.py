@@ -82,8 +82,17 @@ def test_projector_matches_the_reference_meshprojector_executed(dev):
     proj = _projector(g, dev)
     x = torch.from_numpy(g["xyz"]).to(dev)
     idx, dis = proj.knn(x)
-    assert torch.equal(idx.cpu(), torch.from_numpy(g["knn_idx"])), "the K nearest vertices, ascending"
+    # the K nearest vertices, ascending: the distances must agree everywhere; two neighbours whose distances differ by less than the
+    # float32 rounding of d^2 may come out in either order (the fixture's search ran in float64)
     np.testing.assert_allclose(dis.cpu().numpy(), g["knn_dis"], rtol=1e-5, atol=1e-6)
+    # indices: the UV sphere has 48 coincident vertices at each pole, and the order of EQUAL distances is unspecified in both searches
+    # (torch.topk there, cell order here): compare the neighbours' POSITIONS, and allow a swap where two distances tie to float32 precision
+    v = g["vertices"]
+    same_pos = (v[idx.cpu().numpy()] == v[g["knn_idx"]]).all(-1)
+    gap = np.abs(np.diff(g["knn_dis"], axis=1, append=np.inf))
+    near_tie = np.minimum(gap, np.roll(gap, 1, axis=1)) < 1e-5 * np.maximum(g["knn_dis"], 1e-3)
+    assert (same_pos | near_tie).all() and same_pos.mean() > 0.99, same_pos.mean()
+    assert (idx.cpu().numpy() == g["knn_idx"]).mean() > 0.9  # away from the poles the indices themselves agree
     inner = g["depth_pos"] < g["depth_neg"]
     both_miss = (g["face_pos"] < 0) & (g["face_neg"] < 0)
     assert both_miss.sum() == 0 and 0.3 < inner.mean() < 0.7
@@ -143,7 +152,10 @@ def test_occupancy_partial_update_is_exact_on_singly_drawn_cells(dev):
         r.step_counter[:5, 0] = torch.tensor([700, 720, 690, 710, 705], dtype=torch.int32, device=dev)
         before = r.density_grid.clone()
         r.update_extra_state(cpu_rng=True)
-        if step < 2:
+        if step != 2:
+            # steps 0, 1: full sweeps (test_occupancy_maintenance_matches_reference_python).  Step 3 draws half of its cells from the cells
+            # step 2 left occupied -- including step 2's duplicate-index cells, which may legitimately differ -- so its draw is not the
+            # reference's draw any more; the first partial update is the one with a well-defined answer
             continue
         drawn = torch.stack([torch.bincount(ix.cpu(), minlength=cells) for ix in r.last_partial_indices])  # [cascade, H^3] multiplicities
         once = (drawn.reshape(-1) <= 1)
@@ -159,7 +171,7 @@ def test_occupancy_partial_update_is_exact_on_singly_drawn_cells(dev):
         untouched = (drawn.reshape(-1) == 0) & (before.reshape(-1).cpu() >= 0)
         assert torch.equal(got[untouched], (before.reshape(-1).cpu()[untouched])), "cells the draw did not name keep their value"
         checked += int(sel.sum())
-    assert checked > 8000
+    assert checked > 4000
 
 
 # ------------------------------------------------------------------------------------------------- C ABI of the large-batch backward
@@ -243,7 +255,9 @@ def test_stale_offsets_registration_is_a_deferred_error_not_a_trap(dev, oracle):
 def test_unregistered_table_under_stream_capture_is_invalid(dev, oracle):
     from nerftex_hip import lib
 
-    off_np, rows = oracle.grid_offsets(3, 8, 1.5, 16, 15, False)
+    # L = 5: a (pointer, L) no other test can have left in the library's cache (the allocator recycles addresses, and a recycled address
+    # with the same contents is -- correctly -- a known table)
+    off_np, rows = oracle.grid_offsets(3, 5, 1.5, 16, 15, False)
     off = torch.from_numpy(off_np).to(dev).clone()
     x, grad, out, launch = _grid_call(dev, 40000, off, rows)
     s = torch.cuda.Stream()
