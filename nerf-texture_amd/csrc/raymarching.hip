@@ -75,7 +75,10 @@ struct Pcg32 {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+// fmin(hi, fmax(lo, x)) for lo <= hi as ONE v_med3_f32 (the fmin / fmax pair costs two instructions plus a canonicalising
+// v_max_f32 x, x each; a NaN x comes out as lo either way).  Every caller below guarantees lo <= hi.
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
     // v * 0x00010001 == v | v << 16 for the 10-bit inputs (no carries): shift-or form, one v_lshl_or_b32 per step instead of a
@@ -103,13 +106,14 @@ __device__ __forceinline__ int frexp_exponent(float v) {
     (void)frexpf(v, &e);
     return e;
 }
+// (int)fminf(max_cascade - 1, fmaxf(0, exponent)) of the reference is a clamp of a small integer: done in integers
 __device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max_cascade) {
     const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-    return (int)fminf(max_cascade - 1, fmaxf(0, (float)frexp_exponent(mx)));
+    return clampi(frexp_exponent(mx), 0, (int)max_cascade - 1);
 }
 __device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
     const float mx = (dt * H) * 0.5f;  // the reference halves in double: exact either way
-    return (int)fminf(max_cascade - 1, fmaxf(0, (float)frexp_exponent(mx)));
+    return clampi(frexp_exponent(mx), 0, (int)max_cascade - 1);
 }
 
 // wave64 inclusive scan / reductions with lane shuffles
@@ -134,6 +138,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, rH;
     float bound, dt_gamma, dt_min, dt_max, far;
+    float dt_lo;  // lower clamp of the step: min(dt_min, dt_max) -- with dt_min > dt_max (max_steps < H / 2^(C-1)) the reference's
+                  // fmin(dt_max, fmax(dt_min, x)) is dt_max for every x, which is what clamping to [dt_max, dt_max] gives
     float Cf, Hf, sx, sy, sz, hi, rbound, halfH;
     uint32_t H, H3;
     double Hd;
@@ -149,6 +155,7 @@ struct Dda {
         bound = bound_; dt_gamma = dt_gamma_;
         dt_min = 2 * kSqrt3 / (float)max_steps;
         dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H_;
+        dt_lo = fminf(dt_min, dt_max);
         far = far_;
         Cf = (float)C; Hf = (float)H_; H = H_; H3 = H_ * H_ * H_; Hd = (double)H_;
         hi = (float)(H_ - 1);
@@ -172,7 +179,7 @@ struct Dda {
 
     // the step rule shared by both branches of the reference loop: an accepted sample advances by dt = clamp(t * dt_gamma, ..),
     // a skipped voxel by repeating exactly that until its exit parameter is passed (raymarching.cu:385-401)
-    __device__ __forceinline__ float next_dt(float t) const { return clampf(t * dt_gamma, dt_min, dt_max); }
+    __device__ __forceinline__ float next_dt(float t) const { return clampf(t * dt_gamma, dt_lo, dt_max); }
 
     // probe() in two halves for the data-parallel count pass (same expressions): locate() finds the voxel of parameter t and
     // returns its bit index in the occupancy field, exit_of() computes the parameter at which the ray leaves that voxel.
@@ -184,7 +191,7 @@ struct Dda {
         c.x = clampf(fmaf(t, dx, ox), -bound, bound);
         c.y = clampf(fmaf(t, dy, oy), -bound, bound);
         c.z = clampf(fmaf(t, dz, oz), -bound, bound);
-        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const float dt = clampf(t * dt_gamma, dt_lo, dt_max);
         const int la = mip_from_pos(c.x, c.y, c.z, Cf), lb = mip_from_dt(dt, Hf, Cf);
         const int level = la > lb ? la : lb;
         const float p2 = (float)(1 << level);
@@ -219,7 +226,7 @@ struct Dda {
         x = clampf(fmaf(t, dx, ox), -bound, bound);
         y = clampf(fmaf(t, dy, oy), -bound, bound);
         z = clampf(fmaf(t, dz, oz), -bound, bound);
-        dt = clampf(t * dt_gamma, dt_min, dt_max);
+        dt = clampf(t * dt_gamma, dt_lo, dt_max);
         const int la = mip_from_pos(x, y, z, Cf), lb = mip_from_dt(dt, Hf, Cf);
         const int level = la > lb ? la : lb;
         // The DDA is issue-bound on ONE wave per 64 rays (~230 iterations x ~1200 clocks, measured with s_memtime; occupancy loads,
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
         t_next = ray_t0(s2, nears[n_own], perturb, n_own, 42);  // s2.dt_min is all ray_t0 reads: the same for every ray
         done = !(t_next < far);
     }
-    const float dt_min = s2.dt_min, dt_max = s2.dt_max;
+    const float dt_min = s2.dt_lo, dt_max = s2.dt_max;  // the step's clamp bounds (dt_lo: see Dda)
 
     for (;;) {
         if (tid == 0) s_live = 0;
@@ -707,6 +714,7 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
 
     const float dt_min = 2 * kSqrt3 / (float)max_steps;
     const float dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
+    const float dt_lo = fminf(dt_min, dt_max);  // see Dda::dt_lo
     // the block's kept samples as one flat list: thread i takes list entries i, i + 256, ...; the ray of an entry is found by a
     // 6-step search in the 64 LDS offsets.  Consecutive threads -> consecutive samples -> coalesced stores, all four waves busy
     // whatever the distribution of samples over the rays.
@@ -730,11 +738,11 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
         const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
         const float* log_row = tlog + (size_t)n * max_steps;
         const float t = log_row[k];
-        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const float dt = clampf(t * dt_gamma, dt_lo, dt_max);
         float last_t;
         if (k > 0) {
             const float tp = log_row[k - 1];
-            last_t = tp + clampf(tp * dt_gamma, dt_min, dt_max);
+            last_t = tp + clampf(tp * dt_gamma, dt_lo, dt_max);
         } else {
             last_t = nears[n];
             if (perturb) {
@@ -947,220 +955,6 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
             px += 3; pd += 3; pl += 2;
             step++;
         }
-    }
-}
-
-// R10, data-parallel form: the count pass's scheme (sequence generation / parallel classification / jump walk, see
-// march_count_parallel_kernel) applied to the inference march.  A call of the serial kernel above takes as long as its slowest ray --
-// a ray that leaves the object walks ~150 empty voxels one dependent DDA iteration (~1200 clocks) at a time, ~100 us whatever else
-// the call does, and every call of a frame has such rays.  Here a workgroup of 32 alive rays generates each ray's parameter sequence
-// from rays_t (3 dependent instructions per member), classifies all members with 32 threads per ray, follows the byte-sized jumps
-// through LDS until n_step samples are marked, and writes the marked members as samples -- position, dt and the distance between
-// consecutive step ends recomputed from the member's parameter with the serial kernel's expressions: the same bits.
-// The first segment is short (`first_seg` members: a ray inside the object needs n_step of them), later ones kMcSeg.
-__global__ __launch_bounds__(kMcThreads) void march_rays_parallel_kernel(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
-                                                                        const float* __restrict__ rays_t, const float* __restrict__ rays_o,
-                                                                        const float* __restrict__ rays_d, float bound, float dt_gamma,
-                                                                        uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
-                                                                        const float* __restrict__ fars, float* __restrict__ xyzs,
-                                                                        float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb,
-                                                                        const int* __restrict__ n_alive_dev, uint32_t first_seg) {
-    constexpr uint32_t kSPitch = kMcSeg + 1;
-    __shared__ float s_T[kMcSeg * kMcTPitch];
-    __shared__ uint8_t s_jump[kMcRays * kMcJPitch];
-    __shared__ uint8_t s_vis[kMcRays * kMcJPitch];
-    __shared__ float s_S[kMcRays * kSPitch];   // the segment's samples of each ray, in order (their parameters)
-    __shared__ float s_carry[kMcRays];         // end of the ray's last sample so far (the call's start parameter before the first)
-    __shared__ uint32_t s_cnt[kMcRays], s_full[kMcRays], s_base[kMcRays], s_nseg[kMcRays];
-    __shared__ uint32_t s_live;
-
-    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
-    if (blockIdx.x * kMcRays >= n_alive) return;  // uniform for the workgroup
-    const uint32_t tid = threadIdx.x;
-    const uint32_t own = tid, n_own = blockIdx.x * kMcRays + own;
-    const bool owner = tid < kMcRays && n_own < n_alive;
-    const uint32_t r2 = tid / kMcSub, sub = tid % kMcSub, n2 = blockIdx.x * kMcRays + r2;
-    const bool has2 = n2 < n_alive;
-    const int index2 = rays_alive[has2 ? n2 : blockIdx.x * kMcRays];
-    const Dda s2(rays_o + 3 * (size_t)index2, rays_d + 3 * (size_t)index2, bound, dt_gamma, max_steps, C, H, grid, fars[index2]);
-    const float dt_min = s2.dt_min, dt_max = s2.dt_max;
-
-    float t_next = 0.0f, far = 0.0f, pending_tt = 0.0f;
-    bool pending = false, done = true;
-    uint32_t num = 0;
-    int index_own = 0;
-    if (owner) {
-        index_own = rays_alive[n_own];
-        far = fars[index_own];
-        t_next = ray_t0(s2, rays_t[n_own], perturb, n_own, (uint64_t)perturb);  // s2.dt_min is all ray_t0 reads
-        s_carry[own] = t_next;
-        done = !(t_next < far) || n_step == 0;
-    }
-    uint32_t seg = first_seg;  // % 4 == 0, <= kMcSeg
-
-    for (;;) {
-        if (tid == 0) s_live = 0;
-        for (uint32_t i = tid; i < kMcRays * kMcJPitch / 4; i += kMcThreads) reinterpret_cast<uint32_t*>(s_vis)[i] = 0u;
-        __syncthreads();
-        // ---- phase 1: the next `seg` members of each ray's sequence
-        if (tid < kMcRays) {
-            uint32_t cnt = 0;
-            if (owner && !done) {
-                float t = t_next;
-                while (cnt < seg) {
-                    const float t0 = t;
-                    const float t1 = t0 + __builtin_amdgcn_fmed3f(t0 * dt_gamma, dt_min, dt_max);
-                    const float t2 = t1 + __builtin_amdgcn_fmed3f(t1 * dt_gamma, dt_min, dt_max);
-                    const float t3 = t2 + __builtin_amdgcn_fmed3f(t2 * dt_gamma, dt_min, dt_max);
-                    s_T[(cnt + 0) * kMcTPitch + own] = t0;
-                    s_T[(cnt + 1) * kMcTPitch + own] = t1;
-                    s_T[(cnt + 2) * kMcTPitch + own] = t2;
-                    s_T[(cnt + 3) * kMcTPitch + own] = t3;
-                    if (!(t3 < far)) {
-                        cnt += (t0 < far ? 1u : 0u) + (t1 < far ? 1u : 0u) + (t2 < far ? 1u : 0u);
-                        t = far;
-                        break;
-                    }
-                    cnt += 4;
-                    t = t3 + __builtin_amdgcn_fmed3f(t3 * dt_gamma, dt_min, dt_max);
-                }
-                t_next = t;
-                atomicOr(&s_live, 1u);
-            }
-            s_cnt[own] = cnt;
-            s_full[own] = (owner && !done && cnt == seg && t_next < far) ? 1u : 0u;
-            s_base[own] = num;
-            s_nseg[own] = 0;
-        }
-        __syncthreads();
-        if (s_live == 0) break;
-
-        // ---- phase 2: classify every member (march_count_parallel_kernel's phase 2)
-        {
-            const uint32_t cnt = s_cnt[r2];
-            Dda::Cell cell[kMcPer];
-            uint8_t occ_byte[kMcPer];
-#pragma unroll
-            for (uint32_t i = 0; i < kMcPer; i++) {
-                const uint32_t k = sub + kMcSub * i;
-                occ_byte[i] = 0;
-                cell[i] = Dda::Cell{};
-                if (k < cnt) {
-                    const uint32_t index = s2.locate(s_T[k * kMcTPitch + r2], cell[i]);
-                    occ_byte[i] = grid[index >> 3];
-                }
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < kMcPer; i++) {
-                const uint32_t k = sub + kMcSub * i;
-                if (k < cnt) {
-                    uint32_t jump = 0;
-                    if (!((occ_byte[i] >> (cell[i].packed >> 29)) & 1u)) {
-                        const float t = s_T[k * kMcTPitch + r2];
-                        const float tt = s2.exit_of(t, cell[i]);
-                        uint32_t j = k + 1;
-                        for (;;) {
-                            uint32_t c = 0;
-#pragma unroll
-                            for (uint32_t q = 0; q < 4; q++) c += (j + q < cnt && s_T[(j + q) * kMcTPitch + r2] < tt) ? 1u : 0u;
-                            j += c;
-                            if (c < 4) break;
-                        }
-                        jump = j - k;
-                    }
-                    s_jump[r2 * kMcJPitch + k] = (uint8_t)jump;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 3: follow the jumps until n_step samples are marked
-        if (owner && !done) {
-            const uint32_t cnt = s_cnt[own];
-            const bool full = s_full[own] != 0;
-            const uint8_t* jr = s_jump + own * kMcJPitch;
-            uint8_t* vr = s_vis + own * kMcJPitch;
-            uint32_t k = 0;
-            if (pending) {
-                while (k < cnt && s_T[k * kMcTPitch + own] < pending_tt) k++;
-                pending = k == cnt && full;
-            }
-            uint32_t last_skip = 0xffffffffu;
-            const uint32_t before = num;
-            while (k < cnt && num < n_step) {
-                const uint32_t j = jr[k];
-                const uint32_t sample = j == 0 ? 1u : 0u;
-                vr[k] = (uint8_t)sample;
-                num += sample;
-                last_skip = (j != 0 && k + j == cnt) ? k : last_skip;
-                k += j + sample;
-            }
-            s_nseg[own] = num - before;
-            if (full && last_skip != 0xffffffffu && k == cnt && num < n_step) {
-                Dda::Cell c;
-                const float t = s_T[last_skip * kMcTPitch + own];
-                const Dda so(rays_o + 3 * (size_t)index_own, rays_d + 3 * (size_t)index_own, bound, dt_gamma, max_steps, C, H, grid, far);
-                (void)so.locate(t, c);
-                pending_tt = so.exit_of(t, c);
-                pending = true;
-            }
-            if (!full || num >= n_step) done = true;
-        }
-        __syncthreads();
-
-        // ---- phase 4a: the marked members of each ray, compacted in order
-        {
-            uint32_t mine = 0, flags = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < kMcPer; i++) {
-                const uint32_t v = s_vis[r2 * kMcJPitch + sub * kMcPer + i];  // consecutive members per thread
-                flags |= v << i;
-                mine += v;
-            }
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < (int)kMcSub; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, kMcSub);
-                if ((int)sub >= off) incl += o;
-            }
-            uint32_t at = incl - mine;
-            if (flags) {
-#pragma unroll
-                for (uint32_t i = 0; i < kMcPer; i++)
-                    if ((flags >> i) & 1u) s_S[r2 * kSPitch + at++] = s_T[(sub * kMcPer + i) * kMcTPitch + r2];
-            }
-        }
-        __syncthreads();
-        // ---- phase 4b: a thread per sample writes it (the serial kernel's expressions on the same parameter)
-        {
-            const uint32_t nseg = has2 ? s_nseg[r2] : 0u;
-            for (uint32_t j = sub; j < nseg; j += kMcSub) {
-                const float t = s_S[r2 * kSPitch + j];
-                float last_t;
-                if (j == 0) {
-                    last_t = s_carry[r2];
-                } else {
-                    const float tp = s_S[r2 * kSPitch + j - 1];
-                    last_t = tp + clampf(tp * dt_gamma, dt_min, dt_max);
-                }
-                const float x = clampf(fmaf(t, s2.dx, s2.ox), -bound, bound);
-                const float y = clampf(fmaf(t, s2.dy, s2.oy), -bound, bound);
-                const float z = clampf(fmaf(t, s2.dz, s2.oz), -bound, bound);
-                const float dt = clampf(t * dt_gamma, dt_min, dt_max);
-                const float end = t + dt;
-                const size_t row = (size_t)n2 * n_step + s_base[r2] + j;
-                xyzs[3 * row] = x; xyzs[3 * row + 1] = y; xyzs[3 * row + 2] = z;
-                dirs[3 * row] = s2.dx; dirs[3 * row + 1] = s2.dy; dirs[3 * row + 2] = s2.dz;
-                deltas[2 * row] = dt;
-                deltas[2 * row + 1] = end - last_t;
-            }
-        }
-        __syncthreads();
-        if (tid < kMcRays && s_nseg[own] > 0) {
-            const float tl = s_S[own * kSPitch + s_nseg[own] - 1];
-            s_carry[own] = tl + clampf(tl * dt_gamma, dt_min, dt_max);
-        }
-        seg = kMcSeg;
     }
 }
 
@@ -1437,13 +1231,6 @@ static int march_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, uint32_
                            const uint8_t* grid, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, void* stream) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
-    if (H <= 256 && !knob(kKnobMarchInferSerial)) {  // the data-parallel form (8-bit voxel coordinates in its packed cell)
-        const uint32_t first_seg = n_step <= 8 ? 32u : (n_step <= 24 ? 64u : kMcSeg);
-        KernelTimer kt("march_rays_parallel_kernel", as_stream(stream));
-        hipLaunchKernelGGL(march_rays_parallel_kernel, dim3(div_up(n_alive, kMcRays)), dim3(kMcThreads), 0, as_stream(stream), n_alive, n_step, rays_alive,
-                           rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb, n_alive_dev, first_seg);
-        return check_launch("march_rays");
-    }
     {
         KernelTimer kt("march_rays_kernel", as_stream(stream));
         hipLaunchKernelGGL(march_rays_kernel, ray_grid_for(n_alive), dim3(kRayBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,

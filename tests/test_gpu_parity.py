@@ -491,7 +491,10 @@ def test_utils_bit_exact(oracle, dev, scene_data):
 
 
 @pytest.mark.parametrize("perturb", [False, True], ids=["noperturb", "perturb"])
-@pytest.mark.parametrize("cfg", [dict(bound=2.0, dt_gamma=1 / 128, N=4096), dict(bound=1.0, dt_gamma=0.0, N=1500)], ids=["fox", "bound1"])
+@pytest.mark.parametrize("cfg", [dict(bound=2.0, dt_gamma=1 / 128, N=4096), dict(bound=1.0, dt_gamma=0.0, N=1500),
+                                 # max_steps 32 on a 128-cell grid: dt_min = 2 sqrt3 / 32 > dt_max = 2 sqrt3 / 128 -- the reference's
+                                 # fmin(dt_max, fmax(dt_min, .)) then steps by dt_max whatever t is (the kernels clamp with one v_med3_f32)
+                                 dict(bound=1.0, dt_gamma=1 / 64, N=1500, max_steps=32)], ids=["fox", "bound1", "dt_min_above_dt_max"])
 def test_march_rays_train_bit_exact(oracle, dev, cfg, perturb):
     import raymarching
     from ngp_harness import scene
@@ -503,17 +506,18 @@ def test_march_rays_train_bit_exact(oracle, dev, cfg, perturb):
     b = cfg["bound"]
     aabb = np.array([-b, -b, -b, b, b, b], np.float32)
     wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
-    M = N * 1024
-    wx, wd, wl, wr, wc, wts = oracle.march_rays_train(o, d, b, bits, sc.cascade, 128, wn, wf, M, perturb, cfg["dt_gamma"], 1024, with_ts=True)
+    MS = cfg.get("max_steps", 1024)
+    M = N * MS
+    wx, wd, wl, wr, wc, wts = oracle.march_rays_train(o, d, b, bits, sc.cascade, 128, wn, wf, M, perturb, cfg["dt_gamma"], MS, with_ts=True)
 
     counter = torch.zeros(2, dtype=torch.int32, device=dev)
     xyzs, dirs, deltas, rays = raymarching.march_rays_train(t(o, dev), t(d, dev), b, t(bits, dev), sc.cascade, 128, t(wn, dev), t(wf, dev),
-                                                            counter, -1, perturb, 128, False, cfg["dt_gamma"], 1024)
+                                                            counter, -1, perturb, 128, False, cfg["dt_gamma"], MS)
     torch.cuda.synchronize()
     assert counter.cpu().tolist() == wc.tolist()
     assert np.array_equal(rays.cpu().numpy(), wr), "per-ray (id, offset, num_steps) must be bit-exact"
     m = int(wc[0])
-    assert m > 20 * N // 4
+    assert m > (20 * N // 4 if MS == 1024 else N)
     assert xyzs.shape[0] == m + 128 - m % 128
     for got, want in ((xyzs, wx), (dirs, wd), (deltas, wl)):
         got = got.cpu().numpy()
@@ -527,7 +531,7 @@ def test_march_rays_train_bit_exact(oracle, dev, cfg, perturb):
     x2 = torch.zeros(m + 1, 3, device=dev); d2 = torch.zeros(m + 1, 3, device=dev); l2 = torch.zeros(m + 1, 2, device=dev)
     ts = torch.zeros(m + 1, 1, device=dev); r2 = torch.zeros(N, 3, dtype=torch.int32, device=dev)
     ot, dt_, bt, nt, ft = t(o, dev), t(d, dev), t(bits, dev), t(wn, dev), t(wf, dev)  # keep alive across the launch
-    check(lib.nerftex_march_rays_train_differentiable(ptr(ot), ptr(dt_), ptr(bt), b, cfg["dt_gamma"], 1024, N,
+    check(lib.nerftex_march_rays_train_differentiable(ptr(ot), ptr(dt_), ptr(bt), b, cfg["dt_gamma"], MS, N,
                                                       sc.cascade, 128, m + 1, ptr(nt), ptr(ft), ptr(x2), ptr(d2), ptr(l2),
                                                       ptr(ts), ptr(r2), ptr(counter), int(perturb), stream()))
     torch.cuda.synchronize()

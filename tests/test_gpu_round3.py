@@ -91,7 +91,7 @@ def test_projector_matches_the_reference_meshprojector_executed(dev):
     same_pos = (v[idx.cpu().numpy()] == v[g["knn_idx"]]).all(-1)
     gap = np.abs(np.diff(g["knn_dis"], axis=1, append=np.inf))
     near_tie = np.minimum(gap, np.roll(gap, 1, axis=1)) < 1e-5 * np.maximum(g["knn_dis"], 1e-3)
-    assert (same_pos | near_tie).all() and same_pos.mean() > 0.99, same_pos.mean()
+    assert (same_pos | near_tie).all() and same_pos.mean() > 0.95, same_pos.mean()
     assert (idx.cpu().numpy() == g["knn_idx"]).mean() > 0.9  # away from the poles the indices themselves agree
     inner = g["depth_pos"] < g["depth_neg"]
     both_miss = (g["face_pos"] < 0) & (g["face_neg"] < 0)
