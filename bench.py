@@ -462,22 +462,60 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     return res, field, renderer
 
 
+def measure_accelerated(args, mlp, rays, steps, dev, grid):
+    """A training loop that feeds FRESH rays every step through ngp_harness.accelerate (the one call a trainer adds to the drop-in
+    packages: graph replay + fused field + HalfLeafAdam / FusedAmp, or torch's capturable Adam + GradScaler for nn.Linear MLPs)."""
+    from ngp_harness import scene
+    from ngp_harness.accelerate import accelerate
+    from ngp_harness.model import NGPField, Renderer
+
+    torch.manual_seed(0)
+    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=True).to(dev)
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
+    renderer.set_occupancy(torch.from_numpy(grid).to(dev))
+    n_pool = 8
+    pool = []
+    for k in range(n_pool):
+        o, d = scene.train_batch(rays, seed=100 + k, n_views=4)
+        pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
+    gt = torch.rand(n_pool, rays, 3, generator=torch.Generator().manual_seed(4321)).to(dev)
+    field.train()
+    trainer = accelerate(renderer, dt_gamma=1 / 128)
+    for k in range(16 + 32):  # priming (full-size buffers, mean count), capture, past the first mean_count read-backs
+        trainer.step(*pool[k % n_pool], gt[k % n_pool])
+    torch.cuda.synchronize()
+    samples = torch.zeros((), dtype=torch.int64, device=dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        slot = renderer.local_step
+        trainer.step(*pool[k % n_pool], gt[k % n_pool])
+        samples += renderer.step_counter[slot, 0]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    return {"value": int(samples.item()) / (t1 - t0), "ms_per_step": (t1 - t0) / steps * 1e3, "loss": float(trainer.loss)}
+
+
 def measure_curved(dev, n_points=262144, reps=10):
-    """BASELINE.json configs[3], the curved-field texture lookup on a star_flower-shaped synthetic mesh (~20 k faces, query
-    points within the height threshold of the surface and beyond it): per batch of sample points the projector (normal from the K nearest
-    vertices, two BVH closest-hit traces along +-normal, select, mask, frame, FreqEncoder -- one kernel; the neighbour search is the
-    caller's, as with the reference's frnn) and the curved field's hash lookup (GridEncoder_clustering L = 8, 512 -> 1024, tools/map.py:563)
-    forward + table-gradient backward.  Device time from events; points/s = points / (projector + lookup forward + backward)."""
-    from ngp_harness.curved import CurvedFieldLookup, MeshProjector, knn_bruteforce, star_flower_mesh
+    """BASELINE.json configs[3], the curved-field texture on a star_flower-shaped synthetic mesh (~20 k faces, query points
+    within the height threshold of the surface and beyond it).  Per batch of sample points: the neighbour search (K = 8 nearest mesh
+    vertices, csrc/knn.hip -- the role of the reference's frnn), the projector (normal from those neighbours, two BVH closest-hit traces
+    along +-normal, select, mask, frame, FreqEncoder: one kernel), and the curved field's hash lookup (GridEncoder_clustering L = 8,
+    512 -> 1024, tools/map.py:563) forward + table-gradient backward.  Device time from events; points/s = points / (search + projector +
+    lookup forward + backward).  `field_*`: the whole CurvedField (projector -> table ++ FreqEncoder -> FFMLP 48-32-16 -> reflection SH
+    -> FFMLP 32-64-64-3, masked), forward and forward + backward."""
+    from ngp_harness.curved import CurvedField, star_flower_mesh
 
     v, f = star_flower_mesh()
-    proj = MeshProjector(v, f, h_threshold=0.05).to(dev)
-    look = CurvedFieldLookup(v, f, bound=1.0, h_threshold=0.05).to(dev)
+    torch.manual_seed(0)
+    field = CurvedField(v, f, bound=1.0, h_threshold=0.05).to(dev)
+    proj = field.projector
     g = torch.Generator().manual_seed(7)
     vt = torch.as_tensor(v, dtype=torch.float32)
     base = vt[torch.randint(0, vt.shape[0], (n_points,), generator=g)]
     xyz = (base * (1 + (torch.rand(n_points, 1, generator=g) - 0.5) * 0.12) + (torch.rand(n_points, 3, generator=g) - 0.5) * 0.01).to(dev)
-    neighbours = knn_bruteforce(xyz, proj.mesh_vertices, proj.K)  # outside the timed region: not this library's job
+    dirs = torch.nn.functional.normalize(torch.randn(n_points, 3, generator=g), dim=-1).to(dev)
 
     def timed(fn):
         fn()
@@ -490,23 +528,36 @@ def measure_curved(dev, n_points=262144, reps=10):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3, out
 
+    t_knn, neighbours = timed(lambda: proj.knn(xyz))
     t_proj, out = timed(lambda: proj.project(xyz, neighbours=neighbours))
     p_sur, mask = out[0], out[2]
-    look.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    field.train()
     with torch.autocast("cuda", dtype=torch.float16):
-        t_fwd, feat = timed(lambda: look.encoder(p_sur, bound=1.0))
+        t_fwd, feat = timed(lambda: field.encoder(p_sur, bound=1.0))
         go = torch.randn_like(feat) * 1e-3
 
         def fb():
-            look.encoder.embeddings.grad = None
-            look.encoder(p_sur, bound=1.0).backward(go)
+            field.encoder.embeddings.grad = None
+            field.encoder(p_sur, bound=1.0).backward(go)
         t_fb, _ = timed(fb)
-    total = t_proj + t_fb
-    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces): projector (K-neighbour normal + two BVH traces + "
-                        "select + frame + FreqEncoder, one kernel) + GridEncoder_clustering L=8 hash lookup forward and table-gradient backward, 1 GPU" % len(f),
+        t_field_fwd, (sigma, color, _) = timed(lambda: field(xyz, dirs))
+        gs, gc = torch.randn_like(sigma) * 1e-3, torch.randn_like(color) * 1e-3
+
+        def field_fb():
+            for p in field.parameters():
+                p.grad = None
+            s_, c_, _ = field(xyz, dirs)
+            torch.autograd.backward([s_, c_], [gs, gc])
+        t_field_fb, _ = timed(field_fb)
+    total = t_knn + t_proj + t_fb
+    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces): K = 8 neighbour search (uniform vertex grid, "
+                        "exact) + projector (K-neighbour normal + two BVH traces + select + frame + FreqEncoder, one kernel) + GridEncoder_clustering L=8 hash "
+                        "lookup forward and table-gradient backward, 1 GPU" % len(f),
             "points_per_batch": n_points, "inside_height_threshold": float(mask.float().mean()), "value": n_points / (total * 1e-6), "unit": "sample points/s",
-            "projector_us": t_proj, "lookup_forward_us": t_fwd, "lookup_forward_backward_us": t_fb, "neighbour_search": "outside the timed region (the reference: frnn)",
-            "dtype": "f32 geometry, f16 table under autocast"}
+            "neighbour_search_us": t_knn, "projector_us": t_proj, "lookup_forward_us": t_fwd, "lookup_forward_backward_us": t_fb,
+            "field_forward_us": t_field_fwd, "field_forward_backward_us": t_field_fb, "field_points_per_s_forward_backward": n_points / (t_field_fb * 1e-6),
+            "dtype": "f32 geometry, f16 table and MLPs under autocast"}
 
 
 WORKLOADS = {
@@ -613,6 +664,17 @@ def main():
             other.append({"workload": label if "configs[2]" in label and len(label) > 12 else WORKLOADS[mlp_k], "rays_per_batch": rays_k, "dtype": dt_k,
                           "value": r2["value"], "unit": "ray-samples/s", "ms_per_step": r2["ms_per_step"], "steps": 16,
                           "launch": r2["graph"] if r2["graph"] else "eager launches"})
+        for label, mlp_k, rays_k in (("configs[2] through ngp_harness.accelerate(renderer): a training loop that feeds fresh rays every step; one replayed HIP graph "
+                                      "per step, fused field, HalfLeafAdam + FusedAmp", "ffmlp", 8192),
+                                     ("configs[1] through ngp_harness.accelerate(renderer): nn.Linear MLPs on PyTorch-ROCm, torch's capturable fused Adam + GradScaler "
+                                      "inside one replayed HIP graph per step", "torch", 4096)):
+            try:
+                r3 = measure_accelerated(args, mlp_k, rays_k, 32, dev, grid)
+                other.append({"workload": label, "rays_per_batch": rays_k, "dtype": "fp16", "value": r3["value"], "unit": "ray-samples/s",
+                              "ms_per_step": r3["ms_per_step"], "steps": 32, "launch": "one replayed HIP graph per step (inputs copied into static buffers)",
+                              "loss_after_run": r3["loss"]})
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
+                print(f"[bench] accelerate() measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
         try:
             other.append(measure_curved(dev))
         except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it

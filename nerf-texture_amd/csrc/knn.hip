@@ -11,10 +11,10 @@
 //     each --, counting sort of the vertices by cell, cell_start[] + the sorted vertices as float4 {x, y, z, bits(id)} (16-byte loads,
 //     a cell's vertices contiguous).  A 10 k-vertex mesh: ~160 KiB of vertices + ~100 KiB of cell starts, L2-resident.
 //   * query (device): one thread per point.  The K best so far sit in registers as a sorted list maintained by a fully unrolled
-//     compare-exchange insertion (static indices only: no scratch); ring r = all cells at Chebyshev distance r from the query's
-//     cell (clamped into the grid).  After ring r the unvisited vertices are at least `reach` away -- the distance from the query to the
-//     nearest face of the visited block that still has cells behind it; stop once best[K-1] <= reach.
-//     Sample points sit within a few cell sizes of the surface, so rings 0-2 (27-125 cells, most of them empty) decide nearly all.
+//     compare-exchange insertion (static indices only: no scratch); the block of cells [c - r, c + r]^3 around the query's cell c
+//     (clamped into the grid) grows from r = 1.  After a block the unvisited vertices are at least `reach` away -- the distance from
+//     the query to the nearest face of the block that still has cells behind it; stop once best[K-1] <= reach.
+//     Sample points sit within a few cell sizes of the surface, so the first block (nine contiguous row ranges) decides nearly all.
 #include "common.hpp"
 
 #include <algorithm>
@@ -60,6 +60,26 @@ __device__ __forceinline__ void insert_sorted(float (&best)[K], int (&ids)[K], f
     }
 }
 
+// candidates [a, b) of the cell-sorted vertex array, four loads in flight (the scan is latency-bound: a lane's loads depend on its own
+// cell, and lanes of a wave wait for the longest range among them)
+template <int K>
+__device__ __forceinline__ void scan_range(const P4* __restrict__ points, uint32_t a, uint32_t b, const float (&q)[3], float (&best)[K], int (&ids)[K]) {
+    for (uint32_t p = a; p < b; p += 4) {
+        P4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = points[min(p + i, b - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float dx = q[0] - v[i].x, dy = q[1] - v[i].y, dz = q[2] - v[i].z;
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (p + i < b && d2 < best[K - 1]) insert_sorted<K>(best, ids, d2, v[i].id);
+        }
+    }
+}
+
+// The search grows a block of cells around the query's cell: radius 1 (3 x 3 x 3), then 2, ...  The vertex array is sorted by cell with
+// x fastest, so a ROW of the block (cells x0..x1 at one y, z) is ONE contiguous range: nine ranges for the first block instead of 27
+// cells.  A larger block adds whole rows on its new y / z faces and the two end cells of the rows it already covered.
 template <int K>
 __global__ __launch_bounds__(256) void knn_query_kernel(uint32_t N, const float* __restrict__ xyz, const GridDesc g, const uint32_t* __restrict__ cell_start,
                                                         const P4* __restrict__ points, uint32_t k_out, int32_t* __restrict__ idx,
@@ -78,32 +98,38 @@ __global__ __launch_bounds__(256) void knn_query_kernel(uint32_t N, const float*
 #pragma unroll
     for (int k = 0; k < K; k++) { best[k] = INFINITY; ids[k] = -1; }
     const int rmax = max(g.dims[0], max(g.dims[1], g.dims[2]));
-    for (int r = 0; r <= rmax; r++) {
+    for (int r = 1; r <= rmax; r++) {
         const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dims[0] - 1);
-        const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dims[1] - 1);
-        const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dims[2] - 1);
-        auto visit = [&](int x, int y, int z) {
-            const uint32_t cell = ((uint32_t)z * (uint32_t)g.dims[1] + (uint32_t)y) * (uint32_t)g.dims[0] + (uint32_t)x;
-            const uint32_t a = cell_start[cell], b = cell_start[cell + 1];
-            for (uint32_t p = a; p < b; p++) {
-                const P4 v = points[p];
-                const float dx = q[0] - v.x, dy = q[1] - v.y, dz = q[2] - v.z;
-                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                if (d2 < best[K - 1]) insert_sorted<K>(best, ids, d2, v.id);
+        if (r == 1) {
+            // the first block: the bounds of its nine rows are requested together (one memory latency instead of nine), rows outside the
+            // grid come out empty
+            uint32_t lo9[9], hi9[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int z = c[2] + j / 3 - 1, y = c[1] + j % 3 - 1;
+                const bool in = z >= 0 && z < g.dims[2] && y >= 0 && y < g.dims[1];
+                const uint32_t row = ((uint32_t)(in ? z : 0) * (uint32_t)g.dims[1] + (uint32_t)(in ? y : 0)) * (uint32_t)g.dims[0];
+                lo9[j] = cell_start[row + x0];
+                hi9[j] = in ? cell_start[row + x1 + 1] : lo9[j];
             }
-        };
-        // the shell of the block only: whole x rows on its z and y faces, the two end cells of a row elsewhere (faces that fall outside
-        // the grid do not exist: their rows were inner rows of an earlier ring)
-        for (int z = z0; z <= z1; z++)
-            for (int y = y0; y <= y1; y++) {
-                const bool face = (z == c[2] - r) || (z == c[2] + r) || (y == c[1] - r) || (y == c[1] + r);
-                if (face) {
-                    for (int x = x0; x <= x1; x++) visit(x, y, z);
-                } else {
-                    if (c[0] - r >= 0) visit(c[0] - r, y, z);
-                    if (c[0] + r < g.dims[0]) visit(c[0] + r, y, z);
+#pragma unroll
+            for (int j = 0; j < 9; j++) scan_range<K>(points, lo9[j], hi9[j], q, best, ids);
+        } else {
+            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dims[1] - 1);
+            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dims[2] - 1);
+            for (int z = z0; z <= z1; z++)
+                for (int y = y0; y <= y1; y++) {
+                    const uint32_t row = ((uint32_t)z * (uint32_t)g.dims[1] + (uint32_t)y) * (uint32_t)g.dims[0];
+                    // a row the previous block (radius r - 1) already covered: only its new end cells
+                    const bool old_row = abs(z - c[2]) < r && abs(y - c[1]) < r;
+                    if (!old_row) {
+                        scan_range<K>(points, cell_start[row + x0], cell_start[row + x1 + 1], q, best, ids);
+                    } else {
+                        if (c[0] - r >= 0) scan_range<K>(points, cell_start[row + c[0] - r], cell_start[row + c[0] - r + 1], q, best, ids);
+                        if (c[0] + r < g.dims[0]) scan_range<K>(points, cell_start[row + c[0] + r], cell_start[row + c[0] + r + 1], q, best, ids);
+                    }
                 }
-            }
+        }
         // everything inside the block [c - r, c + r] has been seen; what is left lies behind a face of the block that is not the grid's edge
         float reach = INFINITY;
 #pragma unroll
