@@ -16,8 +16,10 @@ into the graphs; a trainer cannot):
   * `NGPField(fused_glue=True)`: everything behind the hash-grid gather as one kernel forward, the glue folded into the MLP backward;
   * `HalfLeafAdam` + `FusedAmp`: Adam on the fp16 gradients and GradScaler's device side as two launches (FFMLP fields); a field with
     nn.Linear MLPs (BASELINE configs[1]) gets torch's fused capturable Adam + GradScaler inside the same graph;
-  * every 16 steps the ring's mean sample count is read back (the reference does the same in update_extra_state) and, if the count
-    left the captured buffer size, the graphs are re-captured.
+  * sample buffers of a FIXED size, the ring's mean count rounded up to 4096 + 4096 (the reference sizes every step's buffers by the
+    mean itself and silently drops the rays that do not fit, raymarching.cu:419; with the margin none are dropped); every 16 steps the
+    mean is read back (the reference does the same in update_extra_state) and, if it left the size, two eager steps at the new size
+    and a new capture follow.
 The occupancy update stays the caller's (`renderer.update_extra_state_device()` every 16 steps writes grid and bitfield in place: the
 graphs keep reading the same tensors).  Values: the same kernels in the same order as the eager step -- tests/test_gpu_training.py holds
 the replayed step to the eager loss trajectory.
@@ -51,7 +53,7 @@ class AcceleratedTrainer:
             self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype == torch.float16)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
         self._graphs, self._M, self._static = None, 0, None
-        self._primed = 0
+        self._primed, self._warm = 0, 0
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
 
     # ---- one eager step on (ro, rd, tgt); mean_count None = the ring's (full-size buffers while it is unknown)
@@ -76,17 +78,11 @@ class AcceleratedTrainer:
         return counter
 
     def _capture(self):
+        """Record the 16 graphs.  Nothing is executed here: the two eager steps at this buffer size that `step` ran just before (real
+        training steps) have sized the library's workspaces and done every lazy initialisation outside the capture."""
         r = self.renderer
-        self._M = (r.mean_count + 4095) // 4096 * 4096 + 4096
         ro, rd, tgt = self._static
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
         keep_step = r.local_step
-        with torch.cuda.stream(side):  # allocator / library workspaces at this size, outside the capture
-            for g in range(2):
-                r.local_step = g
-                self._body(ro, rd, tgt, mean_count=self._M)
-        torch.cuda.current_stream().wait_stream(side)
         graphs, pool = [], None
         for g in range(RING):  # one graph per ring slot: the step's counter is slot g, as in the eager loop
             r.local_step = g
@@ -110,25 +106,33 @@ class AcceleratedTrainer:
         assert rays_o.shape[0] == self.n_rays, "a captured step has a fixed batch size"
         for dst, src in zip(self._static, (rays_o, rays_d, target)):
             dst.copy_(src, non_blocking=True)
-        if not self.use_graph or self._primed < RING:
-            # the reference's first steps: full-size sample buffers until the ring holds a mean count (its update_extra_state cadence)
-            self._body(*self._static)
+        if not self.use_graph or self._primed < RING or self._warm < 2:
+            # the reference's first steps: full-size sample buffers until the ring holds a mean count (its update_extra_state cadence);
+            # then -- and after every change of the buffer size -- two eager steps at the size the graphs will be recorded with
+            sized = self._primed >= RING  # (graph=False keeps the same buffer-size policy, launched eagerly)
+            self._body(*self._static, mean_count=self._M if sized else None)
             self._primed += 1
+            self._warm += 1 if sized else 0
             if r.local_step == RING:
                 r.update_mean_count()
+                self._resize()
             return self.loss
         if self._graphs is None:
-            if r.mean_count <= 0:
-                r.update_mean_count()
             self._capture()
         g = r.local_step
         self._graphs[g].replay()
         r.local_step = g + 1
         if r.local_step == RING:
             r.update_mean_count()  # one read-back per 16 steps, as in the reference
-            if r.mean_count + 128 > self._M or r.mean_count < 0.8 * self._M:
-                self._capture()  # the sample count left the captured buffer size
+            self._resize()
         return self.loss
+
+    def _resize(self):
+        """After a mean_count read-back: (re)choose the sample-buffer size; a change drops the graphs (two eager steps, then a new capture)."""
+        r = self.renderer
+        if self._M == 0 or r.mean_count + 128 > self._M or r.mean_count < 0.8 * self._M:
+            self._M = (r.mean_count + 4095) // 4096 * 4096 + 4096
+            self._graphs, self._warm = None, 0
 
 
 def accelerate(renderer, **kw):
