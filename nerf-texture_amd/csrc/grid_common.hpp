@@ -63,7 +63,12 @@ inline LevelConsts make_level_consts(uint32_t L, float S, uint32_t H, bool affin
 }
 
 // uniform (per level) description of the index function, gridencoder.cu:54-72
-template <int D>
+// MODE: 0 = every decision at run time (scalar flags; the kernels whose time is memory, not instructions);
+//       1 = hashed level, power-of-two table: rows = xor of the per-axis products, masked;
+//       2 = dense level (every axis in the dense loop), table size not a power of two, index < 2 size: sums, one conditional subtraction.
+// A VALU-bound kernel (the large-batch backward's K3d) asks the run-time object for its mode() once per workgroup -- the level is
+// uniform there -- and runs a body compiled for that mode: no selects between the xor and the sum of every corner, no branches.
+template <int D, int MODE = 0>
 struct IndexFn {
     uint32_t stride[D];  // stride[d] used while the reference loop is still running
     uint32_t ndense;     // number of dimensions the dense loop covers
@@ -93,6 +98,17 @@ struct IndexFn {
         // through the C ABI -- it needs the real modulo as well)
         modulo = s > hashmap_size;
     }
+    template <int M2>
+    __device__ explicit IndexFn(const IndexFn<D, M2>& o) : ndense(o.ndense), hashed(o.hashed), pow2(o.pow2), modulo(o.modulo), size(o.size) {
+#pragma unroll
+        for (int d = 0; d < D; d++) stride[d] = o.stride[d];
+    }
+    // which compiled mode serves this level (see above); 0 = none of the special ones
+    __device__ __forceinline__ int mode() const {
+        if (hashed && pow2) return 1;
+        if (!hashed && !pow2 && !modulo && ndense == (uint32_t)D) return 2;
+        return 0;
+    }
 
     // The same index, factored: every corner coordinate is pg[d] or pg[d] + 1, so the per-dimension terms are computed once (one
     // integer multiply per dimension instead of one per dimension per corner; (p + 1) * k == p * k + k in uint32 arithmetic) and a
@@ -101,16 +117,27 @@ struct IndexFn {
         constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            const uint32_t k = hashed ? primes[d] : ((uint32_t)d < ndense ? stride[d] : 0u);
+            uint32_t k;
+            if constexpr (MODE == 1) k = primes[d];
+            else if constexpr (MODE == 2) k = stride[d];
+            else k = hashed ? primes[d] : ((uint32_t)d < ndense ? stride[d] : 0u);
             t[d][0] = pg[d] * k;
             t[d][1] = t[d][0] + k;
         }
     }
-    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return hashed ? (a ^ b) : (a + b); }
+    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const {
+        if constexpr (MODE == 1) return a ^ b;
+        else if constexpr (MODE == 2) return a + b;
+        else return hashed ? (a ^ b) : (a + b);
+    }
     __device__ __forceinline__ uint32_t wrap(uint32_t index) const {
-        if (pow2) return index & (size - 1);
-        if (modulo) return index % size;
-        return index >= size ? index - size : index;
+        if constexpr (MODE == 1) return index & (size - 1);
+        else if constexpr (MODE == 2) return min(index, index - size);  // index < 2 size: index - size wraps to a huge value unless index >= size
+        else {
+            if (pow2) return index & (size - 1);
+            if (modulo) return index % size;
+            return index >= size ? index - size : index;
+        }
     }
 
     __device__ __forceinline__ uint32_t operator()(const uint32_t (&p)[D]) const {

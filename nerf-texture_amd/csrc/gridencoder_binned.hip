@@ -42,6 +42,7 @@ constexpr uint32_t kTileBytes = 64 * 1024;              // LDS accumulator tile 
 constexpr uint32_t kMaxTilesPerLevel = 128;             // 2^19 rows of an fp16 level
 constexpr uint32_t kSliceRecords = 32 * 1024;           // records per K4 work item
 constexpr uint32_t kSumThreads = 1024;
+constexpr uint32_t kMergeMaxResolution = 0xffffffffu;    // K3d merges same-cell runs on levels up to this resolution (tuned below)
 // A record is ONE x-neighbour pair of corners of a sample on a level (rows a and b = a ^ (2^(k+1) - 1) inside one tile: adjacent
 // rows on dense levels, one aligned block on hashed levels because prime[0] == 1) together with the pair's share of the gradient
 // g' = w_yz * grad and the x fraction p: row a receives (1 - p) g', row b receives p g'.  Or, kcode 15, a single row that receives g'
@@ -132,9 +133,9 @@ __device__ __forceinline__ void merge_step(float (&va)[NP][2], float (&vb)[NP][2
 // Runs of consecutive samples in one cell (coarse levels; samples are ray-ordered) are merged onto the run's first lane before
 // anything is emitted -- inside 16-lane rows, so that the moves are DPP row shifts (a run that crosses a row boundary continues as a
 // second run): the same-row pile-ups of the coarse levels never reach the LDS atomics of K4d.
-template <typename T, int D>
+template <typename T, int D, int MODE>
 __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[D], bool in_batch, const float (&g)[2], float scale,
-                                            bool align_corners, const IndexFn<D>& index_of, bool merge_runs) {
+                                            bool align_corners, const IndexFn<D, MODE>& index_of, bool merge_runs) {
     constexpr int NP = Sample<T, D>::NP;
     constexpr uint32_t kRows = rows_per_tile<T>();
     const int lane = threadIdx.x & (kWave - 1);
@@ -160,6 +161,13 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
     index_of.terms(pg, term);
     float wyz[NP];
     uint32_t unpairable = 0;
+    // hashed level, power-of-two table: row a ^ row b = (term a ^ term b) & (size - 1) whatever the other coordinates contribute --
+    // one pairability test per sample instead of one per pair (K3d is VALU-bound)
+    const bool common_mask = MODE == 1 || (MODE == 0 && index_of.hashed && index_of.pow2);
+    if (common_mask) {
+        const uint32_t m = (term[0][0] ^ term[0][1]) & (index_of.size - 1u);
+        if (m == 0u || (m & (m + 1u)) != 0u || m >= kRows) unpairable = (1u << NP) - 1u;
+    }
 #pragma unroll
     for (int q = 0; q < NP; q++) {  // q enumerates the corner bits of dimensions 1..D-1
         float w = 1;
@@ -173,9 +181,14 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
         wyz[q] = w;
         sm.row_a[q] = index_of.wrap(index_of.combine(term[0][0], yz));
         sm.row_b[q] = index_of.wrap(index_of.combine(term[0][1], yz));
-        const uint32_t m = sm.row_a[q] ^ sm.row_b[q];  // a pair: b = a ^ (2^k - 1) inside one tile
-        if (m == 0u || (m & (m + 1u)) != 0u || m >= kRows) unpairable |= 1u << q;
+        if (!common_mask) {
+            const uint32_t m = sm.row_a[q] ^ sm.row_b[q];  // a pair: b = a ^ (2^k - 1) inside one tile
+            if (m == 0u || (m & (m + 1u)) != 0u || m >= kRows) unpairable |= 1u << q;
+        }
     }
+    // a non-finite gradient (an overflowed loss-scaled backward) must come back as inf on BOTH rows of every pair -- that is what
+    // GradScaler looks for -- and a split of inf between two rows could leave each below the overflow threshold: single-row records
+    if (!(fabsf(g[0]) <= 3.0e38f) || !(fabsf(g[1]) <= 3.0e38f)) unpairable = (1u << NP) - 1u;
 
     // head of a run: the previous lane (same 16-lane row) is not a valid sample of the same cell
     bool same = valid && (lane & 15) != 0 && merge_runs;
@@ -189,15 +202,14 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
     const uint64_t heads = __ballot(!same);
     const bool merging = heads != ~0ull;                                   // some lane of this wave has followers
     const bool splitting = merging || __ballot(sm.live && unpairable) != 0ull;  // wave-uniform: the two rows' sums are needed
-    float va[NP][2], vb[NP][2];
 #pragma unroll
     for (int q = 0; q < NP; q++) {
         sm.ga[q][0] = wyz[q] * g[0];
         sm.ga[q][1] = wyz[q] * g[1];
-        va[q][0] = va[q][1] = vb[q][0] = vb[q][1] = 0.0f;
     }
     sm.split = 0;
-    if (splitting) {
+    if (splitting) {  // (the common wave takes none of this: no row sums, no selects -- sm.gb stays unset and is never read)
+        float va[NP][2], vb[NP][2];
         const float wa0 = 1 - pos[0];
 #pragma unroll
         for (int q = 0; q < NP; q++) {
@@ -217,23 +229,24 @@ __device__ __forceinline__ void make_sample(Sample<T, D>& sm, const float (&xs)[
             merge_step<8, NP>(va, vb, lane & 15, run_end);
         }
         sm.split = merged ? (1u << NP) - 1u : unpairable;
-    }
 #pragma unroll
-    for (int q = 0; q < NP; q++) {
-        const bool sp = (sm.split >> q) & 1u;
-        sm.ga[q][0] = sp ? va[q][0] : sm.ga[q][0];
-        sm.ga[q][1] = sp ? va[q][1] : sm.ga[q][1];
-        sm.gb[q][0] = vb[q][0];
-        sm.gb[q][1] = vb[q][1];
+        for (int q = 0; q < NP; q++) {
+            const bool sp = (sm.split >> q) & 1u;
+            sm.ga[q][0] = sp ? va[q][0] : sm.ga[q][0];
+            sm.ga[q][1] = sp ? va[q][1] : sm.ga[q][1];
+            sm.gb[q][0] = vb[q][0];
+            sm.gb[q][1] = vb[q][1];
+        }
     }
 }
 
+__device__ __forceinline__ uint32_t fraction16(float p) { return min(65535u, (uint32_t)(p * 65536.0f + 0.5f)); }  // x fraction in 2^-16 units
+// p16s: fraction16(p) << 16, computed once per sample (fp16 records)
 template <typename T>
-__device__ __forceinline__ Rec<T> make_record(uint32_t local_row, uint32_t code, float p, const float (&v)[2]) {
+__device__ __forceinline__ Rec<T> make_record(uint32_t local_row, uint32_t code, float p, uint32_t p16s, const float (&v)[2]) {
     Rec<T> r;
     if constexpr (sizeof(T) == 2) {
-        const uint32_t p16 = min(65535u, (uint32_t)(p * 65536.0f + 0.5f));
-        r.word = local_row | (code << row_bits<T>()) | (code == kSingle ? 0u : p16 << 16);
+        r.word = local_row | (code << row_bits<T>()) | (code == kSingle ? 0u : p16s);
         r.g = half2_t{(half_t)v[0], (half_t)v[1]};
     } else {
         r.word = local_row | (code << row_bits<T>());
@@ -250,7 +263,9 @@ __device__ __forceinline__ Rec<T> make_record(uint32_t local_row, uint32_t code,
 // The record buffer is addressed, not packed (capacity 8192 records per region, the worst case of every pair split),
 // which is what 288 GB of HBM is for.
 constexpr uint32_t kStageRecords = 4096 + 256;            // LDS slots per K3d workgroup; rarer overflow goes straight to memory
-constexpr uint32_t kRegionRecords = 2 * 4 * kBinSamples;  // capacity of one (chunk, level) region
+constexpr uint32_t kQuad = 4;                              // a tile's run inside a region is padded to whole quads of records: K4d's unit of work
+constexpr uint32_t kRegionRecords = 2 * 4 * kBinSamples + (kQuad - 1) * kMaxTilesPerLevel + 128;  // capacity of one (chunk, level) region (worst case + padding), a multiple of kQuad
+static_assert(kRegionRecords % kQuad == 0 && kRegionRecords < 65536, "directory words hold 16-bit offsets and counts");
 constexpr uint32_t kDirLdsBytes = (kSumThreads / kWave) * 2 * kWave * 4;  // K4d: per-wave run tables
 
 struct DirTable {
@@ -274,7 +289,7 @@ template <typename T, int D, bool BLC>
 __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                                   const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
                                                                   uint32_t gridtype, bool align_corners, const DirTable tab,
-                                                                  uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, bool merge_runs,
+                                                                  uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, uint32_t merge_res,
                                                                   uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel];
@@ -317,7 +332,14 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     }
     const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
     Sample<T, D> sm;
-    make_sample<T, D>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, merge_runs);
+    // runs are merged on the coarse levels only (resolution <= merge_res): see grid_backward_binned.  The level is uniform for the
+    // workgroup: the record construction runs in the body compiled for the level's kind (IndexFn's MODE)
+    const bool merge_runs = lc.resolution[level] <= merge_res;
+    switch (index_of.mode()) {
+        case 1: make_sample<T, D, 1>(sm, xs, in_batch, g, lc.scale[level], align_corners, IndexFn<D, 1>(index_of), merge_runs); break;
+        case 2: make_sample<T, D, 2>(sm, xs, in_batch, g, lc.scale[level], align_corners, IndexFn<D, 2>(index_of), merge_runs); break;
+        default: make_sample<T, D, 0>(sm, xs, in_batch, g, lc.scale[level], align_corners, index_of, merge_runs);
+    }
     if (probe == 1) {  // ablation: loads + record construction only
         if (sm.ga[0][0] == 1234.5f && sm.row_b[NP - 1] == 77u && sm.gb[0][1] == 3.0f) dir[0] = 1;
         return;
@@ -334,7 +356,10 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     }
     __syncthreads();
     if (threadIdx.x < kWave) {  // wave 0: exclusive prefix over the level's tiles (two per lane) + the directory entries
-        uint32_t cnt[2] = {hist[lane], hist[lane + kWave]};
+        // a tile's run is padded to whole quads (K4d takes four consecutive records per lane: one run search, one 32-byte load); the
+        // pad slots are written below as records that add nothing
+        const uint32_t real[2] = {hist[lane], hist[lane + kWave]};
+        uint32_t cnt[2] = {(real[0] + kQuad - 1) & ~(kQuad - 1), (real[1] + kQuad - 1) & ~(kQuad - 1)};
         uint32_t incl[2] = {cnt[0], cnt[1]};
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
@@ -348,6 +373,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
             const uint32_t t = lane + h * kWave;
             lbase[t] = base[h];
             lcount[t] = 0;
+            hist[t] = real[h] | (cnt[h] << 16);  // (real, padded) for the pad pass
             if (t < ntiles) dir[((size_t)level * kMaxTilesPerLevel + t) * nchunks + chunk] = (base[h] << 16) | cnt[h];  // both < 2^16
         }
         if (lane == kWave - 1) lbase[kMaxTilesPerLevel] = first_half + incl[1];
@@ -356,10 +382,11 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     if (probe == 2) return;  // ablation: + count + scan + directory
 
     // ---- place: LDS for the first kStageRecords slots of the block, the rest straight to the region
+    const uint32_t p16s = fraction16(sm.p) << 16;
     auto place = [&](uint32_t row, uint32_t code, const float (&v)[2]) {
         const uint32_t t = row / kRows;
         const uint32_t at = lbase[t] + atomicAdd(&lcount[t], 1u);
-        const Rec<T> r = make_record<T>(row - t * kRows, code, sm.p, v);
+        const Rec<T> r = make_record<T>(row - t * kRows, code, sm.p, p16s, v);
         if (at < kStageRecords) stage[at] = __builtin_bit_cast(Bits, r);
         else region[at] = r;
     };
@@ -370,6 +397,15 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
             const bool sp = (sm.split >> q) & 1u;
             place(sm.row_a[q], sp ? kSingle : 30u - (uint32_t)__builtin_clz(m + 1u), sm.ga[q]);  // m = 2^(k+1) - 1 -> code k
             if (sp) place(sm.row_b[q], kSingle, sm.gb[q]);
+        }
+    }
+    if (threadIdx.x < kMaxTilesPerLevel) {  // the pad slots of each tile's run: single-row records with a zero gradient
+        const uint32_t real = hist[threadIdx.x] & 0xffffu, padded = hist[threadIdx.x] >> 16;
+        const float zero2[2] = {0.0f, 0.0f};
+        const Rec<T> r = make_record<T>(0u, kSingle, 0.0f, 0u, zero2);
+        for (uint32_t at = lbase[threadIdx.x] + real; at < lbase[threadIdx.x] + padded; at++) {
+            if (at < kStageRecords) stage[at] = __builtin_bit_cast(Bits, r);
+            else region[at] = r;
         }
     }
     __syncthreads();
@@ -387,8 +423,10 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
 }
 
 // K4d: one record into the tile's accumulators.  fp16: value * 2^24 in 64-bit integers -- every half is an integer multiple of
-// 2^-24 below 2^16 -- split between the pair's rows as fixed(g') * p16 / 2^16 and the exact remainder, so the two shares always add
-// up to g'; ds_add_u64 sums are exact and order-independent.  fp32: float LDS atomics.
+// 2^-24 below 2^16 -- split between the pair's rows as fixed(g') * p16 / 2^16 (rounded to nearest) and the exact remainder, so the two
+// shares always add up to g'; ds_add_u64 sums are exact and order-independent.  fp32: float LDS atomics.
+// The split without a 64-bit multiply: fixed(g') = ms << s with the half's signed significand ms (12 bits) and s = max(exponent - 1, 0),
+// so fixed(g') p16 = (ms p16) << s with ms p16 one full-rate 24-bit multiply.
 template <typename T>
 __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
     constexpr uint32_t kBits = row_bits<T>();
@@ -396,21 +434,28 @@ __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
     const uint32_t rb = ra ^ ((2u << code) - 1u);
     if constexpr (sizeof(T) == 2) {
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
-        // sign-magnitude all the way: magnitude * 2^24 (< 2^41), the pair's split on magnitudes, the sign applied once per addend
+        // two's complement from the start: the half's signed 12-bit significand ms, fixed(g') = ms << sh (a 64-bit shift of the
+        // sign-extended word), the share of row b = ((ms p16) << sh + 2^15) >> 16 with ms p16 one signed 24-bit multiply (< 2^27, so
+        // the shifted product stays below 2^57) and an arithmetic shift: rounded to nearest, ties up.  A single-row record carries
+        // p16 = 0: its share of row b is 0 and row a's remainder is all of fixed(g') -- no select.  K3d never emits a PAIR for a
+        // non-finite gradient (both rows must come back as inf for GradScaler: two single-row records do that), so no special case
+        // here either.  (The first version worked on magnitudes, multiplied in 64 bits and applied the sign to each addend: ~85
+        // instructions per record against ~50; the kernel is VALU-bound.)
         const uint32_t gbits = __builtin_bit_cast(uint32_t, r.g);  // (element-wise bit_casts of r.g[1] came back as element 0 with this compiler)
         const uint32_t h[2] = {gbits & 0xffffu, gbits >> 16};
-        const uint32_t p16 = r.word >> 16;
+        const int p16 = (int)(r.word >> 16);
         const bool single = code == kSingle;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const uint32_t e = (h[c] >> 10) & 31u;
-            const unsigned long long mag = (unsigned long long)((h[c] & 1023u) | (e ? 1024u : 0u)) << (e ? e - 1u : 0u);
-            unsigned long long b = (mag * p16 + 32768ull) >> 16;  // row b's share, rounded to nearest; row a gets the exact remainder
-            unsigned long long a = mag - b;
-            if (e == 31u) a = b = mag;  // inf / nan (>= 2^40): both rows come back as inf, which is what GradScaler needs to see
-            const unsigned long long s = (h[c] & 0x8000u) ? ~0ull : 0ull;
-            atomicAdd(acc64 + (size_t)ra * 2 + c, ((single ? mag : a) ^ s) - s);
-            if (!single) atomicAdd(acc64 + (size_t)rb * 2 + c, (b ^ s) - s);
+            const int m = (int)((h[c] & 1023u) + (min(e, 1u) << 10));  // the implicit bit of a normal number
+            const uint32_t sh = max(e, 1u) - 1u;
+            const int sgn = -(int)(h[c] >> 15);          // 0 or -1
+            const int ms = (m ^ sgn) - sgn;
+            const long long fixed = (long long)ms << sh;  // value * 2^24, exact
+            const long long bshare = ((((long long)__mul24(ms, p16)) << sh) + 32768ll) >> 16;
+            atomicAdd(acc64 + (size_t)ra * 2 + c, (unsigned long long)(fixed - bshare));
+            if (!single) atomicAdd(acc64 + (size_t)rb * 2 + c, (unsigned long long)bshare);
         }
     } else {
         float* acc32 = reinterpret_cast<float*>(smem);
@@ -425,6 +470,11 @@ __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
             atomicAdd(acc32 + (size_t)rb * 2 + 1, r.p * r.g1);
         }
     }
+}
+template <typename T>
+__device__ __forceinline__ bool adds_nothing(const Rec<T>& r) {  // a pad record (or a real one whose gradient is +0)
+    if constexpr (sizeof(T) == 2) return __builtin_bit_cast(uint32_t, r.g) == 0u;
+    else return r.g0 == 0.0f && r.g1 == 0.0f;
 }
 
 // which (tile, chunk range) a K4d workgroup owns
@@ -489,15 +539,17 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
 }
 
 // K4d: a wave takes 64 runs at a time (chunks c_lo + wave + 16 k): their lengths are prefix-summed into a per-wave LDS table and
-// the wave walks the concatenation as ONE flat list -- every lane busy, loads independent -- finding the run of an element with a
-// 6-step search in that table.  (Measured alternatives: a wave per run leaves half the lanes idle, 159 us against 95; a lane per
+// the wave walks the concatenation as ONE flat list of QUADS (four consecutive records; K3d pads every run to whole quads) -- every
+// lane busy, loads independent -- finding the run of a quad with a 6-step search in that table: the search, ~25 of the ~108
+// instructions a record used to cost (the kernel is VALU-bound: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = its duration), is paid
+// once per four records.  (Measured alternatives: a wave per run leaves half the lanes idle, 159 us against 95; a lane per
 // run makes every load divergent, 410; one run table for the whole workgroup with 4-16 loads in flight per lane puts two
 // barriers in front of every pass: 137-161.)
 template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
                                                                    const bool overwrite, unsigned long long* __restrict__ partials,
-                                                                   const int* __restrict__ offsets) {
+                                                                   const int* __restrict__ offsets, const uint32_t probe) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SumItem it;
     if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it)) return;
@@ -508,12 +560,13 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
     __syncthreads();
 
     const uint32_t* drow = dir + ((size_t)it.level * kMaxTilesPerLevel + it.t) * nchunks;
-    uint32_t* s_excl = reinterpret_cast<uint32_t*>(smem + kTileBytes) + wave * 2 * kWave;  // [64] exclusive prefix, then [64] record index
+    uint32_t* s_excl = reinterpret_cast<uint32_t*>(smem + kTileBytes) + wave * 2 * kWave;  // [64] exclusive prefix (in quads), then [64] first record
     uint32_t* s_base = s_excl + kWave;
+    struct alignas(sizeof(Rec<T>) * kQuad) Quad { Rec<T> r[kQuad]; };
     for (uint32_t cb = it.c_lo + wave; cb < it.c_hi; cb += kWaves * kWave) {
         const uint32_t c = cb + lane * kWaves;
         const uint32_t entry = c < it.c_hi ? drow[c] : 0u;
-        const uint32_t cnt = entry & 0xffffu;
+        const uint32_t cnt = (entry & 0xffffu) / kQuad;  // runs are padded to whole quads (K3d)
         uint32_t incl = cnt;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
@@ -523,19 +576,33 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
         const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
         s_excl[lane] = incl - cnt;
         s_base[lane] = (uint32_t)(((size_t)it.level * nchunks + (c < it.c_hi ? c : it.c_lo)) * kRegionRecords) + (entry >> 16);  // < 2^32 records
-        for (uint32_t i = lane; i < total; i += 2 * kWave) {
-            uint32_t k0 = 0, k1 = 0;
-            const uint32_t i1 = i + kWave;
+        // the 64 runs as ONE flat list of quads: a lane takes quad i -- one 6-step search for its run, one load of four consecutive
+        // records (32 bytes fp16), four accumulations; pad records are skipped
+        for (uint32_t i = lane; i < total; i += kWave) {
+            uint32_t k = 0;
 #pragma unroll
-            for (uint32_t step = kWave / 2; step > 0; step >>= 1) {
-                if (s_excl[k0 + step] <= i) k0 += step;
-                if (s_excl[k1 + step] <= i1) k1 += step;
+            for (uint32_t step = kWave / 2; step > 0; step >>= 1)
+                if (s_excl[k + step] <= i) k += step;
+            Quad q;
+            if (probe == 11) {  // ablation: no record loads (synthetic records from the indices: the arithmetic and the atomics stay)
+#pragma unroll
+                for (uint32_t j = 0; j < kQuad; j++) {
+                    const float v2[2] = {(float)(i & 255u) * 1e-3f + 1e-3f, (float)(k + 1u) * 1e-3f};
+                    q.r[j] = make_record<T>((i * 4u + j * 977u + k * 131u) & (rows_per_tile<T>() - 1u), kSingle, 0.0f, 0u, v2);
+                }
+            } else {
+                q = *reinterpret_cast<const Quad*>(records + (size_t)s_base[k] + (size_t)(i - s_excl[k]) * kQuad);
             }
-            const bool l1 = i1 < total;
-            const Rec<T> r0 = records[(size_t)s_base[k0] + (i - s_excl[k0])];
-            const Rec<T> r1 = records[(size_t)s_base[l1 ? k1 : k0] + (l1 ? i1 - s_excl[k1] : i - s_excl[k0])];
-            add_record<T>(smem, r0);
-            if (l1) add_record<T>(smem, r1);
+            if (probe == 10) {  // ablation: no accumulation (the loads stay: their values decide a store that never happens)
+                uint32_t any = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kQuad; j++) any |= q.r[j].word;
+                if (any == 0xdeadbeefu) reinterpret_cast<uint32_t*>(smem)[lane] = any;
+                continue;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kQuad; j++)
+                if (!adds_nothing<T>(q.r[j])) add_record<T>(smem, q.r[j]);
         }
     }
     __syncthreads();
@@ -733,7 +800,12 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
     unsigned long long* partials = reinterpret_cast<unsigned long long*>(dbase + dir_bytes);
     Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes + part_bytes);
-    const bool merge = !knob(kKnobGridBwdNoMerge);
+    // Merging runs of consecutive samples that share a cell costs the whole WAVE ~200 VALU instructions as soon as one lane has a
+    // follower, and K3d is VALU-bound (475 instructions per wave on average, SQ_INSTS_VALU); it pays where runs are long and rows are
+    // hot -- the coarse levels, whose same-row pile-ups would otherwise serialise in K4d's LDS atomics -- and costs more than the few
+    // records it saves on the fine ones.  grid_bwd_nomerge: 0 = merge levels up to the default resolution, 1 = never, n > 1 = up to n.
+    const long mk = knob(kKnobGridBwdNoMerge);
+    const uint32_t merge = mk == 1 ? 0u : (mk > 1 ? (uint32_t)mk : kMergeMaxResolution);
     const uint32_t probe = (uint32_t)knob(kKnobGridBwdProbe);
     {
         auto fill = blc ? bin_fill_dir_kernel<T, D, true> : bin_fill_dir_kernel<T, D, false>;
@@ -748,7 +820,7 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         auto kernel = sum_tiles_dir_kernel<T>;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
         KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials, offsets_dev);
+        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials, offsets_dev, probe);
     }
     if ((rc = check_launch("grid_encode_backward(sum)")) != NERFTEX_OK) return rc;
     if constexpr (sizeof(T) == 2) {
