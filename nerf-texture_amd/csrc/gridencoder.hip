@@ -171,7 +171,12 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
                                                                  const uint32_t gridtype, const bool align_corners, const uint32_t nchunks) {
     const uint32_t xcd = blockIdx.x % kXcds;
     const uint32_t q = blockIdx.x / kXcds;
-    const uint32_t level = (q / nchunks) * kXcds + xcd;
+    // which level this XCD walks in round r = q / nchunks: rounds alternate direction (x, then 15 - x for 16 levels).  A level's cost
+    // grows with its resolution -- measured alone on one XCD, the 16 levels of the fox table take 20 us (dense, L1-resident) to 67 us
+    // (2^19 hashed rows) for 456 k samples (tools/g1_levels.py) -- and the launch ends with its slowest XCD: with levels (x, x + 8)
+    // XCD 7 carried 110 of the 706 us, with (x, 15 - x) the heaviest pair is 93.
+    const uint32_t round = q / nchunks;
+    const uint32_t level = round * kXcds + ((round & 1u) ? kXcds - 1u - xcd : xcd);
     if (level >= L) return;
     const uint32_t b = (q % nchunks) * blockDim.x + threadIdx.x;
     if (b >= B) return;
