@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-fused-opt", action="store_true", help="torch.optim.Adam(fused=True) on an fp32 table instead of ngp_harness.optim.TableAdam")
     ap.add_argument("--no-fused-amp", action="store_true", help="torch.amp.GradScaler instead of ngp_harness.optim.FusedAmp")
     ap.add_argument("--graph-split", action="store_true", help="1 GPU: use the two-graph form of the multi-GPU path (for testing it)")
+    ap.add_argument("--graph-allreduce", action="store_true", help="N > 1: capture the gradient all-reduce INSIDE the step's graph (march | shade + backward + "
+                    "all-reduce + optimizer) instead of launching it eagerly between two graphs; falls back to the default structure if the "
+                    "backend cannot be captured.  Also NERFTEX_BENCH_GRAPH_ALLREDUCE=1.  Untested on RCCL from the 1-GPU boxes this was written on")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a captured HIP graph (1 GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel hipEvent pairs in the timed region (no roofline)")
     ap.add_argument("--dtype", choices=["fp16", "bf16", "fp32"], default="fp16", help="fp16 = autocast like the reference's --fp16/-O; bf16 = "
@@ -199,6 +202,15 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # is two graphs (forward + backward | optimizer) with the gradient all-reduce launched eagerly between them.
     use_graph = graph
     split_graph = use_graph and (world > 1 or args.graph_split)
+    # opt-in A/B for the 8-GPU node: the all-reduce as nodes of the step's graph (one graph per step, nothing launched from the host between
+    # backward and optimizer).  `capture` falls back to the split structure when the backend refuses to be captured.
+    ar_state = {"in_graph": bool(split_graph and world > 1 and (args.graph_allreduce or os.environ.get("NERFTEX_BENCH_GRAPH_ALLREDUCE") == "1"))}
+    if ar_state["in_graph"]:
+        import torch.distributed as dist
+
+        if dist.get_backend() != "nccl":  # gloo moves device tensors through the host with stream synchronisations (and aborts the process in a capture)
+            print(f"[bench] --graph-allreduce needs the nccl (RCCL) backend, not {dist.get_backend()}: using the split structure", file=sys.stderr)
+            ar_state["in_graph"] = False
     # 1 GPU: the march of step k+1 needs nothing from step k (rays and the occupancy grid, not the weights): it is its own graph, replayed
     # on a second stream while step k shades, goes backward and updates -- latency-bound work on otherwise idle issue slots
     march_ahead = use_graph and not split_graph and not args.no_march_ahead
@@ -319,6 +331,19 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 marches[g] = (gm, out)  # the sample tensors stay alive: graph A of the slot reads them
         for g in range(RING):  # one graph per ring slot: static ray batch, static counter slot -> nothing to select or copy per step
             ga = torch.cuda.CUDAGraph()
+            if ar_state["in_graph"]:
+                try:
+                    with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
+                        body_fb(g, marches[g][1])
+                        reducer.all_reduce()
+                        body_opt()
+                    mem = ga.pool()
+                    graphs.append((marches[g][0], ga, "in_graph", None))
+                    continue
+                except Exception as e:  # noqa: BLE001 -- this backend's collectives cannot be captured: the default structure
+                    print(f"[bench] all-reduce inside the graph failed ({type(e).__name__}: {e}); using the split structure", file=sys.stderr)
+                    ar_state["in_graph"] = False
+                    ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
                 body_fb(g, marches[g][1] if (split_graph or march_ahead) else None)
                 if not split_graph:
@@ -357,6 +382,13 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             ga.replay()
         elif gb is None:
             ga.replay()
+        elif gb == "in_graph":  # march(g) | shade + backward + all-reduce + optimizer(g); the next march is replayed behind it
+            if gstate["marched"] != g:
+                gm.replay()
+            ga.replay()
+            if g + 1 < RING:
+                gstate["graphs"][g + 1][0].replay()
+                gstate["marched"] = g + 1
         else:  # march(g) | shade + backward(g) | all-reduce(g) overlapped with march(g + 1) | optimizer(g)
             if gstate["marched"] != g:
                 gm.replay()
@@ -442,7 +474,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         collective = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""), "world_size": dist.get_world_size(),
                       "wire_dtype": str(wire_dtype).replace("torch.", "") if wire_dtype is not None else "the gradient's dtype",
                       "bytes_per_step": int(sum(g.numel() * (torch.finfo(wire_dtype).bits // 8 if wire_dtype else g.element_size()) for g in grads if g is not None)),
-                      "allreduce_us_per_step": ev0.elapsed_time(ev1) * 100.0}
+                      "allreduce_us_per_step": ev0.elapsed_time(ev1) * 100.0,
+                      "allreduce_in_graph": bool(use_graph and ar_state["in_graph"])}
     param_l1 = float(sum(p.detach().double().abs().sum() for p in field.parameters()))
     replicas_identical = None
     if world > 1:  # data parallelism keeps full replicas: after the run every rank must hold the same bits (cheap: one checksum vector)

@@ -183,6 +183,22 @@ int nerftex_march_rays_train(const float* rays_o, const float* rays_d, const uin
                              uint32_t C, uint32_t H, uint32_t M, const float* nears,
                              const float* fars, float* xyzs, float* dirs, float* deltas,
                              int32_t* rays, int32_t* counter, uint32_t perturb, void* stream);
+/* EXTENSION (no reference counterpart): the training march as the trainer calls
+ * it every step -- near_far_from_aabb (raymarching.py:22-51), counter.zero_()
+ * (nerf/renderer.py:366-368), three zero-filled sample buffers
+ * (raymarching.py:184-186), march_rays_train -- as ONE call of two launches:
+ * near / far are computed inside the counting pass (same arithmetic) and STORED
+ * to nears / fars [N]; the counter is taken as zero and overwritten
+ * (counter[0] = total points, counter[1] = N); xyzs | dirs | deltas may arrive
+ * uninitialised (they must be consecutive parts of ONE buffer of 8 M floats):
+ * the rows no ray writes are zeroed by the second launch.  Same samples, ray
+ * records and counter as the four-step sequence, bit for bit.                 */
+int nerftex_march_rays_train_fresh(const float* rays_o, const float* rays_d, const uint8_t* grid,
+                                   float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                                   uint32_t C, uint32_t H, uint32_t M, const float* aabb,
+                                   float min_near, float* nears, float* fars, float* xyzs,
+                                   float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                   uint32_t perturb, void* stream);
 /* raymarching.cu:671-678 (kernel :506-669): as above + rays_ts [M] = t after
  * each emitted step.                                                         */
 int nerftex_march_rays_train_differentiable(const float* rays_o, const float* rays_d,

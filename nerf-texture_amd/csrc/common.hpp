@@ -66,7 +66,6 @@ enum Knob {
     kKnobMarchSerial,    // 1: one-ray-per-lane DDA for the counting pass
     kKnobFfmlpWgPerCu,   // forward: workgroups per CU (0 = default)
     kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
-    kKnobMarchInferSerial,  // 1: march_rays (inference) one ray per lane to the end, no regrouping of the stragglers (A/B switch)
     kKnobCount
 };
 extern long g_knobs[kKnobCount];

@@ -265,28 +265,37 @@ struct Dda {
 // ------------------------------------------------------------------------------------------------
 // R1 .. R5
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void near_far_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                          const float* __restrict__ aabb, uint32_t N, float min_near,
-                                                          float* __restrict__ nears, float* __restrict__ fars) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
-    const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
+// near / far of ray n against the box (raymarching.cu:95-145): shared by the kernel below and by the march that computes them itself
+__device__ __forceinline__ void near_far_of(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ aabb,
+                                            float min_near, size_t n, float& near_out, float& far_out) {
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
     constexpr float kMax = 3.402823466e+38f;
     float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
     if (near > far) { tmp = near; near = far; far = tmp; }
     float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
     if (near_y > far_y) { tmp = near_y; near_y = far_y; far_y = tmp; }
-    if (near > far_y || near_y > far) { nears[n] = fars[n] = kMax; return; }
+    if (near > far_y || near_y > far) { near_out = far_out = kMax; return; }
     if (near_y > near) near = near_y;
     if (far_y < far) far = far_y;
     float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
     if (near_z > far_z) { tmp = near_z; near_z = far_z; far_z = tmp; }
-    if (near > far_z || near_z > far) { nears[n] = fars[n] = kMax; return; }
+    if (near > far_z || near_z > far) { near_out = far_out = kMax; return; }
     if (near_z > near) near = near_z;
     if (far_z < far) far = far_z;
     if (near < min_near) near = min_near;
+    near_out = near;
+    far_out = far;
+}
+
+__global__ __launch_bounds__(kBlock) void near_far_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                          const float* __restrict__ aabb, uint32_t N, float min_near,
+                                                          float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float near, far;
+    near_far_of(rays_o, rays_d, aabb, min_near, (size_t)n, near, far);
     nears[n] = near;
     fars[n] = far;
 }
@@ -372,7 +381,10 @@ __global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t* __restrict
 //   phase 2  all 256 threads classify all (ray, k) in parallel with the very same probe() and store the jump distance,
 //   phase 3  one lane per ray follows the jumps through LDS and logs the members it lands on as samples.
 // Same floating-point expressions on the same values as the serial loop: the samples are bit-identical.
-constexpr uint32_t kMcRays = 32;      // rays per workgroup
+#ifndef NERFTEX_MC_RAYS
+#define NERFTEX_MC_RAYS 32
+#endif
+constexpr uint32_t kMcRays = NERFTEX_MC_RAYS;      // rays per workgroup
 static_assert(kRayBlock % kMcRays == 0, "the expand pass adds whole count-pass totals per 64-ray block");
 constexpr uint32_t kMcSeg = 128;      // sequence members per segment (jump distances fit a byte)
 constexpr uint32_t kMcSub = 32;       // threads per ray in phases 2 and 4 (two waves per SIMD: the phases are latency-bound)
@@ -386,7 +398,11 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
                                                                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                                          const float* __restrict__ nears, const float* __restrict__ fars,
                                                                          int* __restrict__ rays, const int* __restrict__ counter,
-                                                                         uint32_t* __restrict__ ws, uint32_t perturb, float* __restrict__ tlog) {
+                                                                         uint32_t* __restrict__ ws, uint32_t perturb, float* __restrict__ tlog,
+                                                                         const float* __restrict__ aabb, float min_near,
+                                                                         float* __restrict__ nears_w, float* __restrict__ fars_w) {
+    // aabb != NULL (nerftex_march_rays_train_fresh): near / far are computed here (and stored for the callers further down the step) instead
+    // of read, and the counter is taken as zero -- the near_far launch and the caller's counter.zero_() are not made
     __shared__ float s_T[kMcSeg * kMcTPitch];
     __shared__ uint8_t s_jump[kMcRays * kMcJPitch];
     __shared__ uint8_t s_vis[kMcRays * kMcJPitch];  // 1 = this member is a sample of the ray
@@ -401,8 +417,12 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
     const bool owner = tid < kMcRays && n_own < N;
     const uint32_t r2 = tid / kMcSub, sub = tid % kMcSub, n2 = blockIdx.x * kMcRays + r2;
     const bool has2 = n2 < N;
-    const Dda s2(rays_o + 3 * (size_t)(has2 ? n2 : 0), rays_d + 3 * (size_t)(has2 ? n2 : 0), bound, dt_gamma, max_steps, C, H, grid,
-                 has2 ? fars[n2] : 0.0f);
+    float near2 = 0.0f, far2 = 0.0f;
+    if (has2) {
+        if (aabb) near_far_of(rays_o, rays_d, aabb, min_near, (size_t)n2, near2, far2);
+        else far2 = fars[n2];
+    }
+    const Dda s2(rays_o + 3 * (size_t)(has2 ? n2 : 0), rays_d + 3 * (size_t)(has2 ? n2 : 0), bound, dt_gamma, max_steps, C, H, grid, far2);
     float* log_row2 = tlog + (size_t)(has2 ? n2 : 0) * max_steps;
 
     // owner state
@@ -410,8 +430,16 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
     bool pending = false, done = true;
     uint32_t num = 0;
     if (owner) {
-        far = fars[n_own];
-        t_next = ray_t0(s2, nears[n_own], perturb, n_own, 42);  // s2.dt_min is all ray_t0 reads: the same for every ray
+        float near;
+        if (aabb) {
+            near_far_of(rays_o, rays_d, aabb, min_near, (size_t)n_own, near, far);
+            nears_w[n_own] = near;
+            fars_w[n_own] = far;
+        } else {
+            far = fars[n_own];
+            near = nears[n_own];
+        }
+        t_next = ray_t0(s2, near, perturb, n_own, 42);  // s2.dt_min is all ray_t0 reads: the same for every ray
         done = !(t_next < far);
     }
     const float dt_min = s2.dt_lo, dt_max = s2.dt_max;  // the step's clamp bounds (dt_lo: see Dda)
@@ -561,7 +589,7 @@ __global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const 
         const uint32_t wsum = wave_sum(tid < kMcRays ? num : 0u);
         if (tid == 0) {
             ws[1 + blockIdx.x] = wsum;
-            if (blockIdx.x == 0) ws[0] = (uint32_t)counter[0];
+            if (blockIdx.x == 0) ws[0] = aabb ? 0u : (uint32_t)counter[0];
         }
     }
 }
@@ -681,8 +709,11 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
                                                            const float* __restrict__ nears, float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas, float* __restrict__ rays_ts, int* __restrict__ rays,
                                                            int* __restrict__ counter, const uint32_t* __restrict__ ws, uint32_t perturb,
-                                                           const float* __restrict__ tlog, uint32_t ws_per_block) {
+                                                           const float* __restrict__ tlog, uint32_t ws_per_block, uint32_t fresh) {
+    // fresh (nerftex_march_rays_train_fresh): the counter is OVERWRITTEN (taken as zero at entry) and the sample rows nobody writes -- the
+    // ranges of the rays the drop rule below cuts, and [total, M) -- are zeroed here: the caller's buffers may arrive uninitialised
     __shared__ uint32_t red[kExpandThreads / kWave];
+    __shared__ uint32_t s_zero[2];  // fresh: first and one-past-last row this block has to zero
     __shared__ uint32_t s_off[kRayBlock], s_cnt[kRayBlock];
     const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
@@ -707,10 +738,32 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
         }
         if (blockIdx.x == gridDim.x - 1 && lane == kWave - 1) {
             counter[0] = (int)(point_index + num_steps);
-            counter[1] = counter[1] + (int)N;
+            counter[1] = (fresh ? 0 : counter[1]) + (int)N;
+        }
+        if (fresh) {
+            // the rows of this block's rays that the drop rule leaves unwritten form one run (offsets only grow): from the first cut
+            // ray's offset to the end of the block's range; the last block adds everything up to M
+            const bool cut = num_steps != 0 && point_index + num_steps >= M;
+            const unsigned long long cuts = __ballot(cut);
+            const uint32_t first_cut = cuts ? (uint32_t)__shfl(point_index, __ffsll((long long)cuts) - 1) : 0xffffffffu;
+            const uint32_t block_end = (uint32_t)__shfl(point_index + num_steps, kWave - 1);
+            if (lane == 0) {
+                const bool last = blockIdx.x == gridDim.x - 1;
+                s_zero[0] = cuts ? first_cut : (last ? block_end : 0xffffffffu);
+                s_zero[1] = last ? M : block_end;
+            }
         }
     }
     __syncthreads();
+    if (fresh) {
+        const uint32_t z0 = s_zero[0], z1 = s_zero[1] < M ? s_zero[1] : M;
+        if (z0 < z1) {
+            for (size_t i = (size_t)3 * z0 + threadIdx.x; i < (size_t)3 * z1; i += kExpandThreads) { xyzs[i] = 0.0f; dirs[i] = 0.0f; }
+            for (size_t i = (size_t)2 * z0 + threadIdx.x; i < (size_t)2 * z1; i += kExpandThreads) deltas[i] = 0.0f;
+            if constexpr (WITH_TS)
+                for (size_t i = (size_t)z0 + threadIdx.x; i < (size_t)z1; i += kExpandThreads) rays_ts[i] = 0.0f;
+        }
+    }
 
     const float dt_min = 2 * kSqrt3 / (float)max_steps;
     const float dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
@@ -1059,11 +1112,20 @@ __global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive,
 inline dim3 grid_for(uint32_t n) { return dim3(div_up(n, kBlock)); }
 inline dim3 ray_grid_for(uint32_t n) { return dim3(div_up(n, kRayBlock)); }
 
+__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b, size_t nb) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * kBlock) {
+        if (i < na) a[i] = 0u;
+        else b[i - na] = 0u;
+    }
+}
+
+// aabb != NULL: the "fresh" form (nerftex_march_rays_train_fresh) -- near / far computed by the march itself and stored to nears / fars,
+// the counter taken as zero and overwritten, the sample buffers allowed to arrive uninitialised
 template <bool WITH_TS>
 int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars,
                      float* xyzs, float* dirs, float* deltas, float* rays_ts, int32_t* rays, int32_t* counter, uint32_t perturb,
-                     void* stream) {
+                     void* stream, const float* aabb = nullptr, float min_near = 0.0f) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
     if (C == 0 || C > 16) {
@@ -1083,10 +1145,26 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     float* tlog = use_log ? reinterpret_cast<float*>(base + head) : nullptr;
     hipStream_t st = as_stream(stream);
     const bool parallel_count = use_log && H <= 256 && !knob(kKnobMarchSerial);  // march_serial = 1: the one-ray-per-lane DDA (A/B switch); the packed voxel of the parallel pass holds 8-bit coordinates
+    if (aabb && !parallel_count) {  // the folded form lives in the data-parallel kernels: otherwise the three steps it stands for, then the plain march
+        {
+            KernelTimer kt("near_far_kernel", st);
+            hipLaunchKernelGGL(near_far_kernel, grid_for(N), dim3(kBlock), 0, st, rays_o, rays_d, aabb, N, min_near, const_cast<float*>(nears),
+                               const_cast<float*>(fars));
+        }
+        {
+            KernelTimer kt("zero_words_kernel", st);
+            hipLaunchKernelGGL(zero_words_kernel, dim3(1024), dim3(kBlock), 0, st, reinterpret_cast<uint32_t*>(xyzs), (size_t)M * 8,
+                               reinterpret_cast<uint32_t*>(counter), (size_t)2);
+        }
+        int rc0 = check_launch("march_rays_train_fresh(prologue)");
+        if (rc0 != NERFTEX_OK) return rc0;
+        aabb = nullptr;
+    }
     if (parallel_count) {
         KernelTimer kt("march_count_parallel_kernel", st);
         hipLaunchKernelGGL(march_count_parallel_kernel, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                           max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog);
+                           max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog, aabb, min_near, const_cast<float*>(nears),
+                           const_cast<float*>(fars));
     } else {
         KernelTimer kt("march_count_kernel", st);
         hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
@@ -1098,7 +1176,8 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
         {
             KernelTimer kt("march_expand_kernel", st);
             hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(kExpandThreads), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
-                               nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog, parallel_count ? kRayBlock / kMcRays : 1u);
+                               nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog, parallel_count ? kRayBlock / kMcRays : 1u,
+                               aabb ? 1u : 0u);
         }
         return check_launch("march_rays_train(expand)");
     }
@@ -1172,6 +1251,26 @@ extern "C" int nerftex_march_rays_train(const float* rays_o, const float* rays_d
                                         uint32_t perturb, void* stream) {
     return march_train_impl<false>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                                    nullptr, rays, counter, perturb, stream);
+}
+
+// extension: near_far_from_aabb + counter.zero_() + zero-filled sample buffers + march_rays_train as ONE call of two launches (the caller's
+// buffers xyzs | dirs | deltas must be one allocation of 8 M floats in that order only for the fallback's single fill: see the header)
+extern "C" int nerftex_march_rays_train_fresh(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* aabb, float min_near,
+                                              float* nears, float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                              uint32_t perturb, void* stream) {
+    if (!aabb) {
+        clear_error();
+        set_error("march_rays_train_fresh: aabb must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (dirs != xyzs + (size_t)3 * M || deltas != xyzs + (size_t)6 * M) {
+        clear_error();
+        set_error("march_rays_train_fresh: xyzs, dirs, deltas must be consecutive parts of one buffer of 8 M floats");
+        return NERFTEX_ERR_INVALID;
+    }
+    return march_train_impl<false>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, nullptr, rays, counter,
+                                   perturb, stream, aabb, min_near);
 }
 
 extern "C" int nerftex_march_rays_train_differentiable(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,

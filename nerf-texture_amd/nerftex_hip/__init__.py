@@ -60,6 +60,7 @@ _SIGNATURES = {
     "nerftex_morton3D_invert": [_vp, _u32, _vp, _vp],
     "nerftex_packbits": [_vp, _u32, _f32, _vp, _vp],
     "nerftex_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "nerftex_march_rays_train_fresh": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "nerftex_march_rays_train_differentiable": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "nerftex_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "nerftex_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],

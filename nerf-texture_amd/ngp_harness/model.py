@@ -356,10 +356,19 @@ class Renderer(nn.Module):
         """First half of the training branch: everything that depends on the rays and the occupancy grid only (:361-387)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
         if counter is None:
             counter = self.step_counter[self.local_step % 16]
             self.local_step += 1
+        m = self.mean_count if mean_count is None else mean_count
+        if getattr(self, "fused_march", True) and not force_all_rays and m > 0:
+            # a fixed sample budget (the graph-replayed step): near / far, the counter reset and the buffers' zero fill ride on the march's two
+            # launches (raymarching.march_rays_train_fresh: same bits as the sequence below, tests/test_gpu_round3.py)
+            with torch.no_grad():
+                nears, fars, xyzs, dirs, deltas, rays = raymarching.march_rays_train_fresh(
+                    rays_o.float(), rays_d.float(), self.bound, self.density_bitfield, self.cascade, self.grid_size, self.aabb_train, self.min_near,
+                    counter, m + 128 - m % 128, perturb, dt_gamma, max_steps)  # (the budget rule of march_rays_train with align = 128)
+            return (nears, fars, xyzs, dirs, deltas, rays), counter
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
         counter.zero_()
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
                                                                 nears, fars, counter, self.mean_count if mean_count is None else mean_count, perturb,

@@ -184,6 +184,28 @@ class _march_rays_train(Function):
 march_rays_train = _march_rays_train.apply
 
 
+def march_rays_train_fresh(rays_o, rays_d, bound, density_bitfield, C, H, aabb, min_near, step_counter, M, perturb=False, dt_gamma=0, max_steps=1024):
+    """EXTENSION (not in the reference API): what the trainer does in front of every training render --
+        nears, fars = near_far_from_aabb(rays_o, rays_d, aabb, min_near);  step_counter.zero_()
+        xyzs, dirs, deltas, rays = march_rays_train(..., nears, fars, step_counter, mean_count=M, ...)      (M: a fixed row count, M % 4 == 0)
+    as one library call of TWO launches instead of five: the counting pass computes near / far itself, the counter is overwritten, and the
+    rows of the sample buffers that no ray writes are zeroed by the expanding pass (nerftex_march_rays_train_fresh).  Same bits.
+    Returns nears, fars, xyzs, dirs, deltas, rays."""
+    rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+    dev, N, M = rays_o.device, rays_o.shape[0], int(M)
+    assert M % 4 == 0 and M > 0, "march_rays_train_fresh: a fixed, 4-aligned row count"
+    nf = torch.empty(2, N, dtype=torch.float32, device=dev)
+    flat = torch.empty(M * 8, dtype=torch.float32, device=dev)
+    xyzs, dirs, deltas = flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    tok = timer.start("march_rays_train")
+    check(lib.nerftex_march_rays_train_fresh(ptr(rays_o), ptr(rays_d), ptr(density_bitfield.contiguous()), float(bound), float(dt_gamma), int(max_steps), N,
+                                             int(C), int(H), M, ptr(_f32(aabb).contiguous()), float(min_near), ptr(nf[0]), ptr(nf[1]), ptr(xyzs), ptr(dirs),
+                                             ptr(deltas), ptr(rays), ptr(step_counter), int(perturb), stream()))
+    timer.stop(tok)
+    return nf[0], nf[1], xyzs, dirs, deltas, rays
+
+
 class _march_rays_train_differentiable(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,

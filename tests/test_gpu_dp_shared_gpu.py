@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--no-fused-opt"]], ids=["half-leaf-adam", "torch-adam"])
+@pytest.mark.parametrize("extra", [[], ["--no-fused-opt"], ["--graph-allreduce"]], ids=["half-leaf-adam", "torch-adam", "allreduce-in-graph-or-fallback"])
 def test_two_ranks_on_one_gpu_keep_identical_replicas(extra):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, NERFTEX_DP_SHARE_GPU="1")
-    port = 29600 + os.getpid() % 200 + (7 if extra else 0)
+    port = 29600 + os.getpid() % 200 + (0 if not extra else 7 if extra[0] == "--no-fused-opt" else 13)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4", "--rays", "2048", "--no-cpu-baseline",
            "--no-other", "--no-infer", "--no-kernel-timing"] + extra
@@ -29,6 +29,9 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas(extra):
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
     assert res["config"]["replicas_identical_after_run"] is True
     assert res["value"] > 0
+    # --graph-allreduce: only RCCL collectives can be captured; under gloo (this test) the bench must fall back to the split structure and
+    # say so (the branch itself runs on the driver's 8-GPU node)
+    assert res["config"]["collective"]["allreduce_in_graph"] is False
 
 
 def _bench(n_ranks, rays, extra, port):

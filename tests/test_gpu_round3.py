@@ -460,3 +460,52 @@ def test_accelerate_replays_the_eager_step(dev, mlp):
     # the same kernels on the same inputs; sample buffers of a different (fixed) size change nothing per sample, and with perturb off the
     # march is deterministic: the trajectories agree to the fp16 accumulation-order noise of the MLP gradients
     np.testing.assert_allclose(graphed, eager, rtol=5e-2, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------- the march as one call of two launches
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("budget", ["fits", "cut"])
+def test_fresh_march_equals_the_four_step_sequence(dev, perturb, budget):
+    """raymarching.march_rays_train_fresh (extension) = near_far_from_aabb + counter.zero_() + zero-filled buffers + march_rays_train, bit for
+    bit: near / far, ray records, counter, every sample row -- and the rows NO ray writes are zero although the buffers arrive uninitialised
+    (also when the budget cuts rays off: raymarching.cu:418-419)."""
+    import raymarching
+
+    torch.manual_seed(5)
+    N, C, H, bound = 3000, 2, 128, 2.0
+    o = (torch.rand(N, 3, device=dev) - 0.5) * 2.4
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
+    o[:7] = 9.0  # rays that miss the box
+    d[7] = torch.tensor([1.0, 0.0, 0.0], device=dev)  # an axis-aligned ray (1/0 slabs)
+    bits = (torch.rand(C * H ** 3 // 8, device=dev) < 0.35).to(torch.uint8) * torch.randint(0, 256, (C * H ** 3 // 8,), device=dev, dtype=torch.uint8)
+    aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], device=dev)
+    nears, fars = raymarching.near_far_from_aabb(o, d, aabb, 0.2)
+    counter = torch.full((2,), 77, dtype=torch.int32, device=dev)
+    counter.zero_()
+    probe = torch.zeros(2, dtype=torch.int32, device=dev)
+    raymarching.march_rays_train(o, d, bound, bits, C, H, nears, fars, probe, -1, perturb, 128, True, 1 / 128, 256)
+    total = int(probe[0])
+    assert total > 20000
+    M = (total + 4096) // 128 * 128 if budget == "fits" else (total // 2) // 128 * 128
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, bound, bits, C, H, nears, fars, counter, M - 128, perturb, 128, False, 1 / 128, 256)
+    assert xyzs.shape[0] == M
+    c2 = torch.full((2,), 12345, dtype=torch.int32, device=dev)  # garbage: the fresh form overwrites
+    for _ in range(2):  # twice: the second call finds the caching allocator's recycled (dirty) buffers
+        n2, f2, x2, d2, l2, r2 = raymarching.march_rays_train_fresh(o, d, bound, bits, C, H, aabb, 0.2, c2, M, perturb, 1 / 128, 256)
+        assert torch.equal(n2, nears) and torch.equal(f2, fars)
+        assert torch.equal(r2, rays) and torch.equal(c2, counter)
+        assert torch.equal(x2, xyzs) and torch.equal(d2, dirs) and torch.equal(l2, deltas)
+        x2.fill_(float("nan")), d2.fill_(float("nan")), l2.fill_(float("nan"))
+        del n2, f2, x2, d2, l2, r2
+    if budget == "cut":
+        kept = rays[:, 2] > 0
+        assert int((rays[kept, 1] + rays[kept, 2]).max()) >= M  # some ray was cut off, so there is a zero suffix that is not "past the total"
+
+
+def test_fresh_march_needs_one_buffer(dev):
+    from nerftex_hip import lib
+
+    z = torch.zeros(64, device=dev)
+    rc = lib.nerftex_march_rays_train_fresh(z.data_ptr(), z.data_ptr(), z.data_ptr(), 1.0, 0.0, 16, 1, 1, 128, 4, z.data_ptr(), 0.2, z.data_ptr(), z.data_ptr(),
+                                            z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, None)
+    assert rc == 1 and b"one buffer" in lib.nerftex_last_error()

@@ -23,8 +23,8 @@ for i in (1, 2, 3):
     for r in csv.DictReader(open(fs[0])):
         name = r["Kernel_Name"]
         if not re.search(r"$filt", name): continue
-        m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
-        k = (m.group(1) + (m.group(2) or "")) if m else name[:80]
+        m = re.search(r"\d+([a-z_0-9]+_kernel)(I.*?)?Ev", name) if name.startswith("_Z") else re.search(r"(\w+_kernel)(<[^>]*>)?", name)
+        k = (m.group(1) + (m.group(2) or "")) if m else name[:80]  # (mangled names keep their template arguments: Li3E = 3, Lb1E = true)
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     with open("$out/summary_p%d.txt" % i, "w") as f:
         for k in sorted(agg):
