@@ -36,7 +36,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
 # Memory-side bytes per launch of the default workload's hash-grid ops (fp16 table, ~459 k samples), from separate rocprofv3 PMC
-# passes (FETCH_SIZE, WRITE_SIZE; profiles/r02_pmc_grid.txt).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
+# passes (FETCH_SIZE, WRITE_SIZE; profiles/r03_pmc_grid.txt).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
 # MI355X_MICROARCH.md for wide coalesced streams: here the 8-B record stream) + WRITE_SIZE.  Forward: FETCH_SIZE as reported
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
 TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 578.0e6}
@@ -638,6 +638,9 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dominant),
+            "traffic_source": "CONSTANT, not measured in this run: PMC counters need their own rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE over "
+                              "tools/bench_kernels.py at this workload, summary in profiles/r03_pmc_grid.txt; 2 x FETCH_SIZE + WRITE_SIZE as the guide's gfx950 "
+                              "correction prescribes for coalesced streams)",
             "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
             "kernels_avg_us": kern[dominant]["kernels_avg_us"],
             "other": {k: v for k, v in kern.items() if k != dominant},

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-level cost of the XCD-pinned hash-grid forward: each level of the fox table run ALONE (L = 1: one XCD does all of it), on the
-bench's sample stream.  Kernel total ~ max over XCDs of the sum of the levels it walks (x, x + 8)."""
+bench's sample stream.  Kernel total ~ max over XCDs of the sum of the levels it walks."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "nerf-texture_amd")]
@@ -43,5 +43,7 @@ for l in range(16):
         check(lib.nerftex_grid_encode_forward(ptr(x01), ptr(sub), ptr(o1), ptr(out), M, 3, 2, 1, 0.0, Hres, 0, None, 0, 1, F16, 0, stream()))
     e1.record(); torch.cuda.synchronize()
     res[l] = round(e0.elapsed_time(e1) * 100, 1)
-pairs = {x: round(res[x] + res[x + 8], 1) for x in range(8)}
-print(json.dumps({"points": M, "level_us_alone_on_one_xcd": res, "xcd_sums": pairs}, indent=1))
+pairs = {x: round(res[x] + res[x + 8], 1) for x in range(8)}          # the round-2 deal: XCD x walks levels x, x + 8
+serp = {x: round(res[x] + res[15 - x], 1) for x in range(8)}          # round 3: rounds alternate direction (x, 15 - x)
+print(json.dumps({"points": M, "level_us_alone_on_one_xcd": res, "sum_over_levels": round(sum(res.values()), 1), "xcd_sums_x_x+8": pairs,
+                  "xcd_sums_x_15-x (what the kernel does)": serp}, indent=1))
