@@ -269,7 +269,18 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         else:
             scaler.step(opt)
             scaler.update()
-    total_samples = torch.zeros((), dtype=torch.int64, device=dev)
+    # samples marched in the timed region: the step-counter ring already holds every step's count and is read back every 16 steps (the reference's
+    # own mean_count read-back): the ring sums are added up on the host there -- no counting kernel inside the step
+    counted = {"rings": 0}
+
+    def ring_end():
+        renderer.update_mean_count()
+        counted["rings"] += renderer.last_ring_samples
+        renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
+
+    def partial_ring():  # the executed steps of the ring in progress (a read-back: outside the timed region only)
+        n = renderer.local_step
+        return int(renderer.step_counter[:n, 0].sum().item()) if n else 0
     dt_gamma = 1 / 128
     field.train()
 
@@ -279,11 +290,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         counter = forward_backward(ro, rd, gt[k % n_pool])
         reducer.all_reduce()
         optimizer_step()
-        if count:
-            total_samples.add_(counter[0])
         if renderer.local_step == 16:  # update_extra_state cadence (nerf/utils.py:1011): mean_count read-back
-            renderer.update_mean_count()
-            renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
+            ring_end()
 
     # ---- the same step as ONE replayed HIP graph: the eager loop is bound by the host's launch rate (the same kernels took 1.60 or
     # 1.83 ms per step depending on the box's host); a graph takes the host out of it.  Sixteen graphs, one per slot of the
@@ -299,15 +307,13 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
 
     def body_fb(g, marched=None):
         reducer.zero_grad()
-        counter = forward_backward(*pool[g % n_pool], gt[g % n_pool], marched=body_march(g) if marched is None else marched)
-        total_samples.add_(counter[0])
+        forward_backward(*pool[g % n_pool], gt[g % n_pool], marched=body_march(g) if marched is None else marched)
 
     def body_opt():
         optimizer_step()
 
     def capture():
         gstate["M"] = (renderer.mean_count + 4095) // 4096 * 4096 + 4096
-        kept = total_samples.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -363,7 +369,6 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         gstate["graphs"] = graphs
         gstate["marched"] = -1
         renderer.local_step = 0
-        total_samples.copy_(kept)  # the warm-up steps above are not among the counted ones
 
     def graph_step(k):
         g = renderer.local_step
@@ -401,8 +406,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             gb.replay()
         renderer.local_step = g + 1
         if renderer.local_step == RING:
-            renderer.update_mean_count()
-            renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
+            ring_end()
             if renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]:
                 capture()  # the sample count left the captured buffer size (does not happen on a static scene)
 
@@ -421,7 +425,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = split_graph = march_ahead = False
-    total_samples.zero_()
+    torch.cuda.synchronize()
+    counted["rings"] = -partial_ring()  # the steps of the ring in progress that ran before the timed region
 
     if time_grid_kernels and not use_graph:
         nerftex_hip.kernel_profile(2, reset=True)  # hipEvent pairs around the hash-grid kernels only (8 of ~90 launches per step)
@@ -433,7 +438,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     torch.cuda.synchronize()
     dp.barrier()
     t1 = time.perf_counter()
-    samples_timed = total_samples.clone()
+    samples_timed = torch.tensor(counted["rings"] + partial_ring(), dtype=torch.int64, device=dev)
     kernel_us, all_kernel_us = {}, {}
     if time_grid_kernels:
         if use_graph:  # event pairs cannot be read back from a replayed graph: the same step, launched eagerly, right after the timed region

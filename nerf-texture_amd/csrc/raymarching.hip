@@ -924,6 +924,25 @@ __global__ __launch_bounds__(kCompBlock) void composite_train_bwd_kernel(const f
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
                    num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    if constexpr (TAIL) {
+        // The gradient buffers arrive UNINITIALISED here (the caller's zero fill is not made): the rows no ray covers are zeroed by this
+        // launch.  With this library's ordered records (record n = ray n, offsets = exclusive prefix sums) those rows are [total, M) --
+        // every wave takes a slice -- or, when the budget cut rays off (raymarching.cu:418-419), [offset of the first cut ray, M).
+        const uint32_t total = (uint32_t)rays[3 * (size_t)(N - 1) + 1] + (uint32_t)rays[3 * (size_t)(N - 1) + 2];
+        uint32_t z0 = M, z1 = M;
+        if (total < M) {
+            const uint32_t per = (M - total + N - 1) / N;
+            z0 = total + n * per < M ? total + n * per : M;
+            z1 = z0 + per < M ? z0 + per : M;
+        } else if (num_steps != 0 && offset < M && offset + num_steps >= M) {
+            z0 = offset;
+        }
+        for (size_t i = (size_t)4 * z0 + lane; i < (size_t)4 * z1; i += kWave) {  // 4 floats per row: 1 of grad_sigmas, 3 of grad_rgbs
+            const size_t row = i >> 2, c = i & 3;
+            if (c == 0) grad_sigmas[row] = 0.0f;
+            else grad_rgbs[3 * row + c - 1] = 0.0f;
+        }
+    }
     if (num_steps == 0 || offset + num_steps >= M) return;
     float gws, gi0, gi1, gi2;
     if constexpr (TAIL) {
@@ -1310,6 +1329,8 @@ extern "C" int nerftex_composite_rays_train_backward(const float* grad_weights_s
 }
 
 // Extension (harness level): nerftex_render_tail_backward + nerftex_composite_rays_train_backward as one launch (TailBackward above).
+// Unlike the reference-shaped entry above, grad_sigmas / grad_rgbs need NOT be pre-zeroed: the launch zeroes the rows no ray covers.  That
+// relies on this library's ordered ray records (record n = ray n, offsets ascending), which is what its march emits.
 extern "C" int nerftex_composite_tail_backward(const float* grad_loss, const float* scale, float loss_mul, const float* image_out, const float* target,
                                                float bg, const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                                const float* weights_sum, const float* image, uint32_t M, uint32_t N, float* grad_sigmas,

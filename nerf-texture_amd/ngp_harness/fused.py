@@ -280,8 +280,8 @@ class _composite_tail(Function):
         bg, loss_mul = ctx.consts
         M, N = sigmas.shape[0], rays.shape[0]
         grad_scaled = grad_scaled.contiguous().float()
-        # rows the rays do not cover (the tail of a buffer sized by the mean count) get no gradient: zeros, like the reference's buffers
-        grads = torch.zeros(4 * M, dtype=torch.float32, device=sigmas.device)
+        # rows the rays do not cover (the tail of a buffer sized by the mean count) get no gradient: zeros, like the reference's buffers --
+        grads = torch.empty(4 * M, dtype=torch.float32, device=sigmas.device)  # (zeroed where no ray writes by the launch itself)
         grad_sigmas, grad_rgbs = grads[:M], grads[M:].view(M, 3)
         check(lib.nerftex_composite_tail_backward(ptr(grad_scaled), ptr(scale), loss_mul, ptr(image_out), ptr(target), bg, ptr(sigmas), ptr(rgbs), ptr(deltas),
                                                   ptr(rays), ptr(weights_sum), ptr(image), M, N, ptr(grad_sigmas), ptr(grad_rgbs), stream()))

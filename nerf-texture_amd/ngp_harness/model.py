@@ -336,8 +336,10 @@ class Renderer(nn.Module):
     def update_mean_count(self):
         """The step-counter half of update_extra_state (:656-660): one D2H read every 16 steps."""
         total = min(16, self.local_step)
+        self.last_ring_samples = 0  # what the ring's steps marched in total (bench.py adds these up instead of counting per step)
         if total > 0:
-            self.mean_count = int(self.step_counter[:total, 0].sum().item() / total)
+            self.last_ring_samples = int(self.step_counter[:total, 0].sum().item())
+            self.mean_count = int(self.last_ring_samples / total)
         self.local_step = 0
 
     def render_train(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=True, force_all_rays=False, max_steps=1024, counter=None,
