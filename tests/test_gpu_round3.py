@@ -509,3 +509,43 @@ def test_fresh_march_needs_one_buffer(dev):
     rc = lib.nerftex_march_rays_train_fresh(z.data_ptr(), z.data_ptr(), z.data_ptr(), 1.0, 0.0, 16, 1, 1, 128, 4, z.data_ptr(), 0.2, z.data_ptr(), z.data_ptr(),
                                             z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, None)
     assert rc == 1 and b"one buffer" in lib.nerftex_last_error()
+
+
+# ------------------------------------------------------------------------------------------------- neighbour search, stand-alone
+@pytest.mark.parametrize("K", [1, 4, 8, 16])
+@pytest.mark.parametrize("cloud", ["surface", "clustered"])
+def test_knn_is_exact_on_random_clouds(dev, K, cloud):
+    """nerftex_knn_query against cdist + topk: the K smallest DISTANCES (indices may differ only between equidistant points) for queries
+    inside the cloud, far outside its bounding box, exactly on vertices, and for a cloud that leaves most grid cells empty."""
+    import ctypes
+
+    from nerftex_hip import check, lib, ptr, stream
+
+    g = torch.Generator().manual_seed(3 + K)
+    V = 5000
+    if cloud == "surface":  # a sphere's surface: what a mesh's vertices look like to the grid (most cells empty)
+        pts = torch.nn.functional.normalize(torch.randn(V, 3, generator=g), dim=-1) * 0.8
+    else:  # three tight clusters far apart + duplicates
+        centres = torch.tensor([[0.0, 0.0, 0.0], [5.0, 5.0, 5.0], [-3.0, 4.0, 0.5]])
+        pts = centres[torch.randint(0, 3, (V,), generator=g)] + 0.01 * torch.randn(V, 3, generator=g)
+        pts[100:110] = pts[100]
+    handle = ctypes.c_void_p()
+    host = np.ascontiguousarray(pts.numpy(), dtype=np.float32)
+    check(lib.nerftex_knn_create(host.ctypes.data_as(ctypes.c_void_p), V, ctypes.byref(handle)))
+    try:
+        q = torch.cat([pts[:300] + 0.02 * torch.randn(300, 3, generator=g), pts[300:400], 30.0 * torch.randn(100, 3, generator=g),
+                       torch.tensor([[1e6, -1e6, 0.0]])]).to(dev).contiguous()
+        idx = torch.empty(q.shape[0], K, dtype=torch.int32, device=dev)
+        dis = torch.empty(q.shape[0], K, dtype=torch.float32, device=dev)
+        check(lib.nerftex_knn_query(handle, ptr(q), q.shape[0], K, ptr(idx), ptr(dis), stream()))
+        d = torch.cdist(q.double(), pts.to(dev).double())
+        want, _ = torch.topk(d, K, dim=-1, largest=False, sorted=True)
+        assert torch.allclose(dis.double(), want, rtol=2e-6, atol=1e-6)
+        assert int(idx.min()) >= 0 and int(idx.max()) < V
+        own = (q.unsqueeze(1).double() - pts.to(dev).double()[idx.long()]).norm(dim=-1)  # the reported indices really are at the reported distances
+        assert torch.allclose(own, dis.double(), rtol=2e-6, atol=1e-6)
+        assert bool((dis[:, 1:] >= dis[:, :-1]).all())
+        check(lib.nerftex_knn_query(handle, ptr(q), 0, K, ptr(idx), ptr(dis), stream()))  # no queries: nothing to do
+        assert lib.nerftex_knn_query(handle, ptr(q), 4, V + 1, ptr(idx), ptr(dis), stream()) == 1  # more neighbours than points (or > 16): invalid
+    finally:
+        check(lib.nerftex_knn_destroy(handle))
