@@ -406,7 +406,17 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             gb.replay()
         renderer.local_step = g + 1
         if renderer.local_step == RING:
-            ring_end()
+            if march_ahead:
+                # Every march of the ring has run by now (the last one under step RING - 2), so the ring's counters are final while step RING - 1
+                # is still on the main stream: the read-back waits for the SIDE stream only, and the next ring's first march goes out at once --
+                # under the tail of this step -- instead of running inline after the main stream has drained (same 16 counters, same mean)
+                with torch.cuda.stream(side_stream):
+                    ring_end()
+                    if not (renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]):
+                        gstate["graphs"][0][0].replay()
+                        gstate["marched"] = 0
+            else:
+                ring_end()
             if renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]:
                 capture()  # the sample count left the captured buffer size (does not happen on a static scene)
 
@@ -415,6 +425,10 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         train_step(k, count=False)
     renderer.update_mean_count()
     renderer.mean_count = dp.all_reduce_max_int(renderer.mean_count, dev)
+    # the two priming steps ran on full-size buffers (8192 x 1024 rows): the library's grow-only scratch followed (gigabytes of binning records);
+    # hand it back before the steady state sizes it again
+    torch.cuda.synchronize()
+    nerftex_hip.check(nerftex_hip.lib.nerftex_release_workspaces())
     for k in range(warmup):
         train_step(k, count=False)
     if use_graph:

@@ -131,6 +131,13 @@ class AcceleratedTrainer:
         """After a mean_count read-back: (re)choose the sample-buffer size; a change drops the graphs (two eager steps, then a new capture)."""
         r = self.renderer
         if self._M == 0 or r.mean_count + 128 > self._M or r.mean_count < 0.8 * self._M:
+            if self._M == 0:
+                # the first ring ran on full-size buffers (N * max_steps rows, as the reference's first steps do): the library's scratch grew to
+                # match -- gigabytes of binning records -- and would stay that size; give it back once, now that a sample count exists
+                from nerftex_hip import check, lib
+
+                torch.cuda.synchronize()
+                check(lib.nerftex_release_workspaces())
             self._M = (r.mean_count + 4095) // 4096 * 4096 + 4096
             self._graphs, self._warm = None, 0
 
