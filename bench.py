@@ -536,13 +536,13 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid):
     field.train()
     trainer = accelerate(renderer, dt_gamma=1 / 128)
     for k in range(16 + 32):  # priming (full-size buffers, mean count), capture, past the first mean_count read-backs
-        trainer.step(*pool[k % n_pool], gt[k % n_pool])
+        trainer.step(*pool[k % n_pool], gt[k % n_pool], next_rays=pool[(k + 1) % n_pool])
     torch.cuda.synchronize()
     samples = torch.zeros((), dtype=torch.int64, device=dev)
     t0 = time.perf_counter()
-    for k in range(steps):
+    for k in range(steps):  # a trainer that has the next batch's rays one step early (next_rays): their march runs beside this step
         slot = renderer.local_step
-        trainer.step(*pool[k % n_pool], gt[k % n_pool])
+        trainer.step(*pool[k % n_pool], gt[k % n_pool], next_rays=pool[(k + 1) % n_pool])
         samples += renderer.step_counter[slot, 0]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -719,14 +719,14 @@ def main():
             other.append({"workload": label if "configs[2]" in label and len(label) > 12 else WORKLOADS[mlp_k], "rays_per_batch": rays_k, "dtype": dt_k,
                           "value": r2["value"], "unit": "ray-samples/s", "ms_per_step": r2["ms_per_step"], "steps": 16,
                           "launch": r2["graph"] if r2["graph"] else "eager launches"})
-        for label, mlp_k, rays_k in (("configs[2] through ngp_harness.accelerate(renderer): a training loop that feeds fresh rays every step; one replayed HIP graph "
+        for label, mlp_k, rays_k in (("configs[2] through ngp_harness.accelerate(renderer): a training loop that feeds fresh rays every step (and has the next batch's rays one step early: next_rays); replayed HIP graphs "
                                       "per step, fused field, HalfLeafAdam + FusedAmp", "ffmlp", 8192),
                                      ("configs[1] through ngp_harness.accelerate(renderer): nn.Linear MLPs on PyTorch-ROCm, torch's capturable fused Adam + GradScaler "
                                       "inside one replayed HIP graph per step", "torch", 4096)):
             try:
                 r3 = measure_accelerated(args, mlp_k, rays_k, 32, dev, grid)
                 other.append({"workload": label, "rays_per_batch": rays_k, "dtype": "fp16", "value": r3["value"], "unit": "ray-samples/s",
-                              "ms_per_step": r3["ms_per_step"], "steps": 32, "launch": "one replayed HIP graph per step (inputs copied into static buffers)",
+                              "ms_per_step": r3["ms_per_step"], "steps": 32, "launch": "two replayed HIP graphs per step (inputs copied into static buffers): the step, and on a second stream the march of the batch handed over as next_rays",
                               "loss_after_run": r3["loss"]})
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
                 print(f"[bench] accelerate() measurement failed ({type(e).__name__}: {e})", file=sys.stderr)

@@ -4,15 +4,21 @@ The reference trainer's step (nerf/utils.py:1011-1022, :559-620) is
     pred = model.render(rays_o, rays_d, staged=False, bg_color=..., perturb=True, force_all_rays=..., **opt)
     loss = criterion(pred['image'], gt);  scaler.scale(loss).backward();  scaler.step(optimizer);  scaler.update()
 -- ~90 framework launches per step on the HIP kernels of the drop-in packages, bound by the host's launch rate (1.0-1.4 ms per
-8192-ray step depending on the host, against 0.65 ms of kernels).  What the headline adds on top of the drop-in packages is host-side
+8192-ray step depending on the host, against 0.57 ms of kernels).  What the headline adds on top of the drop-in packages is host-side
 only, and this module packages it behind one call for a loop that feeds FRESH rays every step (bench.py's headline bakes its ray pool
 into the graphs; a trainer cannot):
 
     trainer = accelerate(renderer)                       # renderer: ngp_harness.model.Renderer over an NGPField
     loss = trainer.step(rays_o, rays_d, target_rgb)      # one training step; a device scalar, nothing is read back
+    loss = trainer.step(rays_o, rays_d, target_rgb, next_rays=(o2, d2))   # ... and start marching the NEXT batch beside it
 
-  * the whole step -- march, field, compositing + loss, backward, loss scaler, optimizer -- replayed as ONE HIP graph per slot of the
-    renderer's 16-entry step-counter ring (renderer.py:656-660), reading its rays / targets from static buffers the call copies into;
+  * the step replayed as HIP graphs, one set per slot of the renderer's 16-entry step-counter ring (renderer.py:656-660): the march of a
+    batch (near / far, DDA, sample expansion: it needs the rays and the occupancy grid, NOT the weights) and the rest of the step (field,
+    compositing + loss, backward, loss scaler, optimizer) are separate graphs, reading rays / targets from static buffers the call copies into;
+  * `next_rays`: a trainer that has its next batch's rays when it calls `step` (one `get_rays` ahead: software pipelining) hands them over
+    and their march runs on a second, high-priority stream UNDER this step's kernels -- latency-bound work on issue slots the step leaves
+    idle -- instead of in front of the next step; the next call must then pass the same rays (checked).  It is ordered behind the
+    production of those rays (an event recorded at the call), not behind this step.  Without `next_rays` the march runs inline;
   * `NGPField(fused_glue=True)`: everything behind the hash-grid gather as one kernel forward, the glue folded into the MLP backward;
   * `HalfLeafAdam` + `FusedAmp`: Adam on the fp16 gradients and GradScaler's device side as two launches (FFMLP fields); a field with
     nn.Linear MLPs (BASELINE configs[1]) gets torch's fused capturable Adam + GradScaler inside the same graph;
@@ -21,8 +27,10 @@ into the graphs; a trainer cannot):
     mean is read back (the reference does the same in update_extra_state) and, if it left the size, two eager steps at the new size
     and a new capture follow.
 The occupancy update stays the caller's (`renderer.update_extra_state_device()` every 16 steps writes grid and bitfield in place: the
-graphs keep reading the same tensors).  Values: the same kernels in the same order as the eager step -- tests/test_gpu_training.py holds
-the replayed step to the eager loss trajectory.
+graphs keep reading the same tensors).  A march started by `next_rays` reads the grid as it is at that moment: hand the next rays over
+AFTER the update when one is due (the ring's end, where nothing is marched ahead anyway: the read-back comes first there).
+Values: the same kernels in the same order as the eager step -- tests/test_gpu_round3.py holds the replayed step to the eager loss
+trajectory, with and without `next_rays`.
 """
 import torch
 
@@ -52,12 +60,19 @@ class AcceleratedTrainer:
             self.opt = torch.optim.Adam(field.get_params(lr), betas=betas, eps=eps, fused=True, capturable=self.use_graph)
             self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype == torch.float16)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
-        self._graphs, self._M, self._static = None, 0, None
+        self._graphs, self._M = None, 0
+        self._rays, self._target = None, None  # static inputs: rays per ring slot (the march of slot g + 1 may run while slot g's is still read), one target
         self._primed, self._warm = 0, 0
+        self._ahead = None  # (slot, data_ptr of rays_o, data_ptr of rays_d) of a march started by `next_rays`
+        self._side = None
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
 
-    # ---- one eager step on (ro, rd, tgt); mean_count None = the ring's (full-size buffers while it is unknown)
-    def _body(self, ro, rd, tgt, mean_count=None):
+    # ---- the two halves of one eager step; mean_count None = the ring's (full-size buffers while it is unknown)
+    def _march(self, ro, rd, mean_count=None):
+        with torch.autocast("cuda", dtype=self.amp_dtype):
+            return self.renderer.march_train(ro, rd, dt_gamma=self.dt_gamma, perturb=self.perturb, max_steps=self.max_steps, mean_count=mean_count)
+
+    def _shade(self, marched, tgt):
         r = self.renderer
         if self.fused:
             for leaf in self.opt.leaves:
@@ -65,7 +80,6 @@ class AcceleratedTrainer:
         else:
             self.opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=self.amp_dtype):
-            marched, counter = r.march_train(ro, rd, dt_gamma=self.dt_gamma, perturb=self.perturb, max_steps=self.max_steps, mean_count=mean_count)
             image, depth, loss, scaled = r.shade_train(marched, self.bg_color, target=tgt, scale=self.amp.scale if self.amp else None)
         if self.amp:
             scaled.backward(self._one)
@@ -75,42 +89,48 @@ class AcceleratedTrainer:
             self.scaler.step(self.opt)
             self.scaler.update()
         self.loss.copy_(loss.detach().reshape(()))
-        return counter
 
     def _capture(self):
-        """Record the 16 graphs.  Nothing is executed here: the two eager steps at this buffer size that `step` ran just before (real
+        """Record the graphs.  Nothing is executed here: the two eager steps at this buffer size that `step` ran just before (real
         training steps) have sized the library's workspaces and done every lazy initialisation outside the capture."""
         r = self.renderer
-        ro, rd, tgt = self._static
         keep_step = r.local_step
-        graphs, pool = [], None
-        for g in range(RING):  # one graph per ring slot: the step's counter is slot g, as in the eager loop
+        graphs, pool, pool_m = [], None, None
+        for g in range(RING):  # per ring slot: the step's counter is slot g, as in the eager loop
             r.local_step = g
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
-                self._body(ro, rd, tgt, mean_count=self._M)
-            pool = graph.pool()
-            graphs.append(graph)
+            gm = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"):  # (own memory pool: it may run beside the other graph)
+                marched, _ = self._march(*self._rays[g], mean_count=self._M)
+            pool_m = gm.pool()
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                self._shade(marched, self._target)
+            pool = ga.pool()
+            graphs.append((gm, ga, marched))  # (the sample tensors stay alive: the second graph reads them)
         self._graphs = graphs
         r.local_step = keep_step % RING
 
-    def step(self, rays_o, rays_d, target):
+    def step(self, rays_o, rays_d, target, next_rays=None):
         """One training step on a batch of rays [N,3], [N,3] and their target colours [N,3] (device tensors; N fixed after the first call).
+        next_rays = (rays_o, rays_d) of the batch the NEXT call will pass: its march starts now, beside this step (module docstring).
         Returns the loss as a device scalar that the NEXT call overwrites."""
         r = self.renderer
         rays_o, rays_d, target = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), target.reshape(-1, 3)
-        if self._static is None:
+        if self._rays is None:
             self.n_rays = rays_o.shape[0]
-            self._static = (torch.empty_like(rays_o, dtype=torch.float32), torch.empty_like(rays_d, dtype=torch.float32),
-                            torch.empty_like(target, dtype=torch.float32))
+            self._rays = [(torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev), torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev))
+                          for _ in range(RING)]
+            self._target = torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev)
         assert rays_o.shape[0] == self.n_rays, "a captured step has a fixed batch size"
-        for dst, src in zip(self._static, (rays_o, rays_d, target)):
-            dst.copy_(src, non_blocking=True)
+        main = torch.cuda.current_stream()
         if not self.use_graph or self._primed < RING or self._warm < 2:
             # the reference's first steps: full-size sample buffers until the ring holds a mean count (its update_extra_state cadence);
             # then -- and after every change of the buffer size -- two eager steps at the size the graphs will be recorded with
             sized = self._primed >= RING  # (graph=False keeps the same buffer-size policy, launched eagerly)
-            self._body(*self._static, mean_count=self._M if sized else None)
+            ro, rd = self._rays[r.local_step % RING]
+            ro.copy_(rays_o, non_blocking=True), rd.copy_(rays_d, non_blocking=True), self._target.copy_(target, non_blocking=True)
+            marched, _ = self._march(ro, rd, mean_count=self._M if sized else None)
+            self._shade(marched, self._target)
             self._primed += 1
             self._warm += 1 if sized else 0
             if r.local_step == RING:
@@ -120,12 +140,52 @@ class AcceleratedTrainer:
         if self._graphs is None:
             self._capture()
         g = r.local_step
-        self._graphs[g].replay()
+        gm, ga, _ = self._graphs[g]
+        if self._ahead is not None and self._ahead == (g, rays_o.data_ptr(), rays_d.data_ptr()):
+            main.wait_stream(self._side)  # marched beside the previous step
+        else:
+            assert self._ahead is None, "next_rays of the previous call must be the rays of this call (same tensors)"
+            self._rays[g][0].copy_(rays_o, non_blocking=True), self._rays[g][1].copy_(rays_d, non_blocking=True)
+            gm.replay()
+        self._ahead = None
+        self._target.copy_(target, non_blocking=True)
+        last = g + 1 == RING
+        ready = None
+        if next_rays is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)  # everything enqueued so far (the production of the next rays, an occupancy update, this batch's march) -- NOT the rest of this step
+        ga.replay()
         r.local_step = g + 1
-        if r.local_step == RING:
-            r.update_mean_count()  # one read-back per 16 steps, as in the reference
+        if not last:
+            if ready is not None:
+                self._march_ahead(g + 1, next_rays, ready)
+        else:
+            # one read-back per 16 steps, as in the reference.  Every march of the ring has run by now, so with a second stream at hand the
+            # read-back waits for the marches only, not for this step's backward, and the next ring's first march can go out at once
+            if ready is not None:
+                with torch.cuda.stream(self._side_stream()):
+                    self._side.wait_event(ready)
+                    r.update_mean_count()
+            else:
+                r.update_mean_count()
             self._resize()
+            if ready is not None and self._graphs is not None:
+                self._march_ahead(0, next_rays, ready)
         return self.loss
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev, priority=-1)  # its few, fat workgroups go first when slots free up
+        return self._side
+
+    def _march_ahead(self, slot, next_rays, ready):
+        no, nd = next_rays[0].reshape(-1, 3), next_rays[1].reshape(-1, 3)
+        assert no.shape[0] == self.n_rays
+        with torch.cuda.stream(self._side_stream()):
+            self._side.wait_event(ready)
+            self._rays[slot][0].copy_(no, non_blocking=True), self._rays[slot][1].copy_(nd, non_blocking=True)
+            self._graphs[slot][0].replay()
+        self._ahead = (slot, no.data_ptr(), nd.data_ptr())
 
     def _resize(self):
         """After a mean_count read-back: (re)choose the sample-buffer size; a change drops the graphs (two eager steps, then a new capture)."""

@@ -439,7 +439,7 @@ def test_accelerate_replays_the_eager_step(dev, mlp):
     rays = [(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)) for o, d in rays]
     tgt = torch.rand(6, 2048, 3, generator=torch.Generator().manual_seed(9)).to(dev) * 0.2 + 0.4
 
-    def run(graph):
+    def run(graph, ahead=False):
         torch.manual_seed(0)
         field = NGPField(bound=2.0, mlp=mlp, fused_glue=True).to(dev)
         torch.manual_seed(1)
@@ -450,7 +450,7 @@ def test_accelerate_replays_the_eager_step(dev, mlp):
         tr = accelerate(r, graph=graph, perturb=False)
         losses = []
         for k in range(56):
-            losses.append(tr.step(*rays[k % 6], tgt[k % 6]).clone())
+            losses.append(tr.step(*rays[k % 6], tgt[k % 6], next_rays=rays[(k + 1) % 6] if ahead else None).clone())
         return torch.stack(losses).cpu().numpy(), tr
 
     eager, _ = run(False)
@@ -460,6 +460,16 @@ def test_accelerate_replays_the_eager_step(dev, mlp):
     # the same kernels on the same inputs; sample buffers of a different (fixed) size change nothing per sample, and with perturb off the
     # march is deterministic: the trajectories agree to the fp16 accumulation-order noise of the MLP gradients
     np.testing.assert_allclose(graphed, eager, rtol=5e-2, atol=1e-4)
+    # next_rays: the next batch marched on the second stream beside the step -- the same graphs on the same inputs, another stream
+    ahead, tr2 = run(True, ahead=True)
+    assert tr2._side is not None, "a march ran ahead"
+    if mlp == "ffmlp":  # (the fused path is deterministic kernel by kernel: bit-identical; torch's nn.Linear path uses library GEMMs)
+        assert np.array_equal(ahead, graphed)
+    else:
+        np.testing.assert_allclose(ahead, graphed, rtol=5e-2, atol=1e-4)
+    with pytest.raises(AssertionError):  # the batch that was marched ahead is the batch the next call must pass
+        tr2.step(*rays[5], tgt[5], next_rays=rays[0])
+        tr2.step(*rays[3], tgt[3])
 
 
 # ------------------------------------------------------------------------------------------------- the march as one call of two launches
