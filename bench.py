@@ -75,6 +75,8 @@ def parse():
                     "a sharded run and a single-rank run of the same global batch only see the same samples without it)")
     ap.add_argument("--bound", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps-per-graph", type=int, default=4, help="1 GPU, march-ahead: consecutive steps recorded into ONE graph (1, 2, 4, 8 or 16; the hand-over "
+                    "between two graph launches idles the device for ~10 us).  Falls back to 1 when --steps is not a multiple of it")
     ap.add_argument("--no-march-ahead", action="store_true", help="1 GPU: march inside the step's one graph instead of one step ahead on a second stream")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
@@ -214,6 +216,12 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # 1 GPU: the march of step k+1 needs nothing from step k (rays and the occupancy grid, not the weights): it is its own graph, replayed
     # on a second stream while step k shades, goes backward and updates -- latency-bound work on otherwise idle issue slots
     march_ahead = use_graph and not split_graph and not args.no_march_ahead
+    # steps per replayed graph (march-ahead mode): the marches of a group run on the second stream under the PREVIOUS group
+    group = 1
+    if march_ahead and args.steps_per_graph in (1, 2, 4, 8, 16):
+        group = args.steps_per_graph
+        while steps % group:  # the timed region must end on a graph boundary
+            group //= 2
     use_amp = dtype in ("fp16", "bf16")
     amp_dtype = torch.bfloat16 if dtype == "bf16" else torch.float16
     fused_opt = dtype == "fp16" and mlp == "ffmlp" and not (args.no_fused_opt or no_ext)
@@ -335,6 +343,21 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 else:
                     mem = gm.pool()
                 marches[g] = (gm, out)  # the sample tensors stay alive: graph A of the slot reads them
+        if march_ahead and group > 1:  # `group` consecutive steps per graph (their marches are the per-slot graphs above)
+            groups = []
+            for g0 in range(0, RING, group):
+                gg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gg, pool=mem, capture_error_mode="thread_local"):
+                    for g in range(g0, g0 + group):
+                        body_fb(g, marches[g][1])
+                        body_opt()
+                mem = gg.pool()
+                groups.append(gg)
+            gstate["graphs"] = [(marches[g][0], None, None, None) for g in range(RING)]
+            gstate["groups"] = groups
+            gstate["marched"] = -1
+            renderer.local_step = 0
+            return
         for g in range(RING):  # one graph per ring slot: static ray batch, static counter slot -> nothing to select or copy per step
             ga = torch.cuda.CUDAGraph()
             if ar_state["in_graph"]:
@@ -373,7 +396,23 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     def graph_step(k):
         g = renderer.local_step
         gm, ga, gb, grads = gstate["graphs"][g]
-        if march_ahead:  # march(g + 1) on the side stream under shade + backward + optimizer(g) on this one
+        if march_ahead and group > 1:  # steps g .. g + group - 1 as one graph; the next group's marches on the side stream beside it
+            if g % group == 0:
+                main = torch.cuda.current_stream()
+                if gstate["marched"] < g + group - 1:  # (first group after a capture: nothing marched ahead)
+                    side_stream.wait_stream(main)
+                    with torch.cuda.stream(side_stream):
+                        for s_ in range(max(gstate["marched"] + 1, g), g + group):
+                            gstate["graphs"][s_][0].replay()
+                    gstate["marched"] = g + group - 1
+                main.wait_stream(side_stream)
+                if g + group < RING:  # not across the ring's end: the mean_count read-back comes first there
+                    with torch.cuda.stream(side_stream):
+                        for s_ in range(g + group, g + 2 * group):
+                            gstate["graphs"][s_][0].replay()
+                    gstate["marched"] = g + 2 * group - 1
+                gstate["groups"][g // group].replay()
+        elif march_ahead:  # march(g + 1) on the side stream under shade + backward + optimizer(g) on this one
             main = torch.cuda.current_stream()
             if gstate["marched"] != g:  # first step of a ring: nothing marched ahead
                 gm.replay()
@@ -413,8 +452,9 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 with torch.cuda.stream(side_stream):
                     ring_end()
                     if not (renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]):
-                        gstate["graphs"][0][0].replay()
-                        gstate["marched"] = 0
+                        for s_ in range(group):
+                            gstate["graphs"][s_][0].replay()
+                        gstate["marched"] = group - 1
             else:
                 ring_end()
             if renderer.mean_count + 128 > gstate["M"] or renderer.mean_count < 0.8 * gstate["M"]:
@@ -509,7 +549,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     res = dict(replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
-                      "two replayed HIP graphs per step: shade + backward + optimizer of step k, and on a second stream the march of step k + 1 (it needs the rays and the occupancy grid, not the weights)" if march_ahead else
+                      (f"replayed HIP graphs: shade + backward + optimizer of {group} consecutive steps per graph, and on a second stream the marches of the next {group} steps (a march needs the rays and the occupancy grid, not the weights)") if march_ahead else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
 
