@@ -717,14 +717,19 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
     __shared__ uint32_t s_off[kRayBlock], s_cnt[kRayBlock];
     const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
-    uint32_t part = 0;
+    uint32_t part = 0, rest = 0;
     for (uint32_t j = threadIdx.x; j < blockIdx.x * ws_per_block; j += kExpandThreads) part += ws[1 + j];  // totals of the rays in front of this block
+    if (fresh)  // ... and of this block and the ones behind it: every block knows the grand total and takes its share of the rows past it
+        for (uint32_t j = blockIdx.x * ws_per_block + threadIdx.x; j < gridDim.x * ws_per_block; j += kExpandThreads) rest += ws[1 + j];
     part = wave_sum(part);
-    if (lane == 0) red[wid] = part;
+    rest = wave_sum(rest);
+    __shared__ uint32_t red_rest[kExpandThreads / kWave];
+    if (lane == 0) { red[wid] = part; red_rest[wid] = rest; }
     __syncthreads();
-    uint32_t before = ws[0];
+    uint32_t before = ws[0], grand = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < kExpandThreads / kWave; i++) before += red[i];
+    for (uint32_t i = 0; i < kExpandThreads / kWave; i++) { before += red[i]; grand += red_rest[i]; }
+    grand += before;
     if (wid == 0) {  // one wave = the 64 rays of this workgroup
         const uint32_t n = blockIdx.x * kRayBlock + lane;
         const uint32_t num_steps = n < N ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
@@ -741,16 +746,22 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
             counter[1] = (fresh ? 0 : counter[1]) + (int)N;
         }
         if (fresh) {
-            // the rows of this block's rays that the drop rule leaves unwritten form one run (offsets only grow): from the first cut
-            // ray's offset to the end of the block's range; the last block adds everything up to M
+            // rows nobody writes: [grand total, M), shared out over all blocks; or, when the budget cuts rays off (then the total is >= M), the
+            // rows of this block's cut rays -- one run (offsets only grow) from the first cut ray's offset to the end of the block's range
             const bool cut = num_steps != 0 && point_index + num_steps >= M;
             const unsigned long long cuts = __ballot(cut);
             const uint32_t first_cut = cuts ? (uint32_t)__shfl(point_index, __ffsll((long long)cuts) - 1) : 0xffffffffu;
             const uint32_t block_end = (uint32_t)__shfl(point_index + num_steps, kWave - 1);
             if (lane == 0) {
-                const bool last = blockIdx.x == gridDim.x - 1;
-                s_zero[0] = cuts ? first_cut : (last ? block_end : 0xffffffffu);
-                s_zero[1] = last ? M : block_end;
+                if (grand < M) {
+                    const uint32_t per = (M - grand + gridDim.x - 1) / gridDim.x;
+                    const uint32_t z0 = grand + blockIdx.x * per;
+                    s_zero[0] = z0 < M ? z0 : M;
+                    s_zero[1] = z0 + per < M ? z0 + per : M;
+                } else {
+                    s_zero[0] = cuts ? first_cut : 0xffffffffu;
+                    s_zero[1] = block_end;
+                }
             }
         }
     }
