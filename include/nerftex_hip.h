@@ -337,6 +337,11 @@ int nerftex_knn_query(const nerftex_knn* knn, const float* xyz, uint32_t N, uint
  * by an upper bound the host already has (the count of the PREVIOUS iteration:
  * alive rays never increase) and the kernels read the true count from the device.
  * Same arithmetic per ray as the three reference-shaped entry points above.
+ * nerftex_march_rays_dev does NOT need zero-filled outputs (the reference-shaped
+ * nerftex_march_rays does, raymarching.py:385-387): it writes position 0 and dt = 0
+ * into the slots a ray leaves unused (compositing stops at the first dt == 0,
+ * raymarching.cu:1076); their dirs and second delta keep whatever the buffer held
+ * and are never read by anything that reaches an output.
  * ------------------------------------------------------------------------- */
 int nerftex_march_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive,
                            const float* rays_t, const float* rays_o, const float* rays_d, float bound, float dt_gamma,

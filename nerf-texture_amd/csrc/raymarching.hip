@@ -1039,6 +1039,15 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
             step++;
         }
     }
+    // device-count form (an extension): the caller's buffers need not be zero-filled.  Compositing stops at the first dt == 0
+    // (raymarching.cu:1076); the slots a ray leaves unused are still rows of the field's batch, so they get the position the zero fill
+    // gave them -- one cell for all of them, L1 hits in the gather -- instead of whatever the buffer held (stale samples: real gathers)
+    if (n_alive_dev)
+        for (; step < n_step; step++) {
+            px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f;
+            pl[0] = 0.0f;
+            px += 3; pl += 2;
+        }
 }
 
 __global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,

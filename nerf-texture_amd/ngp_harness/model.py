@@ -523,6 +523,9 @@ class _InferPart:
         torch.arange(N, out=self.rays_alive[0])
         self.rays_t[0] = self.nears
         self.bound, self.step_no, self.i, self.n_samples = N, 0, 0, 0
+        # the iteration's sample buffers (xyzs | dirs | deltas): bound * n_step <= F N rows whatever the iteration; allocated once and NOT
+        # zero-filled (nerftex_march_rays_dev marks the end of a ray's samples itself)
+        self.buf = torch.empty((N * self.F + 128) * 8, dtype=torch.float32, device=dev)
         # the start jitter of the reference is seeded per ray by its index in the alive list, which for the first iteration is the ray id
         assert not (perturb and ray_base), "perturbed inference: one part only (the jitter is seeded by the position in the alive list)"
         self.perturb_u32 = int(perturb)
@@ -553,8 +556,8 @@ class _InferPart:
         n_step = max(min(F * N // bound, 8 * F), F)
         M = bound * n_step
         M += 128 - M % 128
-        buf = torch.zeros(M * 8, dtype=torch.float32, device=dev)  # the three zero-filled outputs of march_rays (raymarching.py:385-387), one fill
-        xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:].view(M, 2)
+        buf = self.buf  # (the reference zero-fills three fresh tensors per iteration, raymarching.py:385-387)
+        xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:8 * M].view(M, 2)
         check(lib.nerftex_march_rays_dev(bound, ptr(counters[cur:]), n_step, ptr(rays_alive[cur]), ptr(rays_t[cur]), ptr(self.rays_o), ptr(self.rays_d),
                                          float(r.bound), self.dt_gamma, self.max_steps, r.cascade, r.grid_size, ptr(r.density_bitfield), ptr(self.fars),
                                          ptr(xyzs), ptr(dirs), ptr(deltas), self.perturb_u32, stream()))
