@@ -559,3 +559,36 @@ def test_knn_is_exact_on_random_clouds(dev, K, cloud):
         assert lib.nerftex_knn_query(handle, ptr(q), 4, V + 1, ptr(idx), ptr(dis), stream()) == 1  # more neighbours than points (or > 16): invalid
     finally:
         check(lib.nerftex_knn_destroy(handle))
+
+
+def test_device_count_march_needs_no_zero_filled_buffers(dev):
+    """nerftex_march_rays_dev (the sync-free inference loop's march) on buffers full of NaN against the reference-shaped march_rays on
+    zero-filled ones: identical positions and step sizes everywhere, identical directions / second deltas wherever a sample was written
+    (the others are never read: compositing stops at the first dt == 0)."""
+    import raymarching
+    from nerftex_hip import check, lib, ptr, stream
+    from ngp_harness import scene
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    _, _, bits = sc.bitfield()
+    bits = torch.from_numpy(bits).to(dev)
+    o, d = scene.train_batch(5000, seed=31, n_views=3)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    aabb = torch.tensor([-2, -2, -2, 2, 2, 2.0], device=dev)
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+    N, n_step, n_alive = ro.shape[0], 12, 4321
+    alive = torch.randperm(N, generator=torch.Generator().manual_seed(2))[:n_alive].int().to(dev)
+    t = nears[alive.long()].clone()
+    xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive, t, ro, rd, 2.0, bits, sc.cascade, 128, nears, fars, 128, False, 1 / 128, 1024)
+    M = xyzs.shape[0]
+    buf = torch.full((M * 8,), float("nan"), device=dev)
+    x2, d2, l2 = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:].view(M, 2)
+    count = torch.tensor([n_alive], dtype=torch.int32, device=dev)
+    check(lib.nerftex_march_rays_dev(n_alive + 500, ptr(count), n_step, ptr(alive), ptr(t), ptr(ro), ptr(rd), 2.0, 1 / 128, 1024, sc.cascade, 128, ptr(bits),
+                                     ptr(fars), ptr(x2), ptr(d2), ptr(l2), 0, stream()))
+    rows = n_alive * n_step
+    used = deltas[:rows, 0] > 0
+    assert 0.2 < float(used.float().mean()) < 0.98, "some rays fill their slots, some do not"
+    assert torch.equal(x2[:rows], xyzs[:rows]) and torch.equal(l2[:rows, 0], deltas[:rows, 0])
+    assert torch.equal(d2[:rows][used], dirs[:rows][used]) and torch.equal(l2[:rows, 1][used], deltas[:rows, 1][used])
+    assert bool(torch.isnan(x2[rows:]).all()), "rows past the device-side count are not touched"
