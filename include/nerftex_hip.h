@@ -338,7 +338,8 @@ int nerftex_knn_query(const nerftex_knn* knn, const float* xyz, uint32_t N, uint
  * alive rays never increase) and the kernels read the true count from the device.
  * Same arithmetic per ray as the three reference-shaped entry points above.
  * nerftex_march_rays_dev does NOT need zero-filled outputs (the reference-shaped
- * nerftex_march_rays does, raymarching.py:385-387): it writes position 0 and dt = 0
+ * nerftex_march_rays does, raymarching.py:385-387): it writes dt = 0 and a position
+ * far outside the box (1e30: the grid encoder returns zeros for it without a gather)
  * into the slots a ray leaves unused (compositing stops at the first dt == 0,
  * raymarching.cu:1076); their dirs and second delta keep whatever the buffer held
  * and are never read by anything that reaches an output.

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void grid_forward_kernel(const float* __restri
     load_coords<D>(lc, inputs, (size_t)b, x);
 #pragma unroll
     for (int d = 0; d < D; d++)
-        if (x[d] < 0 || x[d] > 1) oob = true;
+        if (!(x[d] >= 0 && x[d] <= 1)) oob = true;  // (written so that a NaN coordinate is out of bounds too, not an index)
 
     for (uint32_t level = 0; level < L; level++) {
         T* out = BLC ? outputs + ((size_t)b * L + level) * C : outputs + ((size_t)level * B + b) * C;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     load_coords<D>(lc, inputs, (size_t)b, x);
 #pragma unroll
     for (int d = 0; d < D; d++)
-        if (x[d] < 0 || x[d] > 1) oob = true;
+        if (!(x[d] >= 0 && x[d] <= 1)) oob = true;  // (written so that a NaN coordinate is out of bounds too, not an index)
     T* out = out_lbc + ((size_t)level * B + b) * C;
     T* dyd = dy_dx + ((size_t)b * L + level) * (D * C);
     if (oob) {

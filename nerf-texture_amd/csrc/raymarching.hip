@@ -1040,11 +1040,12 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
         }
     }
     // device-count form (an extension): the caller's buffers need not be zero-filled.  Compositing stops at the first dt == 0
-    // (raymarching.cu:1076); the slots a ray leaves unused are still rows of the field's batch, so they get the position the zero fill
-    // gave them -- one cell for all of them, L1 hits in the gather -- instead of whatever the buffer held (stale samples: real gathers)
+    // (raymarching.cu:1076); the slots a ray leaves unused are still rows of the field's batch, so they get a position far OUTSIDE the
+    // box: the hash-grid gather answers those with zeros without touching the table (gridencoder.cu:118-130) -- cheaper than the zero
+    // fill's position 0 (sixteen levels of real, if cache-resident, gathers) and far cheaper than whatever the buffer held
     if (n_alive_dev)
         for (; step < n_step; step++) {
-            px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f;
+            px[0] = 1e30f; px[1] = 1e30f; px[2] = 1e30f;
             pl[0] = 0.0f;
             px += 3; pl += 2;
         }

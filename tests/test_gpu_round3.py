@@ -563,8 +563,8 @@ def test_knn_is_exact_on_random_clouds(dev, K, cloud):
 
 def test_device_count_march_needs_no_zero_filled_buffers(dev):
     """nerftex_march_rays_dev (the sync-free inference loop's march) on buffers full of NaN against the reference-shaped march_rays on
-    zero-filled ones: identical positions and step sizes everywhere, identical directions / second deltas wherever a sample was written
-    (the others are never read: compositing stops at the first dt == 0)."""
+    zero-filled ones: identical step sizes everywhere, identical positions / directions / second deltas wherever a sample was written
+    (the other slots are never read: compositing stops at the first dt == 0; they get a position outside the box)."""
     import raymarching
     from nerftex_hip import check, lib, ptr, stream
     from ngp_harness import scene
@@ -589,6 +589,7 @@ def test_device_count_march_needs_no_zero_filled_buffers(dev):
     rows = n_alive * n_step
     used = deltas[:rows, 0] > 0
     assert 0.2 < float(used.float().mean()) < 0.98, "some rays fill their slots, some do not"
-    assert torch.equal(x2[:rows], xyzs[:rows]) and torch.equal(l2[:rows, 0], deltas[:rows, 0])
+    assert torch.equal(x2[:rows][used], xyzs[:rows][used]) and torch.equal(l2[:rows, 0], deltas[:rows, 0])
+    assert bool((x2[:rows][~used] > 1e29).all()), "unused slots: a position outside the box (no table access in the encoder)"
     assert torch.equal(d2[:rows][used], dirs[:rows][used]) and torch.equal(l2[:rows, 1][used], deltas[:rows, 1][used])
     assert bool(torch.isnan(x2[rows:]).all()), "rows past the device-side count are not touched"
