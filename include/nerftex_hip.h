@@ -338,11 +338,12 @@ int nerftex_knn_query(const nerftex_knn* knn, const float* xyz, uint32_t N, uint
  * alive rays never increase) and the kernels read the true count from the device.
  * Same arithmetic per ray as the three reference-shaped entry points above.
  * nerftex_march_rays_dev does NOT need zero-filled outputs (the reference-shaped
- * nerftex_march_rays does, raymarching.py:385-387): it writes dt = 0 and a position
- * far outside the box (1e30: the grid encoder returns zeros for it without a gather)
- * into the slots a ray leaves unused (compositing stops at the first dt == 0,
- * raymarching.cu:1076); their dirs and second delta keep whatever the buffer held
- * and are never read by anything that reaches an output.
+ * nerftex_march_rays does, raymarching.py:385-387): it writes dt = 0, a position far
+ * outside the box (1e30: the grid encoder returns zeros for it without a gather) and
+ * 1e30 as the direction's first component (nerftex_field_forward_rows skips a
+ * wave-step whose 32 rows are all marked like that) into the slots a ray leaves
+ * unused -- compositing stops at the first dt == 0, raymarching.cu:1076; the rest of
+ * those slots keeps whatever the buffer held and reaches no output.
  * ------------------------------------------------------------------------- */
 int nerftex_march_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive,
                            const float* rays_t, const float* rays_o, const float* rays_d, float bound, float dt_gamma,

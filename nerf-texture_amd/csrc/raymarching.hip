@@ -1046,8 +1046,9 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
     if (n_alive_dev)
         for (; step < n_step; step++) {
             px[0] = 1e30f; px[1] = 1e30f; px[2] = 1e30f;
+            pd[0] = 1e30f;  // (what the fused field's inference kernel looks at to skip wave-steps made of unused slots only)
             pl[0] = 0.0f;
-            px += 3; pl += 2;
+            px += 3; pd += 3; pl += 2;
         }
 }
 
