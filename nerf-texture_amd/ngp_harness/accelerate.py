@@ -161,7 +161,9 @@ class AcceleratedTrainer:
                 self._march_ahead(g + 1, next_rays, ready)
         else:
             # one read-back per 16 steps, as in the reference.  Every march of the ring has run by now, so with a second stream at hand the
-            # read-back waits for the marches only, not for this step's backward, and the next ring's first march can go out at once
+            # read-back waits for the marches only, not for this step's backward.  Nothing is marched ahead across the ring's end: that is
+            # where the trainer updates the occupancy grid (nerf/utils.py:1011, before the next step), and a march started here would read
+            # the grid while the update writes it
             if ready is not None:
                 with torch.cuda.stream(self._side_stream()):
                     self._side.wait_event(ready)
@@ -169,8 +171,6 @@ class AcceleratedTrainer:
             else:
                 r.update_mean_count()
             self._resize()
-            if ready is not None and self._graphs is not None:
-                self._march_ahead(0, next_rays, ready)
         return self.loss
 
     def _side_stream(self):
