@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=4, help="1 GPU, march-ahead: consecutive steps recorded into ONE graph (1, 2, 4, 8 or 16; the hand-over "
                     "between two graph launches idles the device for ~10 us).  Falls back to 1 when --steps is not a multiple of it")
+    ap.add_argument("--no-lean-march", action="store_true", help="march-ahead: the count pass at its normal 88 registers instead of the 64-register build "
+                    "(`march_lean` knob) that leaves more of the CU to the step's kernels it runs beside")
     ap.add_argument("--no-march-ahead", action="store_true", help="1 GPU: march inside the step's one graph instead of one step ahead on a second stream")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
@@ -336,8 +338,10 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             mem_m = None                # (N > 1) or while the previous step runs (1 GPU: own memory pool, the two graphs run concurrently)
             for g in range(RING):
                 gm = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gm, pool=mem_m if march_ahead else mem, capture_error_mode="thread_local"):
-                    out = body_march(g)
+                # (march_lean: the count pass compiled for 64 registers -- slower alone, but the step's kernels keep twice the occupancy beside it)
+                with nerftex_hip.tune(march_lean=int(march_ahead and not args.no_lean_march)):
+                    with torch.cuda.graph(gm, pool=mem_m if march_ahead else mem, capture_error_mode="thread_local"):
+                        out = body_march(g)
                 if march_ahead:
                     mem_m = gm.pool()
                 else:

@@ -66,6 +66,7 @@ enum Knob {
     kKnobMarchSerial,    // 1: one-ray-per-lane DDA for the counting pass
     kKnobFfmlpWgPerCu,   // forward: workgroups per CU (0 = default)
     kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
+    kKnobMarchLean,      // 1: the training march's count pass compiled for 64 registers (spills; slower alone, a better neighbour on a shared CU)
     kKnobCount
 };
 extern long g_knobs[kKnobCount];

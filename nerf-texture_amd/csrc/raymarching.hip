@@ -393,7 +393,12 @@ constexpr uint32_t kMcPer = kMcSeg / kMcSub;  // members per thread in phases 2 
 constexpr uint32_t kMcTPitch = kMcRays + 1;  // T[k][ray], +1: conflict-free for both access patterns
 constexpr uint32_t kMcJPitch = kMcSeg + 4;   // jump[ray][k] / visited[ray][k] bytes, +4: rows start in different banks
 
-__global__ __launch_bounds__(kMcThreads) void march_count_parallel_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+// LEAN: compiled for 64 registers instead of 88 (16 of them spill: 82 us alone instead of 68).  A march workgroup then holds half of a
+// SIMD's register file instead of two thirds, and the kernels of another stream that share the CU with it -- the benchmarked step runs the
+// next steps' marches on a second stream -- keep two waves per SIMD where they kept one (the field forward: 44 us under the march instead
+// of 87).  Chosen by the `march_lean` knob at launch (bench.py sets it for the marches it runs ahead).
+template <bool LEAN>
+__global__ __launch_bounds__(kMcThreads, LEAN ? 8 : 4) void march_count_parallel_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                                          const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                                          const float* __restrict__ nears, const float* __restrict__ fars,
@@ -1203,9 +1208,14 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
     }
     if (parallel_count) {
         KernelTimer kt("march_count_parallel_kernel", st);
-        hipLaunchKernelGGL(march_count_parallel_kernel, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                           max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog, aabb, min_near, const_cast<float*>(nears),
-                           const_cast<float*>(fars));
+        if (knob(kKnobMarchLean))
+            hipLaunchKernelGGL(march_count_parallel_kernel<true>, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                               max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog, aabb, min_near, const_cast<float*>(nears),
+                               const_cast<float*>(fars));
+        else
+            hipLaunchKernelGGL(march_count_parallel_kernel<false>, dim3(div_up(N, kMcRays)), dim3(kMcThreads), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
+                               max_steps, N, C, H, nears, fars, rays, counter, ws, perturb, tlog, aabb, min_near, const_cast<float*>(nears),
+                               const_cast<float*>(fars));
     } else {
         KernelTimer kt("march_count_kernel", st);
         hipLaunchKernelGGL(march_count_kernel, dim3(nblocks), dim3(kRayBlock), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
