@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 # MI355X_MICROARCH.md for wide coalesced streams: here the 8-B record stream) + WRITE_SIZE.  Forward: FETCH_SIZE as reported
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
 TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 578.0e6}
+TRAFFIC_PROFILE = "profiles/r03_pmc_grid.txt"
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
@@ -52,7 +53,7 @@ GRID_KERNELS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=208, help="timed steps (default 208 = 13 rings of the 16-entry step-counter ring: ~0.12 s of device time)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--rays", type=int, default=8192, help="rays per batch PER GPU (weak scaling; 8 GPUs x 8192 = configs[4]'s 65536)")
     ap.add_argument("--mlp", choices=["torch", "ffmlp"], default="ffmlp")
@@ -84,6 +85,11 @@ def parse():
     ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
     ap.add_argument("--infer-parts", type=int, default=3, help="ray ranges of the rendered frame, each on its own stream")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--no-replay-profile", action="store_true", help="skip the per-kernel timing of the REPLAYED step (external event-record nodes in a copy of "
+                    "the step's graph, run after the timed region); roofline.avg_launch_ms then comes from eager launches")
+    ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
+    ap.add_argument("--allreduce-chunks", type=int, default=1, help="N > 1: exchange the table gradient as this many level-group chunks, each started as soon "
+                    "as the backward has produced its rows (default 1 = one all-reduce after the backward)")
     return ap.parse_args()
 
 
@@ -359,6 +365,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 groups.append(gg)
             gstate["graphs"] = [(marches[g][0], None, None, None) for g in range(RING)]
             gstate["groups"] = groups
+            gstate["marches"], gstate["pool"] = marches, mem
             gstate["marched"] = -1
             renderer.local_step = 0
             return
@@ -490,13 +497,60 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         nerftex_hip.kernel_profile(2, reset=True)  # hipEvent pairs around the hash-grid kernels only (8 of ~90 launches per step)
     dp.barrier()
     torch.cuda.synchronize()
+    ring_marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps // 16 + 1)]  # one event per 16 steps: the spread of the step time inside the region
     t0 = time.perf_counter()
+    ring_marks[0].record()
     for k in range(steps):
         graph_step(k) if use_graph else train_step(k)
+        if k % 16 == 15:
+            ring_marks[k // 16 + 1].record()
     torch.cuda.synchronize()
     dp.barrier()
     t1 = time.perf_counter()
+    per_ring_ms = [ring_marks[i].elapsed_time(ring_marks[i + 1]) / 16 for i in range(steps // 16)]
+    spread = None
+    if len(per_ring_ms) >= 3:
+        q = sorted(per_ring_ms)
+        spread = {"min": q[0], "median": q[len(q) // 2], "max": q[-1], "rings": len(q),
+                  "note": "ms per step over each 16-step ring of the timed region (device events on the main stream)"}
     samples_timed = torch.tensor(counted["rings"] + partial_ring(), dtype=torch.int64, device=dev)
+    # ---- per-kernel durations INSIDE the replayed step: a copy of the first group's graph recorded with the library's timing on (under capture
+    # the event pairs become external event-record nodes, re-recorded by every replay), replayed in place of the original for a few rings with
+    # the marches on the side stream as in the timed region; read back after each ring.  Outside the timed region (the event nodes cost a
+    # little between kernels).
+    replay_us = {}
+    if time_grid_kernels and use_graph and march_ahead and group > 1 and not args.no_replay_profile:
+        try:
+            torch.cuda.synchronize()
+            while renderer.local_step != 0:
+                graph_step(0)
+            torch.cuda.synchronize()
+            nerftex_hip.kernel_profile(1, reset=True)
+            gp = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gp, capture_error_mode="thread_local"):  # (own memory pool)
+                for g in range(group):
+                    body_fb(g, gstate["marches"][g][1])
+                    body_opt()
+            nerftex_hip.kernel_profile(0)
+            renderer.local_step = 0
+            keep, acc = gstate["groups"][0], {}
+            gstate["groups"][0] = gp
+            for ring in range(6):
+                for k in range(RING):
+                    graph_step(k)
+                torch.cuda.synchronize()
+                for name, v in nerftex_hip.kernel_profile().items():
+                    a = acc.setdefault(name, [0, 0.0])
+                    a[0] += v["calls"]
+                    a[1] += v["total_us"]
+            gstate["groups"][0] = keep
+            replay_us = {k: {"calls": c, "avg_us": t / c, "total_us": t} for k, (c, t) in acc.items() if c}
+            nerftex_hip.kernel_profile(reset=True)
+            del gp
+        except Exception as e:  # noqa: BLE001 -- a side measurement: say so and fall back to the eager figures
+            print(f"[bench] per-kernel timing of the replayed step failed ({type(e).__name__}: {e}); roofline from eager launches", file=sys.stderr)
+            nerftex_hip.kernel_profile(0)
+            replay_us = {}
     kernel_us, all_kernel_us = {}, {}
     if time_grid_kernels:
         if use_graph:  # event pairs cannot be read back from a replayed graph: the same step, launched eagerly, right after the timed region
@@ -550,12 +604,55 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         replicas_identical = bool(torch.equal(lo, hi))
         if not replicas_identical:
             print(f"[bench] rank {rank}: parameter replicas differ across ranks after training", file=sys.stderr)
+    occupancy = None
+    if time_grid_kernels and not args.no_occupancy_timing:
+        occupancy = measure_occupancy_update(renderer, use_amp, amp_dtype, elapsed / steps * 1e3, samples / steps / world)
     res = dict(replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
+               replay_us=replay_us, spread=spread, occupancy=occupancy,
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
                       (f"replayed HIP graphs: shade + backward + optimizer of {group} consecutive steps per graph, and on a second stream the marches of the next {group} steps (a march needs the rays and the occupancy grid, not the weights)") if march_ahead else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
+
+
+def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_per_step, reps=4):
+    """The every-16-steps occupancy-grid update of the trainer (nerf/utils.py:1011 -> nerf/renderer.py:566-660), which the metric excludes
+    and SURVEY 8(d) wants reported separately: Renderer.update_extra_state_device, the full sweep (cascade x 128^3 density queries: the
+    first 16 updates of a run) and the partial update (cascade x 2 x 128^3 / 4: every later one), device time from events.  The grid, the
+    bitfield and the ring are restored afterwards (the rendered frame below uses the analytic occupancy)."""
+    saved = (renderer.density_grid.clone(), renderer.density_bitfield.clone(), renderer.mean_density, renderer.iter_density, renderer.mean_count,
+             renderer.local_step, renderer.step_counter.clone())
+    out = {}
+    try:
+        for name, it in (("full", 0), ("partial", 16)):
+            ms = []
+            for rep in range(reps + 1):
+                renderer.iter_density = it
+                renderer.density_grid.copy_(saved[0])
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                with torch.autocast("cuda", dtype=amp_dtype, enabled=use_amp):
+                    renderer.update_extra_state_device(seed=rep)
+                e1.record()
+                torch.cuda.synchronize()
+                if rep:  # (first repetition: allocator / workspace growth)
+                    ms.append(e0.elapsed_time(e1))
+            out[f"ms_{name}"] = sum(ms) / len(ms)
+    finally:
+        renderer.density_grid.copy_(saved[0])
+        renderer.density_bitfield.copy_(saved[1])
+        renderer.mean_density, renderer.iter_density, renderer.mean_count, renderer.local_step = saved[2:6]
+        renderer.step_counter.copy_(saved[6])
+    cells = renderer.cascade * renderer.grid_size ** 3
+    out["points_full"], out["points_partial"] = cells, cells // 2
+    out["amortised_us_per_step"] = out["ms_partial"] * 1e3 / 16
+    out["ms_per_step_including_update"] = ms_per_step + out["ms_partial"] / 16
+    out["value_including_occupancy_update_per_gpu"] = samples_per_step / (out["ms_per_step_including_update"] * 1e-3)
+    out["note"] = ("update_extra_state every 16 steps (nerf/utils.py:1011), excluded from `value` as SURVEY 8(d) defines the metric; steady state = the partial "
+                   "update; device time of Renderer.update_extra_state_device (occupancy kernels + hash-grid gather + sigma net over the sampled cells)")
+    return out
 
 
 def measure_accelerated(args, mlp, rays, steps, dev, grid):
@@ -664,13 +761,39 @@ WORKLOADS = {
 }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1 and a free port) and hand its exit code back.  Under torchrun (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+
+    share = os.environ.get("NERFTEX_DP_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not share:
+        print(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+              f"NERFTEX_DP_SHARE_GPU=1 runs all ranks on cuda:0 over gloo (a test rig, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer mappings fail with the legacy mode on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 # ----------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
     from ngp_harness import dp, scene
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank, world, local = dp.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -686,32 +809,52 @@ def main():
     s_bytes = 2 if use_amp else 4
     bytes_fwd = 12 + 8 * 16 * 2 * s_bytes + 16 * 2 * s_bytes  # 588 B (fp16) / 1164 B (fp32) per point
     bytes_bwd = 12 + 16 * 2 * s_bytes + 8 * 16 * 2 * s_bytes
-    prof = res["kernel_us"]
-    kern = {}
-    for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
-        parts = {k: prof[k] for k in GRID_KERNELS[name] if k in prof}
-        if parts:
-            calls = max(v["calls"] for v in parts.values())
-            ms = sum(v["total_us"] for v in parts.values()) / calls * 1e-3
-            kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
-                          "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in parts.items()}}
+    def per_op(prof):
+        kern = {}
+        for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
+            parts = {k: prof[k] for k in GRID_KERNELS[name] if k in prof}
+            if parts:
+                calls = max(v["calls"] for v in parts.values())
+                ms = sum(v["total_us"] for v in parts.values()) / calls * 1e-3
+                kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
+                              "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in parts.items()}}
+        return kern
+
+    # durations: from INSIDE the replayed step when they could be taken there (external event-record nodes in a copy of the step's graph, the
+    # next steps' marches running beside it as in the timed region), else from eager launches of the same step after the timed region
+    in_replay = bool(res.get("replay_us"))
+    kern = per_op(res["replay_us"] if in_replay else res["kernel_us"])
+    kern_eager = per_op(res["kernel_us"]) if in_replay else {}
+    # what bounds each op, by the counters: the gather is served by the L2s (94 % hits, 128-B lines for 8-B rows): it sits on the
+    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r03_pmc_sq_grid.txt) -- its algorithmic bytes are
+    # still priced against HBM, the nearest roof the contract names
+    BOUND = {"grid_encode_forward": ("l2_line", "the gather is bound by the L2 -> L1 line bandwidth (9.4x line amplification: 128 B moved per 8 B used, 94 % L2 hits; "
+                                                "profiles/r03_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
+             "grid_encode_backward": ("hbm", "priced against HBM as the contract asks; by the SQ counters both kernels sit on VALU issue (DESIGN.md 4.1)")}
     dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
     roofline = None
     if dominant:
+        for k_, v_ in kern.items():
+            v_["bound"], v_["bound_note"] = BOUND[k_]
+            v_["frac_of_hbm_peak"] = v_["gbs"] / HBM_PEAK_GBS
         roofline = {
-            "bound": "hbm", "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": BOUND[dominant][0], "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dominant),
             "traffic_source": "CONSTANT, not measured in this run: PMC counters need their own rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE over "
-                              "tools/bench_kernels.py at this workload, summary in profiles/r03_pmc_grid.txt; 2 x FETCH_SIZE + WRITE_SIZE as the guide's gfx950 "
+                              "tools/bench_kernels.py at this workload, summary in " + TRAFFIC_PROFILE + "; 2 x FETCH_SIZE + WRITE_SIZE as the guide's gfx950 "
                               "correction prescribes for coalesced streams)",
             "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
             "kernels_avg_us": kern[dominant]["kernels_avg_us"],
+            "durations_from": ("inside the replayed step: a copy of the step's graph recorded with hipEventRecordExternal pairs around every library kernel, "
+                               "replayed for 6 rings right after the timed region with the next steps' marches on the second stream as in the timed region"
+                               if in_replay else "eager launches of the same step after the timed region" if res["graph"] else "the timed region itself"),
+            "eager_avg_launch_ms": kern_eager.get(dominant, {}).get("ms"),
             "other": {k: v for k, v in kern.items() if k != dominant},
-            "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(res["all_kernel_us"].items(), key=lambda kv: -kv[1]["total_us"])},
+            "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted((res["replay_us"] if in_replay else res["all_kernel_us"]).items(),
+                                                                              key=lambda kv: -kv[1]["total_us"])},
+            "all_kernels_avg_us_eager": {k: round(v["avg_us"], 2) for k, v in sorted(res["all_kernel_us"].items(), key=lambda kv: -kv[1]["total_us"])} if in_replay else None,
             "note": "avg_launch_ms = sum of the device durations of the kernels one C-ABI call launches (hipEvent pairs recorded by the library on the "
-                    "launch stream, names = rocprofv3 kernel names)" + ("; the timed region replays a captured graph, whose event pairs cannot be read "
-                    "back, so the pairs come from 16 eager launches of the same step right after it" if res["graph"] else " over the timed region") +
-                    "; the 24 MiB table is Infinity-Cache resident and the gathers are bounded by the divergent-request rate, see DESIGN.md 4/6",
+                    "launch stream, names = rocprofv3 kernel names); the 24 MiB table is Infinity-Cache resident, see DESIGN.md 4/6",
         }
 
     # ---- rendered Mpix/s: one 800x800 frame through the reference's inference loop (nerf/renderer.py:436-487)
@@ -792,6 +935,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"],
+            "ms_per_step_spread": res.get("spread"),
+            "occupancy_update": res.get("occupancy"),
+            "value_including_occupancy_update": (res["occupancy"]["value_including_occupancy_update_per_gpu"] * world) if res.get("occupancy") else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -714,7 +714,9 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
                                                            const float* __restrict__ nears, float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas, float* __restrict__ rays_ts, int* __restrict__ rays,
                                                            int* __restrict__ counter, const uint32_t* __restrict__ ws, uint32_t perturb,
-                                                           const float* __restrict__ tlog, uint32_t ws_per_block, uint32_t fresh) {
+                                                           const float* __restrict__ tlog, uint32_t ws_per_block, uint32_t n_totals, uint32_t fresh) {
+    // n_totals: how many workgroup totals the count pass wrote (div_up(N, rays per count workgroup)); gridDim.x * ws_per_block may exceed it by one
+    // when N % 64 is in [1, 32] -- that word was never written
     // fresh (nerftex_march_rays_train_fresh): the counter is OVERWRITTEN (taken as zero at entry) and the sample rows nobody writes -- the
     // ranges of the rays the drop rule below cuts, and [total, M) -- are zeroed here: the caller's buffers may arrive uninitialised
     __shared__ uint32_t red[kExpandThreads / kWave];
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
     uint32_t part = 0, rest = 0;
     for (uint32_t j = threadIdx.x; j < blockIdx.x * ws_per_block; j += kExpandThreads) part += ws[1 + j];  // totals of the rays in front of this block
     if (fresh)  // ... and of this block and the ones behind it: every block knows the grand total and takes its share of the rows past it
-        for (uint32_t j = blockIdx.x * ws_per_block + threadIdx.x; j < gridDim.x * ws_per_block; j += kExpandThreads) rest += ws[1 + j];
+        for (uint32_t j = blockIdx.x * ws_per_block + threadIdx.x; j < n_totals; j += kExpandThreads) rest += ws[1 + j];
     part = wave_sum(part);
     rest = wave_sum(rest);
     __shared__ uint32_t red_rest[kExpandThreads / kWave];
@@ -1228,7 +1230,7 @@ int march_train_impl(const float* rays_o, const float* rays_d, const uint8_t* gr
             KernelTimer kt("march_expand_kernel", st);
             hipLaunchKernelGGL((march_expand_kernel<WITH_TS>), dim3(nblocks), dim3(kExpandThreads), 0, st, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
                                nears, xyzs, dirs, deltas, rays_ts, rays, counter, ws, perturb, tlog, parallel_count ? kRayBlock / kMcRays : 1u,
-                               aabb ? 1u : 0u);
+                               parallel_count ? div_up(N, kMcRays) : nblocks, aabb ? 1u : 0u);
         }
         return check_launch("march_rays_train(expand)");
     }

@@ -133,16 +133,26 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
+// A stream under capture: the pair goes into the graph as EXTERNAL event-record nodes (hipEventRecordExternal), so every replay of the graph
+// re-records both events and nerftex_profile_report() reads the durations of the LAST replay -- per-kernel timing of a replayed step, beside
+// whatever else runs on the device then (bench.py: roofline.avg_launch_ms).  Outside a capture: plain records, one span per launch.
+void record(hipEvent_t ev, hipStream_t st) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        (void)hipEventRecordWithFlags(ev, st, hipEventRecordExternal);
+    else
+        (void)hipEventRecord(ev, st);
+}
 void profile_begin(const char* name, hipStream_t st, int* slot) {
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     Span sp{name, take_event(), take_event()};
-    (void)hipEventRecord(sp.a, st);
+    record(sp.a, st);
     g_spans.push_back(sp);
     *slot = (int)g_spans.size() - 1;
 }
 void profile_end(hipStream_t st, int slot) {
     std::lock_guard<std::mutex> lock(g_profile_mutex);
-    if (slot >= 0 && slot < (int)g_spans.size()) (void)hipEventRecord(g_spans[slot].b, st);
+    if (slot >= 0 && slot < (int)g_spans.size()) record(g_spans[slot].b, st);
 }
 
 }  // namespace nerftex

@@ -115,7 +115,10 @@ class AcceleratedTrainer:
         next_rays = (rays_o, rays_d) of the batch the NEXT call will pass: its march starts now, beside this step (module docstring).
         Returns the loss as a device scalar that the NEXT call overwrites."""
         r = self.renderer
+        # contiguous views: the hand-over of `next_rays` is recognised by the address of these tensors (a reshape of a non-contiguous
+        # tensor would be a fresh copy with a fresh address every call)
         rays_o, rays_d, target = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), target.reshape(-1, 3)
+        assert rays_o.is_contiguous() and rays_d.is_contiguous(), "accelerate().step: rays_o / rays_d must be contiguous [N,3] tensors"
         if self._rays is None:
             self.n_rays = rays_o.shape[0]
             self._rays = [(torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev), torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev))
@@ -144,7 +147,10 @@ class AcceleratedTrainer:
         if self._ahead is not None and self._ahead == (g, rays_o.data_ptr(), rays_d.data_ptr()):
             main.wait_stream(self._side)  # marched beside the previous step
         else:
-            assert self._ahead is None, "next_rays of the previous call must be the rays of this call (same tensors)"
+            if self._ahead is not None:  # the march that ran ahead was of other tensors: forget it (the next call starts clean), then refuse
+                self._ahead = None
+                main.wait_stream(self._side)
+                raise AssertionError("next_rays of the previous call must be the rays of this call (same tensors)")
             self._rays[g][0].copy_(rays_o, non_blocking=True), self._rays[g][1].copy_(rays_d, non_blocking=True)
             gm.replay()
         self._ahead = None
@@ -181,6 +187,7 @@ class AcceleratedTrainer:
     def _march_ahead(self, slot, next_rays, ready):
         no, nd = next_rays[0].reshape(-1, 3), next_rays[1].reshape(-1, 3)
         assert no.shape[0] == self.n_rays
+        assert next_rays[0].is_contiguous() and next_rays[1].is_contiguous(), "next_rays must be contiguous (they are recognised by address in the next call)"
         with torch.cuda.stream(self._side_stream()):
             self._side.wait_event(ready)
             self._rays[slot][0].copy_(no, non_blocking=True), self._rays[slot][1].copy_(nd, non_blocking=True)

@@ -279,7 +279,13 @@ class _composite_tail(Function):
             return (None,) * 10
         bg, loss_mul = ctx.consts
         M, N = sigmas.shape[0], rays.shape[0]
+        if N == 0 or M == 0:
+            return torch.zeros_like(sigmas), torch.zeros_like(rgbs), None, None, None, None, None, None, None, None
         grad_scaled = grad_scaled.contiguous().float()
+        # PRECONDITION of the uninitialised gradient buffers below: `rays` are the records of THIS library's march with the counter at zero
+        # on entry (march_rays_train / march_rays_train_fresh: record n = ray n, offsets an exclusive prefix sum from 0), so that the rows past
+        # rays[N-1].offset + count are exactly the rows no ray covers -- the kernel zeroes those.  Records from anywhere else (a non-zero
+        # starting counter, another order): use raymarching.composite_rays_train + render_tail, whose backward takes zero-filled buffers.
         # rows the rays do not cover (the tail of a buffer sized by the mean count) get no gradient: zeros, like the reference's buffers --
         grads = torch.empty(4 * M, dtype=torch.float32, device=sigmas.device)  # (zeroed where no ray writes by the launch itself)
         grad_sigmas, grad_rgbs = grads[:M], grads[M:].view(M, 3)

@@ -59,9 +59,10 @@ class _SplitKLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gy @ weight.to(gy.dtype)
         if ctx.needs_input_grad[1]:
-            B = x.shape[0]
+            # any leading dimensions, like nn.Linear: [..., in] x [..., out] -> [out, in]
+            x2, g2 = x.reshape(-1, x.shape[-1]).to(gy.dtype), gy.reshape(-1, gy.shape[-1])
+            B = x2.shape[0]
             chunk = next((c for c in (1024, 512, 256, 128) if B % c == 0 and B >= 8 * c), 0)
-            x2, g2 = x.reshape(B, -1).to(gy.dtype), gy.reshape(B, -1)
             if chunk:
                 parts = torch.bmm(g2.view(B // chunk, chunk, -1).transpose(1, 2), x2.view(B // chunk, chunk, -1))
                 gw = parts.sum(0, dtype=torch.float32).to(weight.dtype)

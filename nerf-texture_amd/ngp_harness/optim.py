@@ -24,6 +24,13 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _poll_deferred_error():
+    """A hash-grid backward whose level table no longer matched its registration wrote NO gradient and left a deferred error
+    (include/nerftex_hip.h, nerftex_deferred_error): raise it HERE, before the update consumes that gradient tensor (a host read of one
+    pinned word; an eager step sees a launch of an earlier step at the latest -- the launches of this step may still be in flight)."""
+    check(lib.nerftex_deferred_error())
+
+
 _ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                             decoupled_weight_decay=False)
 
@@ -125,6 +132,7 @@ class HalfLeafAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         """torch.optim protocol (plain, or driven by torch.amp.GradScaler through grad_scale / found_inf)."""
         assert closure is None
+        _poll_deferred_error()
         grad_scale = getattr(self, "grad_scale", None)
         found_inf = getattr(self, "found_inf", None)
         self.step_count += 1
@@ -174,6 +182,7 @@ class FusedAmp:
 
     @torch.no_grad()
     def step(self):
+        _poll_deferred_error()
         grads = [leaf.grad for leaf in self.opt.leaves if leaf.grad is not None]
         if grads:
             self._check(grads)

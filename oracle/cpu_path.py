@@ -8,7 +8,8 @@ The reference's CALLERS of the hot path, restated for the CPU over the oracle's 
   * `Renderer.run`  -- nerf/renderer.py:187-322: uniform samples in [near, far], optional sample_pdf upsampling, exp / cumprod
     compositing.  This is BASELINE.json configs[0], "the reference's pure-PyTorch CPU path" (SURVEY.md 8(d)): the reference has
     no CPU build of its native ops, so G1 / S1 / R1 come from the oracle;
-  * `Renderer.run_cuda_train`  -- nerf/renderer.py:361-425, one training render (march, field, composite).
+  * `Renderer.run_cuda_train`  -- nerf/renderer.py:361-425, one training render (march, field, composite);
+  * `Renderer.run_cuda_infer`  -- nerf/renderer.py:436-487, the inference loop (compact, march, field, composite until no ray is alive).
 
 Pinned: tests/test_reference_python_cpu.py compares all of it with fixtures produced by RUNNING the reference's own modules
 (tools/make_golden.py -> tests/golden/ref_python_run.npz, ref_python_run_cuda.npz, ref_host_pieces.npz).
@@ -318,6 +319,47 @@ class Renderer:
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth, counter
+
+
+    @torch.no_grad()
+    def run_cuda_infer(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, perturb=False, max_steps=1024):
+        """nerf/renderer.py:436-487 (inference branch of run_cuda: compact -> march n_step samples per alive ray -> field -> composite,
+        until no ray is alive), with the wrappers' allocation rules (raymarching/raymarching.py:378-388: M padded to 128, zero-filled).
+        Returns image, depth (un-normalised, as the reference leaves it), sample slots evaluated."""
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        nears, fars = self.near_far(rays_o, rays_d)
+        weights_sum, depth, image = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+        n_alive = N
+        alive_counter = torch.zeros(1, dtype=torch.int32)
+        rays_alive = torch.zeros(2, N, dtype=torch.int32)
+        rays_t = torch.zeros(2, N)
+        step = i = slots = 0
+        while step < max_steps:
+            if step == 0:
+                rays_alive[0] = torch.arange(N, dtype=torch.int32)
+                rays_t[0] = nears
+            else:
+                alive_counter.zero_()
+                be.Raymarching.compact_rays(n_alive, rays_alive[i % 2], rays_alive[(i + 1) % 2], rays_t[i % 2], rays_t[(i + 1) % 2], alive_counter)
+                n_alive = int(alive_counter.item())
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            M = n_alive * n_step
+            M += 128 - M % 128
+            xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+            be.Raymarching.march_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], rays_o, rays_d, self.bound, dt_gamma, max_steps, self.cascade, 128,
+                                      self.density_bitfield, nears, fars, xyzs, dirs, deltas, perturb)
+            sigmas, rgbs = self.field(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            be.Raymarching.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], sigmas.float().contiguous(), rgbs.float().contiguous(), deltas,
+                                          weights_sum, depth, image)
+            slots += M
+            step += n_step
+            i += 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return image, depth, slots
 
 
 class _CompositeTrain(Function):  # raymarching/raymarching.py:296-352

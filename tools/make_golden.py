@@ -499,11 +499,13 @@ def reference_python_goldens():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    if "--round3-only" not in sys.argv:
+    if "--round3-only" not in sys.argv and "--round4-only" not in sys.argv:
         sh_golden()
         module_goldens()
         reference_python_goldens()
-    round3_goldens()
+    if "--round4-only" not in sys.argv:
+        round3_goldens()
+    round4_goldens()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -748,6 +750,78 @@ def round3_goldens():
 
     new = subprocess.run(["find", REF, "-newer", os.path.join(OUT, "..", "..", "BASELINE.json"), "-type", "f"], capture_output=True, text=True).stdout.strip()
     assert new == "", "files appeared under the reference tree:\n" + new
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 4: the whole chain in fp32, NO autocast -- the configuration north_star's "within 1e-4 rel on rendered RGB / sigma" is about
+# ---------------------------------------------------------------------------------------------------------------------------
+def round4_goldens():
+    """nerf/network.py:96-124 (nn.Linear MLPs, fp32) through nerf/renderer.py:338-425 (training branch of run_cuda, with backward) and
+    :436-487 (its inference loop), executed WITHOUT autocast: fp32 table, fp32 SH, fp32 MLPs, fp32 compositing.  512 rays each.  Besides the
+    images the fixture keeps the per-sample sigma / rgb the network returned for the training render (first 8192 samples), the ray records,
+    and fp32 gradients (weights, 2048 sampled table rows, per-level L1)."""
+    import torch
+
+    install_reference_imports()
+    from nerf.network import NeRFNetwork as RefLinearNetwork
+
+    class LinearNetwork(RefLinearNetwork):
+        """The same call bridge as in round3_goldens (the renderer passes keywords and unpacks three values); it also keeps what the
+        network returned, so that sigma / rgb can be pinned per sample."""
+
+        def forward(self, x, d, **kwargs):
+            sigma, color = RefLinearNetwork.forward(self, x, d)
+            self.last_xyz, self.last_sigma, self.last_color = x.detach(), sigma.detach(), color.detach()
+            return sigma, color, {}
+
+    bound = 2
+    torch.manual_seed(0)
+    model = LinearNetwork(bound=bound, cuda_ray=True, min_near=0.2, density_thresh=10)
+    _table(model, 5)
+    grid, bits = _scene_bitfield(bound, model.cascade)
+    model.density_grid.copy_(grid)
+    model.density_bitfield = bits
+    with torch.no_grad():  # nn.Linear's default init leaves sigma = exp(h0) within 0.9 .. 1.15: widen the sigma row so that densities span decades
+        model.sigma_net[-1].weight[0] *= 40.0
+    ro, rd = _rays(512, 61)
+    tgt = np.random.default_rng(62).uniform(0, 1, (512, 3)).astype(np.float32)
+    out = {"bitfield": bits.numpy(), "rays_o": ro, "rays_d": rd, "target": tgt, "table_seed": 5, "bound": bound}
+    for i, l in enumerate(model.sigma_net):
+        out[f"w_sigma_{i}"] = l.weight.detach().numpy().copy()
+    for i, l in enumerate(model.color_net):
+        out[f"w_color_{i}"] = l.weight.detach().numpy().copy()
+    model.train()
+    assert not torch.is_autocast_enabled("cuda") and not torch.is_autocast_enabled("cpu")
+    res = model.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], staged=False, bg_color=1, perturb=True, force_all_rays=False,
+                       dt_gamma=1 / 128, max_steps=1024)
+    assert res["image"].dtype == torch.float32 and model.last_sigma.dtype == torch.float32
+    loss = torch.nn.functional.mse_loss(res["image"][0], torch.from_numpy(tgt))
+    loss.backward()
+    m = int(model.step_counter[0, 0])
+    keep = min(m, 8192)
+    g = model.encoder.embeddings.grad
+    assert g.dtype == torch.float32
+    nz = torch.nonzero(g.abs().sum(-1)).squeeze(-1)
+    pick = nz[torch.from_numpy(np.random.default_rng(63).choice(nz.numel(), 2048, replace=False)).long()]
+    off = model.encoder.offsets.long()
+    out.update(train_image=res["image"][0].detach().numpy(), train_depth=res["depth"][0].detach().numpy(),
+               train_counter=model.step_counter[0].numpy().copy(), train_loss=float(loss),
+               train_xyz=model.last_xyz[:keep].numpy(), train_sigma=model.last_sigma[:keep].numpy(), train_rgb=model.last_color[:keep].numpy(),
+               g_table_rows=pick.numpy(), g_table_vals=g[pick].numpy(), g_table_nonzero_rows=int(nz.numel()),
+               g_table_level_abs=np.array([float(g[off[l]:off[l + 1]].abs().double().sum()) for l in range(16)]))
+    for i, l in enumerate(model.sigma_net):
+        out[f"g_sigma_{i}"] = l.weight.grad.numpy().copy()
+    for i, l in enumerate(model.color_net):
+        out[f"g_color_{i}"] = l.weight.grad.numpy().copy()
+    model.eval()
+    ro2, rd2 = _rays(512, 71)
+    with torch.no_grad():
+        res = model.render(torch.from_numpy(ro2)[None], torch.from_numpy(rd2)[None], staged=False, bg_color=1, perturb=False, dt_gamma=1 / 128,
+                           max_steps=1024)
+    out.update(infer_rays_o=ro2, infer_rays_d=rd2, infer_image=res["image"][0].numpy(), infer_depth=res["depth"][0].numpy())
+    np.savez_compressed(os.path.join(OUT, "ref_python_run_cuda_fp32.npz"), **out)
+    print("ref_python_run_cuda_fp32.npz: train", m, "samples /", int(out["train_counter"][1]), "rays; loss", out["train_loss"],
+          "sigma range", float(out["train_sigma"].min()), float(out["train_sigma"].max()))
 
 
 if __name__ == "__main__":
