@@ -41,6 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
 TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 578.0e6}
 TRAFFIC_PROFILE = "profiles/r03_pmc_grid.txt"
+COMMITTED_STATS = "profiles/r04_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
@@ -85,8 +86,8 @@ def parse():
     ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
     ap.add_argument("--infer-parts", type=int, default=3, help="ray ranges of the rendered frame, each on its own stream")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
-    ap.add_argument("--no-replay-profile", action="store_true", help="skip the per-kernel timing of the REPLAYED step (external event-record nodes in a copy of "
-                    "the step's graph, run after the timed region); roofline.avg_launch_ms then comes from eager launches")
+    ap.add_argument("--no-replay-profile", action="store_true", help="skip the per-kernel timing of the REPLAYED step (a child run of this script under "
+                    "rocprofv3 --kernel-trace --stats, ~40 s); roofline.avg_launch_ms then comes from the committed profile or from eager launches")
     ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
     ap.add_argument("--allreduce-chunks", type=int, default=1, help="N > 1: exchange the table gradient as this many level-group chunks, each started as soon "
                     "as the backward has produced its rows (default 1 = one all-reduce after the backward)")
@@ -178,7 +179,7 @@ def cpu_baseline(args, bits, n_rays):
 def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid, bits, time_grid_kernels, graph=False, dtype=None, dropin_only=False):
     """K timed training steps of one configuration. Returns (result dict, field, renderer).
     dtype: "fp16" | "bf16" | "fp32" (default args.dtype).  bf16 = bf16 autocast with the FFMLPs on their bf16 kernels (the hash table is
-    narrowed to fp16 under any autocast, gridencoder/grid.py:41), no loss scaling, torch's fused Adam.
+    narrowed to fp16 under any autocast, gridencoder/grid.py:41), GradScaler (the table gradient is fp16), torch's fused Adam.
     dropin_only: the reference's callers unchanged -- eager launches, no field glue / render tail kernels, torch.optim.Adam + GradScaler."""
     dtype = dtype or args.dtype
     no_ext = dropin_only
@@ -253,7 +254,11 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     inv_world = 1.0 / world
     # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
     amp = FusedAmp(opt) if fused_amp else None
-    scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=dtype == "fp16")
+    if amp is not None and world == 1 and field.fused_field:
+        amp.attach(field.encoder)  # the non-finite scan rides on the kernels that write the gradients (N > 1: the scan must see the cross-rank sum)
+    # bf16 keeps the loss scaler: the hash table -- and so its gradient -- is fp16 under ANY autocast (gridencoder/grid.py:41), and unscaled
+    # gradients of ~1e-6 sit in fp16's subnormal range (measured: 38 % L1 error of the table gradient without scaling, tools/precision_table.py)
+    scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=dtype in ("fp16", "bf16"))
     one = torch.ones((), dtype=torch.float32, device=dev)  # root gradient, so that autograd does not fill one per step
 
     def march(ro, rd, **kw):
@@ -514,43 +519,12 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         spread = {"min": q[0], "median": q[len(q) // 2], "max": q[-1], "rings": len(q),
                   "note": "ms per step over each 16-step ring of the timed region (device events on the main stream)"}
     samples_timed = torch.tensor(counted["rings"] + partial_ring(), dtype=torch.int64, device=dev)
-    # ---- per-kernel durations INSIDE the replayed step: a copy of the first group's graph recorded with the library's timing on (under capture
-    # the event pairs become external event-record nodes, re-recorded by every replay), replayed in place of the original for a few rings with
-    # the marches on the side stream as in the timed region; read back after each ring.  Outside the timed region (the event nodes cost a
-    # little between kernels).
+    # ---- per-kernel durations INSIDE the replayed step.  hipEvent pairs cannot be read back from a replayed graph (and external event-record
+    # nodes fail to capture on this stack), so this very script runs once more as a child under `rocprofv3 --kernel-trace --stats`: same
+    # workload, same graphs, the marches of the next steps on the second stream -- the device durations rocprofv3 reports are the replay's own.
     replay_us = {}
-    if time_grid_kernels and use_graph and march_ahead and group > 1 and not args.no_replay_profile:
-        try:
-            torch.cuda.synchronize()
-            while renderer.local_step != 0:
-                graph_step(0)
-            torch.cuda.synchronize()
-            nerftex_hip.kernel_profile(1, reset=True)
-            gp = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gp, capture_error_mode="thread_local"):  # (own memory pool)
-                for g in range(group):
-                    body_fb(g, gstate["marches"][g][1])
-                    body_opt()
-            nerftex_hip.kernel_profile(0)
-            renderer.local_step = 0
-            keep, acc = gstate["groups"][0], {}
-            gstate["groups"][0] = gp
-            for ring in range(6):
-                for k in range(RING):
-                    graph_step(k)
-                torch.cuda.synchronize()
-                for name, v in nerftex_hip.kernel_profile().items():
-                    a = acc.setdefault(name, [0, 0.0])
-                    a[0] += v["calls"]
-                    a[1] += v["total_us"]
-            gstate["groups"][0] = keep
-            replay_us = {k: {"calls": c, "avg_us": t / c, "total_us": t} for k, (c, t) in acc.items() if c}
-            nerftex_hip.kernel_profile(reset=True)
-            del gp
-        except Exception as e:  # noqa: BLE001 -- a side measurement: say so and fall back to the eager figures
-            print(f"[bench] per-kernel timing of the replayed step failed ({type(e).__name__}: {e}); roofline from eager launches", file=sys.stderr)
-            nerftex_hip.kernel_profile(0)
-            replay_us = {}
+    if time_grid_kernels and use_graph and world == 1 and not args.no_replay_profile:
+        replay_us = rocprof_replay(args, mlp, rays, dtype)
     kernel_us, all_kernel_us = {}, {}
     if time_grid_kernels:
         if use_graph:  # event pairs cannot be read back from a replayed graph: the same step, launched eagerly, right after the timed region
@@ -614,6 +588,70 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                       (f"replayed HIP graphs: shade + backward + optimizer of {group} consecutive steps per graph, and on a second stream the marches of the next {group} steps (a march needs the rays and the occupancy grid, not the weights)") if march_ahead else
                       "one replayed HIP graph per step") if use_graph else "", dt_gamma=dt_gamma, n_global=n_global)
     return res, field, renderer
+
+
+def _short_kernel_name(name):
+    """rocprofv3 kernel name (mangled or demangled) -> the library's kernel name."""
+    import re
+
+    m = re.search(r"\d+([a-z_0-9]+_kernel)", name) if name.startswith("_Z") else re.search(r"(\w+_kernel)", name)
+    return m.group(1) if m else name[:60]
+
+
+def read_kernel_stats(path):
+    """A rocprofv3 `*_kernel_stats.csv` -> {kernel: {"calls", "avg_us", "total_us"}} (template instantiations of one kernel added up)."""
+    import csv
+
+    out = {}
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            k = _short_kernel_name(row["Name"])
+            e = out.setdefault(k, {"calls": 0, "total_us": 0.0})
+            e["calls"] += int(row["Calls"])
+            e["total_us"] += float(row["TotalDurationNs"]) * 1e-3
+    for e in out.values():
+        e["avg_us"] = e["total_us"] / max(e["calls"], 1)
+    return out
+
+
+def rocprof_replay(args, mlp, rays, dtype, steps=416):
+    """This benchmark's training leg again, as a child process under rocprofv3 (kernel trace + stats): the per-kernel device durations of the
+    replayed step, with whatever runs beside each kernel in the replay.  416 replayed steps against ~20 eager ones (priming, warm-up: they are
+    in the averages too, < 5 %).  {} when rocprofv3 is missing or the child fails (the caller falls back and says so)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        print("[bench] rocprofv3 not found: no per-kernel timing of the replayed step", file=sys.stderr)
+        return {}
+    tmp = tempfile.mkdtemp(prefix="nerftex_prof_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
+               "--steps", str(steps), "--warmup", str(args.warmup), "--rays", str(rays), "--mlp", mlp, "--dtype", dtype, "--bound", str(args.bound),
+               "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer", "--no-kernel-timing"]
+        for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb"):
+            if getattr(args, flag):
+                cmd.append("--" + flag.replace("_", "-"))
+        env = dict(os.environ, TMPDIR="/tmp")
+        env.pop("WORLD_SIZE", None)
+        run = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if run.returncode != 0 or not files:
+            print(f"[bench] rocprofv3 child failed (rc {run.returncode}): {run.stderr[-400:]}", file=sys.stderr)
+            return {}
+        out = read_kernel_stats(files[0])
+        child = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        if child:
+            out["_child"] = {"ms_per_step": json.loads(child[-1])["ms_per_step"], "steps": steps}
+        return out
+    except Exception as e:  # noqa: BLE001 -- a side measurement
+        print(f"[bench] rocprofv3 child failed ({type(e).__name__}: {e})", file=sys.stderr)
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_per_step, reps=4):
@@ -822,7 +860,15 @@ def main():
 
     # durations: from INSIDE the replayed step when they could be taken there (external event-record nodes in a copy of the step's graph, the
     # next steps' marches running beside it as in the timed region), else from eager launches of the same step after the timed region
-    in_replay = bool(res.get("replay_us"))
+    replay_us = dict(res.get("replay_us") or {})
+    child = replay_us.pop("_child", None)
+    source = "rocprofv3 --kernel-trace --stats over a child run of this script (same workload, %d replayed steps, child ms_per_step %.4f)" % (
+        child["steps"], child["ms_per_step"]) if child else None
+    if not replay_us and res["graph"] and os.path.exists(os.path.join(ROOT, COMMITTED_STATS)):  # no live profile: the committed one, labelled
+        replay_us = read_kernel_stats(os.path.join(ROOT, COMMITTED_STATS))
+        source = "CONSTANT from " + COMMITTED_STATS + " (rocprofv3 of the same command, committed): no live rocprofv3 run in this invocation"
+    res["replay_us"] = replay_us
+    in_replay = bool(replay_us)
     kern = per_op(res["replay_us"] if in_replay else res["kernel_us"])
     kern_eager = per_op(res["kernel_us"]) if in_replay else {}
     # what bounds each op, by the counters: the gather is served by the L2s (94 % hits, 128-B lines for 8-B rows): it sits on the
@@ -845,9 +891,8 @@ def main():
                               "correction prescribes for coalesced streams)",
             "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
             "kernels_avg_us": kern[dominant]["kernels_avg_us"],
-            "durations_from": ("inside the replayed step: a copy of the step's graph recorded with hipEventRecordExternal pairs around every library kernel, "
-                               "replayed for 6 rings right after the timed region with the next steps' marches on the second stream as in the timed region"
-                               if in_replay else "eager launches of the same step after the timed region" if res["graph"] else "the timed region itself"),
+            "durations_from": ("the replayed step: " + source if in_replay else
+                               "eager launches of the same step after the timed region (hipEvent pairs)" if res["graph"] else "the timed region itself (hipEvent pairs)"),
             "eager_avg_launch_ms": kern_eager.get(dominant, {}).get("ms"),
             "other": {k: v for k, v in kern.items() if k != dominant},
             "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted((res["replay_us"] if in_replay else res["all_kernel_us"]).items(),
@@ -900,7 +945,7 @@ def main():
                 # the step the UNMODIFIED reference callers would run: drop-in packages only, eager launches, torch.optim.Adam + GradScaler
                 ("configs[2] through the drop-in API only (reference callers unchanged: no graph, no field-glue / render-tail kernels, torch Adam + GradScaler)",
                  "ffmlp", 8192, "fp16", True, False),
-                ("configs[2] with bf16 FFMLPs (bf16 autocast, torch fused Adam, no loss scaling), one replayed HIP graph per step", "ffmlp", 8192, "bf16", False, True)]
+                ("configs[2] with bf16 FFMLPs (bf16 autocast, torch fused Adam + GradScaler: the table gradient stays fp16), one replayed HIP graph per step", "ffmlp", 8192, "bf16", False, True)]
         for label, mlp_k, rays_k, dt_k, dropin, graph_k in runs:
             r2, _, _ = measure_training(args, mlp_k, rays_k, 16, 16, dev, rank, world, sc, grid, bits, False, graph=graph_k, dtype=dt_k, dropin_only=dropin)
             other.append({"workload": label if "configs[2]" in label and len(label) > 12 else WORKLOADS[mlp_k], "rays_per_batch": rays_k, "dtype": dt_k,

@@ -276,6 +276,26 @@ int nerftex_field_backward(const float* grad_sigma, const float* grad_rgbs, cons
                            const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                            void* grad_x, void* grad_sigma_weights, void* grad_color_weights, void* stream);
 
+/* Extension (round 4): GradScaler's non-finite scan (torch/amp/grad_scaler.py `_unscale_grads_` -> found_inf; the reference trainer's
+ * scaler.step, nerf/utils.py:1005-1009) done by the kernels that WRITE the gradients instead of by a pass that re-reads them:
+ * the same calls as nerftex_field_backward / nerftex_grid_encode_backward_affine, and *found_inf (a device float) is set to 1.0f when an
+ * element of grad_sigma_weights / grad_color_weights, resp. of grad_embeddings, comes out inf or nan.  Never cleared here (the
+ * optimizer step clears it: nerftex_adam_half_step_amp); found_inf NULL = the plain call.  Paths of the hash-grid backward whose
+ * stores cannot carry the test (small batches: atomics) scan the finished table in one more launch -- the contract holds for all. */
+int nerftex_field_backward_amp(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                               const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                               void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream);
+int nerftex_grid_encode_backward_amp(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                     void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                     int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                     int dtype, int layout, float in_add, float in_mul, float* found_inf, void* stream);
+
+/* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
+ * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).
+ *   feats_lbc [16, B, 2] half (nerftex_grid_encode_forward*, NERFTEX_LAYOUT_LBC), sigma_weights as nerftex_field_forward's,
+ *   sigma [B] float out.  Same values as nerftex_field_forward's sigma.  B % 128 == 0; fp16 only. */
+int nerftex_field_density(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream);
+
 
 /* ------------------------------------------------------------------------- *
  * Extension (the sync-free inference loop): the two field launches of

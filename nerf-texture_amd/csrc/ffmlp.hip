@@ -84,11 +84,20 @@ extern "C" int nerftex_field_forward(const void* feats_lbc, const float* dirs, c
                                      float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream) {
     return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, x_rows, h, cin, hc, nullptr, 0, stream);
 }
+extern "C" int nerftex_field_density(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream) {
+    return ffmlp_f16::field_density_entry(feats_lbc, sigma_weights, B, sigma, stream);
+}
 extern "C" int nerftex_field_backward(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin, const void* x_rows,
                                       const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin, void* grad_x,
                                       void* grad_sigma_weights, void* grad_color_weights, void* stream) {
     return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
-                                           grad_sigma_weights, grad_color_weights, stream);
+                                           grad_sigma_weights, grad_color_weights, nullptr, stream);
+}
+extern "C" int nerftex_field_backward_amp(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin, const void* x_rows,
+                                          const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin, void* grad_x,
+                                          void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream) {
+    return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                           grad_sigma_weights, grad_color_weights, found_inf, stream);
 }
 extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
                                           float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {

@@ -24,6 +24,9 @@ struct LevelConsts {
     // optional: only the first units_dev[0] * rows_per_unit points carry anything (a launch sized by an upper bound of a device-side count)
     const int32_t* units_dev;
     uint32_t rows_per_unit;
+    // optional (backward): GradScaler's non-finite scan rides on the kernels that write the table gradient -- *found_inf = 1 when a written
+    // element is inf / nan, never cleared (nerftex_grid_encode_backward_amp)
+    float* found_inf;
 };
 
 // coordinate d of point b as the kernels see it (identity unless the caller folded its normalisation in)

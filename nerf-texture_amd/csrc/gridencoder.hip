@@ -807,6 +807,15 @@ __global__ __launch_bounds__(256) void zero_table_rows_kernel(T* __restrict__ ta
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) table[i] = (T)0.0f;
 }
 
+// GradScaler's scan over a finished table gradient (the paths that do not fold it into their own stores): *found_inf = 1 on inf / nan
+template <typename T, int C>
+__global__ __launch_bounds__(256) void table_nonfinite_kernel(const T* __restrict__ table, const int* __restrict__ offsets, uint32_t L, float* __restrict__ found_inf) {
+    const size_t n = (size_t)(uint32_t)offsets[L] * C;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad |= !(fabsf((float)table[i]) <= 3.0e38f);
+    if (__any(bad) && (threadIdx.x & (kWave - 1)) == 0) *found_inf = 1.0f;
+}
+
 template <typename T, int D, int C>
 int launch_backward(const T* grad, const float* inputs, const int* offsets, T* grad_emb, uint32_t B, uint32_t L,
                     const LevelConsts& lc, bool calc_grad, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool align,
@@ -818,6 +827,7 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
         return check_launch("grid_encode_backward(clear)");
     };
     if (B == 0) return overwrite ? clear_table() : NERFTEX_OK;
+    bool scanned = false;  // lc.found_inf: the non-finite scan was done by the kernels that wrote the table
     const uint32_t nchunks = div_up(B, 256u);
     const dim3 grid(kXcds * nchunks * div_up(L, kXcds)), block(256);
     const bool blc = layout == NERFTEX_LAYOUT_BLC;
@@ -828,7 +838,10 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
         if (owner) {  // every level through the LDS tile owners, no per-sample global atomics at all
             if (!knob(kKnobGridBwdSweep)) {  // grid_bwd_sweep = 1 keeps the tile-owner sweep; default = binning
                 rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, overwrite, st);
-                if (rc == NERFTEX_OK) goto table_done;
+                if (rc == NERFTEX_OK) {
+                    scanned = sizeof(T) == 2;
+                    goto table_done;
+                }
                 if (rc > 0) return rc;  // rc < 0: shape outside the binned path's limits -> sweep below
             }
             if (overwrite && (rc = clear_table()) != NERFTEX_OK) return rc;
@@ -872,6 +885,10 @@ table_done:
         }
         rc = check_launch("grid_encode_backward");
         if (rc != NERFTEX_OK) return rc;
+    }
+    if (lc.found_inf && !scanned) {
+        hipLaunchKernelGGL((table_nonfinite_kernel<T, C>), dim3(1024), dim3(256), 0, st, grad_emb, offsets, L, lc.found_inf);
+        if ((rc = check_launch("grid_encode_backward(scan)")) != NERFTEX_OK) return rc;
     }
     if (calc_grad) {
         const dim3 g2(div_up(B * (uint32_t)D, 256u));
@@ -957,7 +974,7 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
                        int layout, bool affine, float in_add, float in_mul, void* stream, const int32_t* units_dev = nullptr, uint32_t rows_per_unit = 0);
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream);
+                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf = nullptr);
 }  // namespace
 
 extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
@@ -1000,6 +1017,18 @@ extern "C" int nerftex_grid_encode_backward_affine(const void* grad, const float
                                align_corners, dtype, layout, true, in_add, in_mul, stream);
 }
 
+extern "C" int nerftex_grid_encode_backward_amp(const void* grad, const float* inputs, const void* embeddings,
+                                                const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                                uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
+                                                void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, int layout,
+                                                float in_add, float in_mul, float* found_inf, void* stream) {
+    (void)embeddings;
+    clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs, gridtype,
+                               align_corners, dtype, layout, true, in_add, in_mul, stream, found_inf);
+}
+
 namespace {
 int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
@@ -1019,13 +1048,14 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
 
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream) {
+                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf) {
     if (!affine) clear_error();
     const bool overwrite = (layout & NERFTEX_LAYOUT_GRAD_OVERWRITE) != 0;
     layout &= ~NERFTEX_LAYOUT_GRAD_OVERWRITE;
     int rc = check_common(L, dtype, layout);
     if (rc != NERFTEX_OK) return rc;
-    const LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
+    LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
+    lc.found_inf = found_inf;
     if (dtype == NERFTEX_F32)
         return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
                                         grad_inputs, gridtype, align_corners != 0, layout, overwrite, as_stream(stream));

@@ -276,7 +276,14 @@ struct DirTable {
     uint32_t split_base[kMaxLevels];     // levels with slices > 1: index of the level's first tile among the split tiles (ticket counters)
     uint32_t part_base[kMaxLevels];      //                         index of the level's first partial tile in the partial-sum buffer
     uint32_t* stale_flag;                // deferred error word (pinned host memory): set when the device table differs from `offsets`
+    float* found_inf;                    // optional: set to 1 when a written gradient element is inf / nan (GradScaler's scan, folded in)
 };
+
+// inf / nan in either half of a pair of fp16 gradient elements
+__device__ __forceinline__ bool half2_nonfinite(half2_t v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    return (b & 0x7c00u) == 0x7c00u || (b & 0x7c000000u) == 0x7c000000u;
+}
 
 // host copy vs device table, for the level a workgroup works on: a stale registration must not size or address anything
 __device__ __forceinline__ bool table_matches(const DirTable& tab, const int* __restrict__ offsets, uint32_t level) {
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
                                                                   uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, uint32_t merge_res,
                                                                   uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1], lcount[kMaxTilesPerLevel];
+    __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1];
     constexpr int NP = Sample<T, D>::NP;
     constexpr uint32_t kRows = rows_per_tile<T>();
     // an LDS-qualified pointer: with a generic one the compiler merges the LDS store and the rare overflow store to global memory of
@@ -346,12 +353,19 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     }
     __syncthreads();
 
-    // ---- count per tile
+    // ---- count per tile.  The counting atomic's RETURN value is the record's rank inside its tile's run: kept (two 16-bit ranks per
+    // register) and added to the tile's base after the scan -- one LDS atomic per record instead of a count pass plus a slot pass
+    // (round 4; the placement phase was a second atomicAdd per record on lcount[])
+    uint32_t rank_a[NP / 2 > 0 ? NP / 2 : 1] = {0}, rank_b[NP / 2 > 0 ? NP / 2 : 1] = {0};
     if (sm.live) {
 #pragma unroll
         for (int q = 0; q < NP; q++) {
-            atomicAdd(&hist[sm.row_a[q] / kRows], 1u);
-            if ((sm.split >> q) & 1u) atomicAdd(&hist[sm.row_b[q] / kRows], 1u);
+            const uint32_t ra = atomicAdd(&hist[sm.row_a[q] / kRows], 1u);
+            rank_a[q / 2] |= ra << (16 * (q & 1));
+            if ((sm.split >> q) & 1u) {
+                const uint32_t rb = atomicAdd(&hist[sm.row_b[q] / kRows], 1u);
+                rank_b[q / 2] |= rb << (16 * (q & 1));
+            }
         }
     }
     __syncthreads();
@@ -372,7 +386,6 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
         for (int h = 0; h < 2; h++) {
             const uint32_t t = lane + h * kWave;
             lbase[t] = base[h];
-            lcount[t] = 0;
             hist[t] = real[h] | (cnt[h] << 16);  // (real, padded) for the pad pass
             if (t < ntiles) dir[((size_t)level * kMaxTilesPerLevel + t) * nchunks + chunk] = (base[h] << 16) | cnt[h];  // both < 2^16
         }
@@ -383,9 +396,9 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
 
     // ---- place: LDS for the first kStageRecords slots of the block, the rest straight to the region
     const uint32_t p16s = fraction16(sm.p) << 16;
-    auto place = [&](uint32_t row, uint32_t code, const float (&v)[2]) {
+    auto place = [&](uint32_t row, uint32_t code, const float (&v)[2], uint32_t rank) {
         const uint32_t t = row / kRows;
-        const uint32_t at = lbase[t] + atomicAdd(&lcount[t], 1u);
+        const uint32_t at = lbase[t] + rank;
         const Rec<T> r = make_record<T>(row - t * kRows, code, sm.p, p16s, v);
         if (at < kStageRecords) stage[at] = __builtin_bit_cast(Bits, r);
         else region[at] = r;
@@ -395,8 +408,8 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
         for (int q = 0; q < NP; q++) {
             const uint32_t m = sm.row_a[q] ^ sm.row_b[q];
             const bool sp = (sm.split >> q) & 1u;
-            place(sm.row_a[q], sp ? kSingle : 30u - (uint32_t)__builtin_clz(m + 1u), sm.ga[q]);  // m = 2^(k+1) - 1 -> code k
-            if (sp) place(sm.row_b[q], kSingle, sm.gb[q]);
+            place(sm.row_a[q], sp ? kSingle : 30u - (uint32_t)__builtin_clz(m + 1u), sm.ga[q], (rank_a[q / 2] >> (16 * (q & 1))) & 0xffffu);  // m = 2^(k+1) - 1 -> code k
+            if (sp) place(sm.row_b[q], kSingle, sm.gb[q], (rank_b[q / 2] >> (16 * (q & 1))) & 0xffffu);
         }
     }
     if (threadIdx.x < kMaxTilesPerLevel) {  // the pad slots of each tile's run: single-row records with a zero gradient
@@ -507,21 +520,30 @@ __device__ __forceinline__ void zero_tile(char* smem, uint32_t nrows) {
 // tile -> table.  A tile with a single work item has a single writer in this launch: plain stores (or read-add-write),
 // deterministic.  Split tiles add their partial sums with atomics; consecutive lanes hit consecutive addresses.
 template <typename T>
-__device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst, uint32_t nrows, bool sole, bool overwrite) {
+__device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst, uint32_t nrows, bool sole, bool overwrite, float* found_inf) {
     if constexpr (sizeof(T) == 2) {
         const unsigned long long* acc64 = reinterpret_cast<const unsigned long long*>(smem);
+        bool bad = false;
         for (uint32_t i = threadIdx.x; i < nrows; i += kSumThreads) {
             const long long s0 = (long long)acc64[(size_t)i * 2], s1 = (long long)acc64[(size_t)i * 2 + 1];
             half2_t* p = reinterpret_cast<half2_t*>(dst) + i;
             if (sole && overwrite) {  // the caller's buffer is uninitialised: this work item owns the tile and writes all of it
-                *p = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
+                const half2_t v = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
+                *p = v;
+                bad |= half2_nonfinite(v);
                 continue;
             }
             if ((s0 | s1) == 0) continue;
             const half2_t v = half2_t{fixed_to_half(s0), fixed_to_half(s1)};
-            if (sole) *p = *p + v;
-            else unsafeAtomicAdd(reinterpret_cast<__half2*>(p), __builtin_bit_cast(__half2, v));
+            if (sole) {
+                const half2_t w = *p + v;
+                *p = w;
+                bad |= half2_nonfinite(w);
+            } else {
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(p), __builtin_bit_cast(__half2, v));
+            }
         }
+        if (found_inf && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) *found_inf = 1.0f;
     } else {
         const float* acc32 = reinterpret_cast<const float*>(smem);
         for (uint32_t i = threadIdx.x; i < nrows * 2; i += kSumThreads) {
@@ -618,7 +640,7 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
             return;
         }
     }
-    write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite);
+    write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite, tab.found_inf);
 }
 
 // The tiles several K4d work items shared: one workgroup per (tile, 64 rows) adds the items' integer partial sums -- wave q takes the
@@ -666,11 +688,15 @@ __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const un
         s1 += s_sum[w][lane][1];
     }
     half2_t* dst = reinterpret_cast<half2_t*>(grad_grid) + (size_t)(uint32_t)tab.offsets[level];
+    half2_t w = half2_t{(half_t)0.0f, (half_t)0.0f};
     if (overwrite) {
-        dst[row] = half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+        w = half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+        dst[row] = w;
     } else if ((s0 | s1) != 0) {
-        dst[row] = dst[row] + half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+        w = dst[row] + half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+        dst[row] = w;
     }
+    if (tab.found_inf && half2_nonfinite(w)) *tab.found_inf = 1.0f;
 }
 
 // ---- host: cached copy of the level table -----------------------------------------------------------------------------
@@ -792,6 +818,7 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     dt.tile_base[L] = tiles;
     dt.item_base[L] = items;
     dt.stale_flag = stale_flag();
+    dt.found_inf = sizeof(T) == 2 ? lc.found_inf : nullptr;  // (fp32 tables: the caller scans, launch_backward)
     if (!dt.stale_flag) { set_error("grid_encode_backward: no pinned memory for the deferred error word"); return NERFTEX_ERR_HIP; }
     const size_t dir_bytes = (sizeof(uint32_t) * (size_t)L * kMaxTilesPerLevel * nchunks + 255) / 256 * 256;
     const size_t part_bytes = (size_t)part_tiles * kTileBytes;  // exact integer partial sums of the tiles several work items share

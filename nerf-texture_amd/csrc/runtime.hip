@@ -133,26 +133,24 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-// A stream under capture: the pair goes into the graph as EXTERNAL event-record nodes (hipEventRecordExternal), so every replay of the graph
-// re-records both events and nerftex_profile_report() reads the durations of the LAST replay -- per-kernel timing of a replayed step, beside
-// whatever else runs on the device then (bench.py: roofline.avg_launch_ms).  Outside a capture: plain records, one span per launch.
-void record(hipEvent_t ev, hipStream_t st) {
+// A stream under capture gets NO timing events: a pair recorded into a graph cannot be read back after a replay (hipEventRecordWithFlags(...,
+// hipEventRecordExternal), the form that could, fails with "invalid argument" during capture on ROCm 7.2 -- tried in round 4), so the spans of
+// a captured launch would only ever report garbage.  bench.py times the kernels of the REPLAYED step with rocprofv3 instead.
+static bool capturing(hipStream_t st) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        (void)hipEventRecordWithFlags(ev, st, hipEventRecordExternal);
-    else
-        (void)hipEventRecord(ev, st);
+    return hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
 }
 void profile_begin(const char* name, hipStream_t st, int* slot) {
+    if (capturing(st)) return;  // *slot stays -1: profile_end is not called
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     Span sp{name, take_event(), take_event()};
-    record(sp.a, st);
+    (void)hipEventRecord(sp.a, st);
     g_spans.push_back(sp);
     *slot = (int)g_spans.size() - 1;
 }
 void profile_end(hipStream_t st, int slot) {
     std::lock_guard<std::mutex> lock(g_profile_mutex);
-    if (slot >= 0 && slot < (int)g_spans.size()) record(g_spans[slot].b, st);
+    if (slot >= 0 && slot < (int)g_spans.size()) (void)hipEventRecord(g_spans[slot].b, st);
 }
 
 }  // namespace nerftex

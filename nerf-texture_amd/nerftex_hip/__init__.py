@@ -27,6 +27,9 @@ _u64, _f64 = C.c_uint64, C.c_double
 _SIGNATURES = {
     "nerftex_field_forward": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_field_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_backward_amp": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_grid_encode_backward_amp": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _f32, _f32, _vp, _vp],
+    "nerftex_field_density": [_vp, _vp, _u32, _vp, _vp],
     "nerftex_release_workspaces": [],
     "nerftex_field_forward_rows": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "nerftex_grid_encode_forward_rows": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _u32, _vp],

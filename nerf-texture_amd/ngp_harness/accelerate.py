@@ -56,9 +56,11 @@ class AcceleratedTrainer:
 
             self.opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights"), (field.color_net, "weights")], lr=lr, betas=betas, eps=eps)
             self.amp, self.scaler = FusedAmp(self.opt), None
+            if field.fused_field:
+                self.amp.attach(field.encoder)  # found_inf raised by the kernels that write the gradients: no separate scan launch
         else:
             self.opt = torch.optim.Adam(field.get_params(lr), betas=betas, eps=eps, fused=True, capturable=self.use_graph)
-            self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype == torch.float16)
+            self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype in (torch.float16, torch.bfloat16))  # (the table gradient is fp16 either way)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
         self._graphs, self._M = None, 0
         self._rays, self._target = None, None  # static inputs: rays per ring slot (the march of slot g + 1 may run while slot g's is still read), one target

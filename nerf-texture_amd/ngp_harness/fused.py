@@ -117,6 +117,7 @@ class _ngp_field(Function):
                                             stream()))
             ctx.save_for_backward(x, table_h, offsets, ws_h, wc_h, x_rows, h, cin, rgbs)
             ctx.meta = (S, H, gridtype, align, affine, table.dtype, ws.dtype, wc.dtype)
+            ctx.amp_sink = getattr(enc, "amp_sink", None)  # optim.FusedAmp.attach: the backward's kernels raise found_inf themselves
         else:
             check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
         ctx.set_materialize_grads(False)
@@ -134,7 +135,12 @@ class _ngp_field(Function):
         grad_rgbs = torch.zeros(B, 3, dtype=torch.float32, device=dev) if grad_rgbs is None else grad_rgbs.contiguous().float()
         grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc_h)
         grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)
-        if FIELD_BACKWARD_FUSED:  # the two glue kernels ride on the MLP backward kernels' load stage, one reduction for both networks
+        sink = ctx.amp_sink if (FIELD_BACKWARD_FUSED and t_dtype == ws_dtype == wc_dtype == torch.float16) else None
+        found = ptr(sink.found_inf) if sink is not None else None
+        if sink is not None:  # GradScaler's non-finite scan rides on the stores of the three gradients (no amp_check launch this step)
+            check(lib.nerftex_field_backward_amp(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B,
+                                                 ptr(grad_cin), ptr(grad_x), ptr(grad_ws), ptr(grad_wc), found, stream()))
+        elif FIELD_BACKWARD_FUSED:  # the two glue kernels ride on the MLP backward kernels' load stage, one reduction for both networks
             check(lib.nerftex_field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin),
                                              ptr(grad_x), ptr(grad_ws), ptr(grad_wc), stream()))
         else:
@@ -146,9 +152,17 @@ class _ngp_field(Function):
             check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws_h), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
         grad_table = torch.empty_like(table_h)
         dummy = torch.empty(1, **half)
-        check(lib.nerftex_grid_encode_backward_affine(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, 0,
-                                                      ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1],
-                                                      stream()))
+        if sink is not None:
+            check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H,
+                                                       0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],
+                                                       affine[1], found, stream()))
+            # the buffers whose scan is done (addresses, not references: a second reference would make autograd copy the gradient instead
+            # of handing the tensor itself to `.grad`); FusedAmp.step checks `.grad` off against them
+            sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
+        else:
+            check(lib.nerftex_grid_encode_backward_affine(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S,
+                                                          H, 0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],
+                                                          affine[1], stream()))
         return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None
 
 
@@ -188,6 +202,33 @@ def ngp_field_infer(x, dirs, encoder, sigma_net, color_net, bound, live=None):
                                                mul, units, rows_per_unit, st))
     check(lib.nerftex_field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), units, rows_per_unit, st))
     return sigma, rgbs
+
+
+def ngp_density(x, encoder, sigma_net, bound):
+    """sigma [B] fp32 of the --ff field's `density` (nerf/network_ff.py:103-117) for B % 128 == 0 points: the hash-grid gather (level-major
+    output) and the sigma net + trunc_exp as ONE kernel behind it (nerftex_field_density) -- the occupancy-grid update's query
+    (nerf/renderer.py:566-660: 2-4 M cell positions every 16 steps).  No autograd; call under autocast(float16)."""
+    import numpy as np
+
+    from nerftex_hip import F16, LAYOUT_LBC
+
+    from gridencoder.grid import register_offsets
+
+    B, dev = x.shape[0], x.device
+    table_h = encoder._table()
+    ws = sigma_net._weights()
+    L = encoder.offsets.shape[0] - 1
+    assert table_h.dtype == torch.float16 and (L, table_h.shape[1], x.shape[1]) == (16, 2, 3) and B % 128 == 0 and x.dtype == torch.float32
+    register_offsets(encoder.offsets, L)
+    ws_h = ws.detach() if ws.dtype == torch.float16 else ws.detach().to(torch.float16)
+    feats = torch.empty(L, B, 2, dtype=torch.float16, device=dev)
+    sigma = torch.empty(B, dtype=torch.float32, device=dev)
+    st = stream()
+    check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table_h), ptr(encoder.offsets), ptr(feats), B, 3, 2, L, float(np.log2(encoder.per_level_scale)),
+                                               int(encoder.base_resolution), int(encoder.gridtype_id), int(bool(encoder.align_corners)), F16, LAYOUT_LBC,
+                                               float(bound), float(np.float32(1.0) / np.float32(2 * bound)), None, 0, st))
+    check(lib.nerftex_field_density(ptr(feats), ptr(ws_h), B, ptr(sigma), st))
+    return sigma
 
 
 def enc_bound(enc):

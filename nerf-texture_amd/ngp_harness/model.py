@@ -175,6 +175,17 @@ class NGPField(nn.Module):
         sigma, geo_feat = self._sigma_feat(x)
         return {"sigma": sigma, "geo_feat": geo_feat}
 
+    @torch.no_grad()
+    def density_sigma(self, x):
+        """density(x)["sigma"] without autograd bookkeeping -- what the occupancy-grid update asks for, millions of points at a time: the
+        fused field's gather + sigma-net kernel when it applies (same values as the field kernel's sigma), else density()."""
+        if (self.fused_field and x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and x.is_contiguous() and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.float16 and self.encoder._table().dtype == torch.float16 and self.sigma_net.hidden_dim == 64):
+            from . import fused
+
+            return fused.ngp_density(x, self.encoder, self.sigma_net, self.bound)
+        return self.density(x)["sigma"].reshape(-1).float()
+
     def get_params(self, lr):
         return [{"params": self.parameters(), "lr": lr}]
 
@@ -306,10 +317,15 @@ class Renderer(nn.Module):
         if not hasattr(self, "_mean_thresh"):
             self._mean_thresh = torch.zeros(2, dtype=torch.float32, device=dev)
 
+        sigma_of = getattr(self.field, "density_sigma", None) or (lambda p: self.field.density(p)["sigma"].reshape(-1).float())
+
         def density(xyzs):
-            out = torch.empty(xyzs.shape[0], dtype=torch.float32, device=dev)
-            for a in range(0, xyzs.shape[0], chunk):
-                out[a:a + chunk] = self.field.density(xyzs[a:a + chunk])["sigma"].reshape(-1).float()
+            if xyzs.shape[0] <= chunk:
+                out = sigma_of(xyzs)
+            else:
+                out = torch.empty(xyzs.shape[0], dtype=torch.float32, device=dev)
+                for a in range(0, xyzs.shape[0], chunk):
+                    out[a:a + chunk] = sigma_of(xyzs[a:a + chunk])
             return out * self.density_scale if self.density_scale != 1 else out
 
         if self.iter_density < 16 or force_full_update:

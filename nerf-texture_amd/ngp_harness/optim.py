@@ -160,6 +160,16 @@ class FusedAmp:
         self.ticket = torch.zeros((), dtype=torch.int32, device=dev)  # "last block to finish" counter of the Adam launch, self-resetting
         self.consts = (float(growth_factor), float(backoff_factor), int(growth_interval))
 
+    def attach(self, encoder):
+        """Let the fused field's backward (ngp_harness/fused.py, over this encoder) raise `found_inf` from the kernels that write the three
+        gradients (nerftex_field_backward_amp, nerftex_grid_encode_backward_amp): `step()` then skips its scan of every gradient tensor that
+        backward produced (checked by data pointer: a gradient that went through anything else -- an accumulation, a cross-rank sum in fp16
+        that can overflow on its own -- is still scanned).  Single-process training; under data parallelism the scan must see the SUMMED
+        gradient, so bench.py does not attach there."""
+        self.covered = None
+        encoder.amp_sink = self
+        return self
+
     def scale_loss(self, loss):
         return loss * self.scale
 
@@ -184,6 +194,10 @@ class FusedAmp:
     def step(self):
         _poll_deferred_error()
         grads = [leaf.grad for leaf in self.opt.leaves if leaf.grad is not None]
+        covered = getattr(self, "covered", None)
+        if covered:  # gradients whose producing kernels already raised found_inf (attach): the very tensors, untouched since
+            grads = [g for g in grads if g.data_ptr() not in covered]
+            self.covered = None
         if grads:
             self._check(grads)
         # Adam (skipped on overflow) and the scale / step-counter update in one launch

@@ -102,6 +102,10 @@ def main():
         return f, r
 
     def run(f, r, amp_dtype):
+        # loss scale: 1024 for both 16-bit modes (the hash table and its gradient are fp16 under any autocast: unscaled gradients sit in fp16's
+        # subnormal range); "bf16-unscaled" shows what bf16 autocast WITHOUT a scaler does to the table gradient
+        k = 1.0 if amp_dtype in (None, "bf16-unscaled") else 1024.0
+        amp_dtype = torch.bfloat16 if amp_dtype == "bf16-unscaled" else amp_dtype
         f.train()
         for p_ in f.parameters():
             p_.grad = None
@@ -112,11 +116,10 @@ def main():
             sigma, rgb, _ = f(xyzs, dirs)
             image, depth = r.shade_train(marched, 1)
             loss = torch.nn.functional.mse_loss(image.float(), tgt)
-        (loss * (1024.0 if amp_dtype == torch.float16 else 1.0)).backward()
+        (loss * k).backward()
         f.eval()
         with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
             patch, _, _ = r.render_infer(po, pd, dt_gamma=1 / 128)
-        k = 1024.0 if amp_dtype == torch.float16 else 1.0
         return dict(m=m, sigma=sigma[:m].float(), rgb=rgb[:m].float(), image=image.float(), loss=loss.float(), patch=patch.float(), k=k)
 
     report = {"rays": 4096, "note": "truth = the same weights in fp32 without autocast (NGPField(mlp='torch')); max_rel is relative to max(|truth|, 1e-3 max|truth|)"}
@@ -143,7 +146,8 @@ def main():
                                                  "color": [l.weight.grad for l in f_t.color_net]}, g_truth)
     # ---- the FFMLP paths, each against its own fp32 twin
     for label, kw, amp in (("ffmlp_fp16", dict(fused_glue=False), torch.float16), ("fused_fp16", dict(fused_glue=True), torch.float16),
-                           ("ffmlp_bf16", dict(fused_glue=False, mlp_dtype=torch.bfloat16), torch.bfloat16)):
+                           ("ffmlp_bf16", dict(fused_glue=False, mlp_dtype=torch.bfloat16), torch.bfloat16),
+                           ("ffmlp_bf16_unscaled_loss", dict(fused_glue=False, mlp_dtype=torch.bfloat16), "bf16-unscaled")):
         f_f, r_f = build("ffmlp", **kw)
         with torch.no_grad():  # widen the sigma row like the fixture does (first row of the sigma net's last matrix)
             n_last = f_f.sigma_net.hidden_dim * f_f.sigma_net.padded_output_dim
