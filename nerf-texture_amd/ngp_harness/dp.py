@@ -27,15 +27,39 @@ def init_from_env(backend=None):
     if os.environ.get("NERFTEX_DP_SHARE_GPU") == "1":
         local, backend = 0, "gloo"
     if world > 1 and not dist.is_initialized():
+        import datetime
+        import sys
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # the host driver only supports dmabuf IPC: without this RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid argument`
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend=backend)
+        # a rendezvous or a first collective that hangs (a rank that died, a GPU another process holds, a wrong MASTER_PORT) must end in a
+        # message, not in a silent stall of the whole node: NERFTEX_DP_TIMEOUT_S seconds (default 180) for the group and every collective
+        timeout = datetime.timedelta(seconds=float(os.environ.get("NERFTEX_DP_TIMEOUT_S", "180")))
+        try:
+            if backend == "nccl":
+                if local >= torch.cuda.device_count():
+                    raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} visible GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)")
+                torch.cuda.set_device(local)
+                dist.init_process_group(backend=backend, device_id=torch.device("cuda", local), timeout=timeout)
+                # first contact: one tiny all-reduce here, where a failure can still be explained (RCCL sets up its xGMI rings lazily, in the
+                # first collective -- without this the first symptom would be a hang inside the first training step)
+                probe = torch.ones(1, device=torch.device("cuda", local))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"first all-reduce returned {probe.item()} on rank {rank}, expected {world}")
+            else:
+                dist.init_process_group(backend=backend, timeout=timeout)
+        except Exception as e:  # noqa: BLE001 -- re-raised below with what a person at an 8-GPU node needs to know
+            print(f"[dp] rank {rank}/{world} (local {local}): process group '{backend}' failed to come up within {timeout.total_seconds():.0f} s: "
+                  f"{type(e).__name__}: {e}\n[dp] rendezvous {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}, HSA_ENABLE_IPC_MODE_LEGACY="
+                  f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, visible GPUs {torch.cuda.device_count() if torch.cuda.is_available() else 0}; "
+                  f"NCCL_DEBUG=INFO shows RCCL's own log, NERFTEX_DP_TIMEOUT_S changes the limit", file=sys.stderr, flush=True)
+            raise
     return rank, world, local
 
 
