@@ -760,7 +760,7 @@ def measure_curved(dev, n_points=262144, reps=10):
         return e0.elapsed_time(e1) / reps * 1e3, out
 
     t_knn, neighbours = timed(lambda: proj.knn(xyz))
-    t_proj, out = timed(lambda: proj.project(xyz, neighbours=neighbours))
+    t_proj, out = timed(lambda: proj.project_fused(xyz, neighbours=neighbours))
     p_sur, mask = out[0], out[2]
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
     field.train()

@@ -64,10 +64,43 @@ def knn_bruteforce(xyz, vertices, K=8, chunk=8192):
     return torch.cat(idx).contiguous(), torch.cat(dist).contiguous()
 
 
+class diff_project_layer(torch.autograd.Function):
+    """tools/map.py:171-186: the projection made differentiable in x by FIAT -- forward hands (xyz, p_sur, sdf, normal) through unchanged; the
+    backward routes dL/dp_sur (its component parallel to the surface: the foot point moves with x along the tangent plane) and dL/dsdf (along
+    the unit normal: the height changes with x along it) to dL/dxyz.  Used by MeshProjector.project(requires_grad_xyz=True) -> the visual /
+    light-model branch of network_curvedfield.py:236-259, where sigma is differentiated with respect to the sample position."""
+
+    @staticmethod
+    def forward(ctx, xyz, p_sur, sdf, normal):
+        ctx.save_for_backward(normal)
+        return xyz, p_sur, sdf, normal
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_psur, g_sdf, g_normal):
+        normal = ctx.saved_tensors[0]
+        normal = normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)
+        g_xyz_parallel2surface = g_psur - normal * (normal * g_psur).sum(dim=-1, keepdim=True)
+        g_xyz_along_normal = g_sdf * normal
+        return g_xyz_along_normal + g_xyz_parallel2surface, g_psur, g_sdf, g_normal
+
+
+def freq_encode(x, multires=12):
+    """tools/encoding.py:5-43 FreqEncoder as get_encoder('frequency', multires=...) builds it (log-sampled bands 2^0 .. 2^(multires-1), input
+    included): [x, sin(x f_0), cos(x f_0), sin(x f_1), ...].  Framework ops -- differentiable; the fused projector kernel evaluates the same
+    ladder for the no-grad path."""
+    bands = (2.0 ** torch.linspace(0.0, multires - 1, multires)).tolist()
+    out = [x]
+    for f in bands:
+        out += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(out, dim=-1)
+
+
 class MeshProjector(torch.nn.Module):
-    """The part of tools/map.py's MeshProjector the curved field uses per sample -- `knn` (:454-501) and `project` (:414-433) -- in two
-    forms: `project_reference` restates the reference's framework-op sequence over RayTracer.trace, `project` is the fused kernel
-    (nerftex_curved_project), which also returns FreqEncoder(height)."""
+    """The part of tools/map.py's MeshProjector the curved field uses per sample -- `knn` (:454-501) and `project` (:414-433):
+    `project(xyz, K=8, h_threshold=None, requires_grad_xyz=False, use_dir_vec=True) -> (p_sur, sdf, h_mask, normal, tbn)` is the
+    reference's signature and tuple, served by the fused kernel (nerftex_curved_project: neighbour-weighted normal + two BVH traces + select
+    + mask + frame in one launch) whenever use_dir_vec is on; `project_fused` is that kernel's full output (adds the face index and
+    FreqEncoder(height)); `project_reference` restates the reference's framework-op sequence over RayTracer.trace."""
 
     def __init__(self, vertices, faces, h_threshold=0.05, K=8, vertex_normals=None, tbn=None):
         """vertex_normals / tbn: the mesh's own (the reference takes them from open3d and from its UV map, tools/map.py:365-366,396);
@@ -117,46 +150,69 @@ class MeshProjector(torch.nn.Module):
         check(lib.nerftex_knn_query(self._knn, ptr(xyz), xyz.shape[0], K, ptr(idx), ptr(dis), stream()))
         return idx, dis
 
-    def knn_normal(self, xyz, idx, dis, dir_vec_wdist=0.05):
-        """knn() with use_dir_vec=True, weighting='Shepard' (tools/map.py:454-501), op for op."""
+    def knn_normal(self, xyz, idx, dis, dir_vec_wdist=0.05, use_dir_vec=True):
+        """knn() with weighting='Shepard' (tools/map.py:454-501), op for op; use_dir_vec: the inverse-distance mean of the directions to the
+        neighbours joins their normals as one more candidate (:473-481)."""
         normals = self.vertex_normals[idx.long()]
         dir_vec_ori = xyz.unsqueeze(-2) - self.mesh_vertices[idx.long()]
         dir_vec = dir_vec_ori / (dir_vec_ori.norm(dim=-1, keepdim=True) + 1e-5)
-        weights_invd = 1 / (dis + 1e-7)
-        mean_dir_vec = (weights_invd.unsqueeze(-1) * dir_vec).sum(1, keepdims=True)
-        normal_test = normals.mean(1, keepdims=True)
-        mean_dir_vec = torch.where((mean_dir_vec * normal_test).sum(dim=-1, keepdims=True) < 0, -mean_dir_vec, mean_dir_vec)
-        mean_dir_vec = mean_dir_vec / (mean_dir_vec.norm(dim=-1, keepdim=True) + 1e-5)
-        normals = torch.cat([normals, mean_dir_vec], dim=1)
-        dis = torch.cat([dis, float(np.clip(dir_vec_wdist, 1e-5, np.inf)) * torch.ones_like(dis[:, :1])], dim=1)
+        if use_dir_vec:
+            weights_invd = 1 / (dis + 1e-7)
+            mean_dir_vec = (weights_invd.unsqueeze(-1) * dir_vec).sum(1, keepdims=True)
+            normal_test = normals.mean(1, keepdims=True)
+            mean_dir_vec = torch.where((mean_dir_vec * normal_test).sum(dim=-1, keepdims=True) < 0, -mean_dir_vec, mean_dir_vec)
+            mean_dir_vec = mean_dir_vec / (mean_dir_vec.norm(dim=-1, keepdim=True) + 1e-5)
+            normals = torch.cat([normals, mean_dir_vec], dim=1)
+            dis = torch.cat([dis, float(np.clip(dir_vec_wdist, 1e-5, np.inf)) * torch.ones_like(dis[:, :1])], dim=1)
         weights = 1 / (dis + 1e-7)
         weights = weights / torch.sum(weights, dim=-1, keepdims=True)
         normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-5)
         normal = (normals * weights.unsqueeze(-1)).sum(-2)
         return normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)
 
+    def _height_limit(self, h_threshold):
+        """min(depth_threshold, h_threshold) of tools/map.py:427-429; None = no limit but the tracer's own (9.5).  The module's default
+        (its constructor's h_threshold) applies when the caller passes the sentinel `...`."""
+        if h_threshold is ...:
+            h_threshold = self.h_threshold
+        return float(min(self.depth_threshold, np.inf if h_threshold is None else h_threshold))
+
     @torch.no_grad()
-    def project_reference(self, xyz, neighbours=None):
-        idx, dis = self.knn(xyz) if neighbours is None else neighbours
-        normal = self.knn_normal(xyz, idx, dis)
+    def project_reference(self, xyz, neighbours=None, K=None, h_threshold=..., use_dir_vec=True):
+        idx, dis = self.knn(xyz, K) if neighbours is None else neighbours
+        normal = self.knn_normal(xyz, idx, dis, use_dir_vec=use_dir_vec)
         p1, _, d1, f1 = self.tracer.trace(xyz, normal)
         p2, _, d2, f2 = self.tracer.trace(xyz, -normal)
         cond = d1 < d2
         p_sur = torch.where(cond.unsqueeze(-1), p1, p2)
         sdf = torch.where(cond, -d1, d2).unsqueeze(-1)
         face_idx = torch.where(cond, f1, f2)
-        h_mask = (sdf.abs() < min(self.depth_threshold, self.h_threshold)).squeeze(-1)
+        h_mask = (sdf.abs() < self._height_limit(h_threshold)).squeeze(-1)
         return p_sur, sdf, h_mask, normal, self.tbn[face_idx], face_idx
 
+    def project(self, xyz, K=8, h_threshold=None, requires_grad_xyz=False, use_dir_vec=True):
+        """tools/map.py:414-433, the reference's signature and return value: -> (p_sur [N,3], sdf [N,1], h_mask [N] bool, normal [N,3],
+        tbn [N,3,3]).  requires_grad_xyz: the outputs carry the reference's gradient to xyz (`diff_project_layer`)."""
+        with torch.no_grad():
+            if use_dir_vec:
+                p_sur, sdf, h_mask, normal, tbn, _, _ = self.project_fused(xyz.detach(), multires=0, K=K, h_threshold=h_threshold)
+            else:  # (no kernel for the plain neighbour-normal average: the reference's op sequence over the tracer)
+                p_sur, sdf, h_mask, normal, tbn, _ = self.project_reference(xyz.detach().float().contiguous(), K=K, h_threshold=h_threshold, use_dir_vec=False)
+        if requires_grad_xyz:
+            xyz, p_sur, sdf, normal = diff_project_layer.apply(xyz, p_sur, sdf, normal)
+        return p_sur, sdf, h_mask, normal, tbn
+
     @torch.no_grad()
-    def project(self, xyz, multires=12, neighbours=None):
-        """-> p_sur [N,3], sdf [N,1], h_mask [N] bool, normal [N,3], tbn [N,3,3], face_idx [N], z_embed [N, 1 + 2 multires].
-        neighbours: (idx [N,K] int32, dis [N,K]) of a neighbour search done elsewhere; default = the library's own (self.knn)."""
+    def project_fused(self, xyz, multires=12, neighbours=None, K=None, h_threshold=...):
+        """-> p_sur [N,3], sdf [N,1], h_mask [N] bool, normal [N,3], tbn [N,3,3], face_idx [N], z_embed [N, 1 + 2 multires]: `project`
+        (use_dir_vec=True) plus the face index and FreqEncoder(height), one launch behind the neighbour search.
+        neighbours: (idx [N,K] int32, dis [N,K]) of a neighbour search done elsewhere; default = the library's own (self.knn).
+        h_threshold: `...` = the module's own (its constructor argument), None = no limit but the tracer's (9.5)."""
         from nerftex_hip import check, lib, ptr, stream
 
         xyz = xyz.float().contiguous()
         N, dev = xyz.shape[0], xyz.device
-        idx, dis = self.knn(xyz) if neighbours is None else neighbours
+        idx, dis = self.knn(xyz, K) if neighbours is None else neighbours
         idx, dis = idx.int().contiguous(), dis.float().contiguous()
         p_sur = torch.empty(N, 3, device=dev)
         sdf = torch.empty(N, device=dev)
@@ -166,7 +222,7 @@ class MeshProjector(torch.nn.Module):
         tbn = torch.empty(N, 9, device=dev)
         z = torch.empty(N, 1 + 2 * multires, device=dev)
         check(lib.nerftex_curved_project(self.tracer._handle, ptr(xyz), ptr(idx), ptr(dis), N, idx.shape[1], ptr(self.mesh_vertices), ptr(self.vertex_normals), self.mesh_vertices.shape[0], 0.05,
-                                         float(self.h_threshold), ptr(self.tbn), multires, ptr(p_sur), ptr(sdf), ptr(mask), ptr(normal), ptr(face_idx), ptr(tbn),
+                                         self._height_limit(h_threshold), ptr(self.tbn), multires, ptr(p_sur), ptr(sdf), ptr(mask), ptr(normal), ptr(face_idx), ptr(tbn),
                                          ptr(z), stream()))
         return p_sur, sdf.unsqueeze(-1), mask.bool(), normal, tbn.view(N, 3, 3), face_idx, z
 
@@ -242,9 +298,16 @@ class CurvedField(torch.nn.Module):
         self.color_pad = (self.color_in + 15) // 16 * 16
         self.color_net = FFMLP(input_dim=self.color_pad, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
 
-    def embed(self, x, no_noise=False):
-        """MeshFeatureField.forward (no import): -> embed [N,41], normal_coarse [N,3], h_mask [N]."""
-        p_sur, sdf, h_mask, normal, _, _, z_embed = self.projector.project(x, multires=self.multires)
+    def embed(self, x, no_noise=False, requires_grad_xyz=False):
+        """MeshFeatureField.forward (no import, tools/map.py:620-641): -> embed [N,41], normal_coarse [N,3], h_mask [N].
+        requires_grad_xyz (network_curvedfield.py:236-259, the branch that differentiates sigma with respect to the sample position): the
+        projection carries `diff_project_layer`'s gradient, the hash table is looked up with input gradients (dy_dx) and the height ladder
+        is evaluated by framework ops on the differentiable height -- dL/dembed reaches x."""
+        if requires_grad_xyz:
+            p_sur, sdf, h_mask, normal, _ = self.projector.project(x, K=self.projector.K, h_threshold=self.h_threshold, requires_grad_xyz=True)
+            z_embed = freq_encode(sdf, self.multires)
+        else:
+            p_sur, sdf, h_mask, normal, _, _, z_embed = self.projector.project_fused(x, multires=self.multires)
         x_embed = self.encoder(p_sur, bound=self.bound)
         if self.encoder_var is not None:
             var = self.encoder_var(p_sur, bound=self.bound)
@@ -259,10 +322,31 @@ class CurvedField(torch.nn.Module):
         h = self.sigma_net(torch.cat([embed, ones], dim=-1))
         return _TruncExp.apply(h[..., 0]), h[..., 1:]
 
-    def density(self, x):
-        embed, _, h_mask = self.embed(x)
+    def density(self, x, requires_grad_xyz=False):
+        embed, _, h_mask = self.embed(x, requires_grad_xyz=requires_grad_xyz)
         sigma, geo = self._sigma(embed)
         return {"sigma": torch.where(h_mask, sigma, torch.zeros_like(sigma)), "geo_feat": geo}
+
+    def density_gradient(self, x, lambda_=5e-2):
+        """network_curvedfield.py:236-254: sigma and d sigma_remap / dx, sigma_remap = (1 - exp(-lambda sigma)) / lambda, through the whole
+        chain -- sigma net backward (with input gradients), FreqEncoder(height) and the hash table's input gradient (G3), the projection's
+        `diff_project_layer`.  -> (sigma [N], gradient [N,3], h_mask [N]); the unmasked sigma, as the reference's branch has it there."""
+        with torch.enable_grad():
+            x = x.detach().requires_grad_(True)
+            embed, _, h_mask = self.embed(x, requires_grad_xyz=True)
+            sigma, _ = self._sigma(embed)
+            sigma_remap = 1 / lambda_ * (1 - torch.exp(-lambda_ * sigma))
+            grad = torch.autograd.grad(sigma_remap, x, torch.ones_like(sigma), create_graph=False)[0]
+        return sigma.detach(), grad, h_mask
+
+    def density_normal(self, x, lambda_=5e-2):
+        """network_curvedfield.py:236-259: the normal from sigma's gradient, n = -d sigma_remap / dx normalised; samples whose gradient is
+        not a number leave the mask.  -> (sigma [N], normal_grad [N,3], h_mask [N])."""
+        sigma, grad, h_mask = self.density_gradient(x, lambda_)
+        normal_grad = -grad
+        normal_grad = normal_grad / (normal_grad.norm(dim=-1, keepdim=True) + 1e-5)
+        h_mask = torch.logical_and(h_mask, torch.logical_not(normal_grad.isnan()).all(dim=-1))
+        return sigma, normal_grad, h_mask
 
     def forward(self, x, d, **kwargs):
         embed, normal_coarse, h_mask = self.embed(x)

@@ -142,7 +142,7 @@ def test_fused_curved_projector_matches_the_reference_op_sequence(dev):
     base = v[rng.integers(0, len(v), 20000)]
     pts = torch.from_numpy((base * (1 + rng.uniform(-0.08, 0.08, (len(base), 1)))).astype(np.float32)).to(dev)  # a shell around the surface
     p0, sdf0, m0, n0, tbn0, face0 = proj.project_reference(pts)
-    p1, sdf1, m1, n1, tbn1, face1, z1 = proj.project(pts)
+    p1, sdf1, m1, n1, tbn1, face1, z1 = proj.project_fused(pts)
     torch.testing.assert_close(n1, n0, rtol=0, atol=2e-5)
     same_face = face1 == face0
     assert same_face.float().mean() > 0.998, "a ray that grazes an edge may pick the neighbouring face when the normal differs in the last bits"

@@ -96,7 +96,7 @@ def test_projector_matches_the_reference_meshprojector_executed(dev):
     inner = g["depth_pos"] < g["depth_neg"]
     both_miss = (g["face_pos"] < 0) & (g["face_neg"] < 0)
     assert both_miss.sum() == 0 and 0.3 < inner.mean() < 0.7
-    for name, out in (("restated ops", proj.project_reference(x)), ("fused kernel", proj.project(x))):
+    for name, out in (("restated ops", proj.project_reference(x)), ("fused kernel", proj.project_fused(x))):
         p_sur, sdf, h_mask, normal, tbn, face = out[:6]
         np.testing.assert_allclose(normal.cpu().numpy(), g["normal"], rtol=0, atol=2e-5, err_msg=name)
         want_face = np.where(inner, g["face_pos"], g["face_neg"])
@@ -120,11 +120,11 @@ def test_projector_neighbour_list_with_frnn_padding_stays_in_bounds(dev):
     idx2 = idx.clone()
     idx2[:, -1] = -1
     idx2[:, -2] = 1 << 30
-    out = proj.project(x, neighbours=(idx2, dis))
+    out = proj.project_fused(x, neighbours=(idx2, dis))
     ref_idx = idx.clone()
     ref_idx[:, -1] = proj.mesh_vertices.shape[0] - 1
     ref_idx[:, -2] = proj.mesh_vertices.shape[0] - 1
-    want = proj.project(x, neighbours=(ref_idx, dis))
+    want = proj.project_fused(x, neighbours=(ref_idx, dis))
     for a, b in zip(out, want):
         assert torch.equal(a, b)
 
@@ -354,7 +354,7 @@ def test_curved_field_matches_the_reference_modules_executed(dev):
     field = _curved_field(g, p, dev)
     x, d = torch.from_numpy(g["xyz"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)
     # rays that grazed an edge may have picked the neighbouring triangle: compare where the projector agrees with the reference's
-    face = field.projector.project(x)[5].cpu().numpy()
+    face = field.projector.project_fused(x)[5].cpu().numpy()
     inner = p["depth_pos"] < p["depth_neg"]
     same = face == np.where(inner, p["face_pos"], p["face_neg"])
     near_edge = np.abs(np.abs(p["sdf"][:, 0]) - float(p["h_threshold"])) < 1e-4

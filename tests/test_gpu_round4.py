@@ -363,3 +363,86 @@ def test_attached_amp_trains_bit_identically_and_skips_on_overflow(dev):
     assert scales[0] == scales[1]
     for a, b in zip(*finals):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------- N4 as a drop-in (tools/map.py:414-433)
+def _mesh_projector(p, dev):
+    from ngp_harness.curved import MeshProjector
+
+    return MeshProjector(p["vertices"], p["faces"], h_threshold=float(p["h_threshold"]), vertex_normals=p["vertex_normals"], tbn=p["tbn"]).to(dev)
+
+
+def test_projector_project_is_the_reference_call_and_carries_its_gradient(dev):
+    """MeshProjector.project(xyz, K=8, h_threshold=None, requires_grad_xyz=False, use_dir_vec=True) -> (p_sur, sdf, h_mask, normal, tbn): the
+    reference's signature and 5-tuple (tools/map.py:414-433); with requires_grad_xyz the outputs carry diff_project_layer's gradient
+    (tools/map.py:171-186) -- dL/dxyz against the reference class EXECUTED (tests/golden/ref_python_projector_grad.npz); and the
+    use_dir_vec=False form (plain neighbour-normal average)."""
+    import inspect
+
+    from ngp_harness.curved import MeshProjector
+
+    sig = inspect.signature(MeshProjector.project)
+    assert [(n, q.default) for n, q in sig.parameters.items()][1:] == [("xyz", inspect.Parameter.empty), ("K", 8), ("h_threshold", None),
+                                                                         ("requires_grad_xyz", False), ("use_dir_vec", True)]
+    p = np.load(os.path.join(GOLDEN, "ref_python_projector.npz"))
+    g = np.load(os.path.join(GOLDEN, "ref_python_projector_grad.npz"))
+    proj = _mesh_projector(p, dev)
+    x = torch.from_numpy(p["xyz"]).to(dev).requires_grad_(True)
+    out = proj.project(x, K=8, h_threshold=0.05, requires_grad_xyz=True)
+    assert len(out) == 5
+    p_sur, sdf, h_mask, normal, tbn = out
+    assert p_sur.shape == (x.shape[0], 3) and sdf.shape == (x.shape[0], 1) and h_mask.dtype == torch.bool and tbn.shape == (x.shape[0], 3, 3)
+    np.testing.assert_allclose(normal.detach().cpu().numpy(), p["normal"], rtol=0, atol=3e-5)
+    inner = p["depth_pos"] < p["depth_neg"]
+    np.testing.assert_allclose(sdf.detach().cpu().numpy(), p["sdf"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(p_sur.detach().cpu().numpy(), p["p_sur"], rtol=0, atol=3e-5)
+    away = np.abs(np.abs(p["sdf"][:, 0]) - 0.05) > 1e-4
+    assert np.array_equal(h_mask.cpu().numpy()[away], p["h_mask"][away]) and 0.3 < inner.mean() < 0.7
+    ((p_sur * torch.from_numpy(g["g_psur"]).to(dev)).sum() + (sdf * torch.from_numpy(g["g_sdf"]).to(dev)).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_xyz"], rtol=0, atol=1e-4 * np.abs(g["grad_xyz"]).max())
+    # without requires_grad_xyz nothing is attached
+    q = proj.project(x.detach(), K=8, h_threshold=0.05)
+    assert not q[0].requires_grad and torch.equal(q[0], p_sur.detach())
+    # h_threshold=None: only the tracer's own limit; use_dir_vec=False: the plain average of the neighbours' normals
+    p2, s2, m2, n2, _ = proj.project(x.detach(), K=8, h_threshold=None, use_dir_vec=False)
+    np.testing.assert_allclose(n2.cpu().numpy(), g["nodir_normal"], rtol=0, atol=3e-5)
+    same_side = np.sign(s2.cpu().numpy()[:, 0]) == np.sign(g["nodir_sdf"][:, 0])
+    assert same_side.mean() > 0.99
+    np.testing.assert_allclose(s2.cpu().numpy()[same_side], g["nodir_sdf"][same_side], rtol=0, atol=5e-5)
+    assert np.array_equal(m2.cpu().numpy(), g["nodir_h_mask"]) and bool(m2.all())
+
+
+def test_curved_field_sigma_gradient_reaches_the_sample_position(dev):
+    """network_curvedfield.py:236-254 (the branch that takes the normal from d sigma / dx) through CurvedField: FFMLP backward with input
+    gradients -> FreqEncoder(height) and the hash grid's INPUT gradient (G3) -> diff_project_layer -> x, against the reference's modules
+    executed (torch.autograd.grad's result captured inside NeRFNetwork.forward with use_grad_normal=True)."""
+    sys_path_golden = os.path.join(GOLDEN, "ref_python_curvedfield.npz")
+    c = np.load(sys_path_golden)
+    p = np.load(os.path.join(GOLDEN, "ref_python_projector.npz"))
+    g = np.load(os.path.join(GOLDEN, "ref_python_projector_grad.npz"))
+    from ngp_harness.curved import CurvedField
+
+    field = CurvedField(p["vertices"], p["faces"], bound=1.0, h_threshold=float(p["h_threshold"]), vertex_normals=p["vertex_normals"], tbn=p["tbn"])
+    gen = torch.Generator().manual_seed(int(c["table_seed"]))
+    with torch.no_grad():
+        field.encoder.embeddings.copy_(torch.rand(field.encoder.embeddings.shape, generator=gen) - 0.5)
+        field.sigma_net.weights.copy_(torch.from_numpy(c["w_sigma"]))
+        field.color_net.weights.copy_(torch.from_numpy(c["w_color"]))
+    field = field.to(dev).train()
+    x = torch.from_numpy(c["xyz"]).to(dev)
+    with torch.autocast("cuda", dtype=torch.float16):
+        sigma, grad, h_mask = field.density_gradient(x)
+        _, normal_grad, _ = field.density_normal(x)
+    want = g["grad_normal_dsigma_remap_dx"]
+    got = grad.float().cpu().numpy()
+    assert np.isfinite(got).all() and (np.abs(got).sum(-1) > 0).all()
+    np.testing.assert_allclose(sigma.float().cpu().numpy(), g["grad_normal_sigma"], rtol=3e-2, atol=3e-3)
+    # fp16 MLP backward, fp16 dy_dx of a table with 512..1024 cells per unit (gradients of several hundred): compare directions and lengths
+    cos = (got * want).sum(-1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(want, axis=-1) + 1e-12)
+    ratio = np.linalg.norm(got, axis=-1) / (np.linalg.norm(want, axis=-1) + 1e-12)
+    print("d sigma_remap / dx vs the reference executed: cosine min %.5f, 1st percentile %.5f; length ratio %.4f .. %.4f" % (
+        cos.min(), np.percentile(cos, 1), ratio.min(), ratio.max()))
+    assert np.percentile(cos, 1) > 0.999 and cos.min() > 0.98
+    assert 0.97 < np.percentile(ratio, 1) and np.percentile(ratio, 99) < 1.03
+    n = normal_grad.float().cpu().numpy()
+    np.testing.assert_allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-3)

@@ -569,7 +569,7 @@ def _install_map_imports():
             self.v, self.f = np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.uint32)
 
         def trace(self, rays_o, rays_d, positions, face_normals, depth, face_idx):
-            pos, nrm, dep, face, _ = orc.raytrace(self.v, self.f, rays_o.numpy(), rays_d.numpy())
+            pos, nrm, dep, face, _ = orc.raytrace(self.v, self.f, rays_o.detach().numpy(), rays_d.detach().numpy())  # (the native op reads the storage whatever requires_grad says)
             positions.copy_(torch.from_numpy(pos)); face_normals.copy_(torch.from_numpy(nrm))
             depth.copy_(torch.from_numpy(dep)); face_idx.copy_(torch.from_numpy(face))
 
@@ -822,6 +822,91 @@ def round4_goldens():
     np.savez_compressed(os.path.join(OUT, "ref_python_run_cuda_fp32.npz"), **out)
     print("ref_python_run_cuda_fp32.npz: train", m, "samples /", int(out["train_counter"][1]), "rays; loss", out["train_loss"],
           "sigma range", float(out["train_sigma"].min()), float(out["train_sigma"].max()))
+
+
+    round4_projector_gradients()
+
+
+def round4_projector_gradients():
+    """MeshProjector.project(requires_grad_xyz=True) -- diff_project_layer, tools/map.py:171-186, :431-432 -- and its use_dir_vec=False
+    form, executed on the mesh and points of ref_python_projector.npz; and the branch of network_curvedfield.NeRFNetwork.forward that
+    differentiates sigma with respect to the sample position (nerf/network_curvedfield.py:236-259, use_grad_normal=True) executed with the
+    curved field of ref_python_curvedfield.npz: the normal it forms from that gradient is captured as torch.autograd.grad returns it."""
+    import torch
+
+    install_reference_imports()
+    _install_map_imports()
+    import tools.map as ref_map
+    from RayTracer import RayTracer as RefRayTracer
+
+    g = np.load(os.path.join(OUT, "ref_python_projector.npz"))
+    c = np.load(os.path.join(OUT, "ref_python_curvedfield.npz"))
+    v, f, vn, tbn, pts = g["vertices"], g["faces"], g["vertex_normals"], g["tbn"], g["xyz"]
+    mp = object.__new__(ref_map.MeshProjector)
+    mp.mesh_vertices, mp.vertex_normals, mp.tbn = torch.from_numpy(v), torch.from_numpy(vn), torch.from_numpy(tbn)
+    mp.grid, mp.radius, mp.max_K, mp.depth_threshold = None, 100.0, v.shape[0], 9.5
+    mp.raytracer = RefRayTracer(v, f)
+    rng = np.random.default_rng(81)
+    x = torch.from_numpy(pts).clone().requires_grad_(True)
+    p_sur, sdf, h_mask, normal, _ = mp.project(x, K=8, h_threshold=0.05, requires_grad_xyz=True)
+    assert np.array_equal(p_sur.detach().numpy(), g["p_sur"])
+    g_psur = rng.normal(size=p_sur.shape).astype(np.float32)
+    g_sdf = rng.normal(size=sdf.shape).astype(np.float32)
+    ((p_sur * torch.from_numpy(g_psur)).sum() + (sdf * torch.from_numpy(g_sdf)).sum()).backward()
+    out = dict(g_psur=g_psur, g_sdf=g_sdf, grad_xyz=x.grad.numpy().copy())
+    with torch.no_grad():
+        p2, s2, m2, n2, _ = mp.project(torch.from_numpy(pts), K=8, h_threshold=None, use_dir_vec=False)
+    out.update(nodir_p_sur=p2.numpy(), nodir_sdf=s2.numpy(), nodir_h_mask=m2.numpy(), nodir_normal=n2.numpy())
+
+    # the curved field as round3_goldens builds it (same seeds -> same table and weights: checked against the fixture)
+    for name, cls in (("sg_light_model", "SG_EnvmapMaterialNet"), ("sh_light_model", "SH_EnvmapMaterialNet"), ("envmap_light_model", "Envmap_EnvmapMaterialNet")):
+        _stub("nerf." + name, **{cls: None})
+    import nerf.network_curvedfield as ref_cf
+    from tools.encoding import get_encoder
+
+    torch.manual_seed(0)
+    mff = object.__new__(ref_map.MeshFeatureField)
+    torch.nn.Module.__init__(mff)
+    mff.h_threshold, mff.K, mff.bound, mff.hash, mff.prob_model, mff.pred_normal, mff.clustering = 0.05, 8, 1, True, False, False, True
+    mff.imported, mff.imported_type, mff.normal_net = False, None, None
+    mff.encoder, mff.encoder_f_out_dim = get_encoder("hashgrid_clustering", desired_resolution=1024, input_dim=3, num_levels=8, level_dim=2, base_resolution=512,
+                                                     log2_hashmap_size=19, align_corners=True)
+    mff.encoder_z, mff.encoder_z_outdim = get_encoder("frequency", input_dim=1, multires=12)
+    mff.meshprojector = mp
+    gen = torch.Generator().manual_seed(int(c["table_seed"]))
+    mff.encoder.embeddings.data.copy_(torch.rand(mff.encoder.embeddings.shape, generator=gen) - 0.5)
+    net = object.__new__(ref_cf.NeRFNetwork)
+    torch.nn.Module.__init__(net)
+    net.visual_mode, net.render_light_model, net.use_grad_normal, net.fc_weight, net.dir_degree = "RGB", False, True, 1.0, 4
+    net.optimize_gamma, net.meshfea_field = False, mff
+    tcnn = sys.modules["tinycudann"]
+    torch.manual_seed(42)
+    net.sigma_net = tcnn.Network(n_input_dims=mff.encoder_z_outdim + mff.encoder_f_out_dim, n_output_dims=16,
+                                 network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 32, "n_hidden_layers": 1})
+    net.encoder_dir = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "SphericalHarmonics", "degree": 4})
+    net.color_net = tcnn.Network(n_input_dims=net.encoder_dir.n_output_dims + 15, n_output_dims=3,
+                                 network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2})
+    assert np.array_equal(net.sigma_net.net.weights.detach().numpy(), c["w_sigma"]), "the curved field of ref_python_curvedfield.npz"
+    net.train()  # (the in-tree FFMLP that stands in for tcnn keeps no activations in eval mode: its backward needs the training forward)
+    captured = []
+    real_grad = torch.autograd.grad
+
+    def spy(*a, **k):
+        res = real_grad(*a, **k)
+        captured.append(res[0].detach().clone())
+        return res
+
+    torch.autograd.grad = spy
+    try:
+        with emulated_autocast():
+            sigma, color, _ = net(torch.from_numpy(pts).clone(), torch.from_numpy(c["dirs"]))
+    finally:
+        torch.autograd.grad = real_grad
+    assert len(captured) == 1
+    out.update(grad_normal_sigma=sigma.detach().float().numpy(), grad_normal_dsigma_remap_dx=captured[0].float().numpy())
+    np.savez_compressed(os.path.join(OUT, "ref_python_projector_grad.npz"), **out)
+    print("ref_python_projector_grad.npz: |dL/dxyz| max", float(np.abs(out["grad_xyz"]).max()), "; d sigma_remap / dx max", float(np.abs(out["grad_normal_dsigma_remap_dx"]).max()),
+          "nonzero rows", int((np.abs(out["grad_normal_dsigma_remap_dx"]).sum(-1) > 0).sum()), "of", pts.shape[0])
 
 
 if __name__ == "__main__":
