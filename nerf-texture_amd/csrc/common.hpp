@@ -67,7 +67,7 @@ enum Knob {
     kKnobFfmlpWgPerCu,   // forward: workgroups per CU (0 = default)
     kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
     kKnobMarchLean,      // 1: the training march's count pass compiled for 64 registers (spills; slower alone, a better neighbour on a shared CU)
-    kKnobFfmlpBwdSel,    // 1: fused MLP backward builds its weight-gradient operands with selection-matrix MFMAs instead of ds_read_b64_tr_b16
+    kKnobFfmlpBwdTr,     // 1: fused MLP backward builds its weight-gradient operands with ds_read_b64_tr_b16 instead of selection-matrix MFMAs (slower: A/B)
     kKnobCount
 };
 extern long g_knobs[kKnobCount];

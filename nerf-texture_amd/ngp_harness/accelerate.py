@@ -11,6 +11,8 @@ into the graphs; a trainer cannot):
     trainer = accelerate(renderer)                       # renderer: ngp_harness.model.Renderer over an NGPField
     loss = trainer.step(rays_o, rays_d, target_rgb)      # one training step; a device scalar, nothing is read back
     loss = trainer.step(rays_o, rays_d, target_rgb, next_rays=(o2, d2))   # ... and start marching the NEXT batch beside it
+    trainer = accelerate(renderer, steps_per_call=4)     # the benchmarked structure for a loop that has 4 batches at a time:
+    loss = trainer.step_group(o4, d4, t4, next_rays=(o4n, d4n))           # [4, N, 3] tensors: one graph for 4 steps, 4 marches ahead
 
   * the step replayed as HIP graphs, one set per slot of the renderer's 16-entry step-counter ring (renderer.py:656-660): the march of a
     batch (near / far, DDA, sample expansion: it needs the rays and the occupancy grid, NOT the weights) and the rest of the step (field,
@@ -39,7 +41,7 @@ RING = 16
 
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
-                 amp_dtype=torch.float16, graph=True):
+                 amp_dtype=torch.float16, graph=True, steps_per_call=1):
         from .model import NGPField
 
         field = renderer.field
@@ -63,7 +65,13 @@ class AcceleratedTrainer:
             self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype in (torch.float16, torch.bfloat16))  # (the table gradient is fp16 either way)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
         self._graphs, self._M = None, 0
-        self._rays, self._target = None, None  # static inputs: rays per ring slot (the march of slot g + 1 may run while slot g's is still read), one target
+        # steps_per_call = k > 1: `step_group` takes the batches of k consecutive steps at once and replays ONE graph for their shade + backward +
+        # optimizer (the hand-over between two graph launches idles the device ~10 us: bench.py's --steps-per-graph), their k marches being
+        # graphs of their own that run ahead on the second stream when the caller hands the NEXT group's rays over
+        self.group = int(steps_per_call)
+        assert self.group in (1, 2, 4, 8, 16), "steps_per_call must divide the 16-entry step-counter ring"
+        self._groups = None
+        self._rays, self._targets = None, None  # static inputs per ring slot: rays (the march of slot g + 1 may run while slot g's is still read), targets
         self._primed, self._warm = 0, 0
         self._ahead = None  # (slot, data_ptr of rays_o, data_ptr of rays_d) of a march started by `next_rays`
         self._side = None
@@ -104,15 +112,104 @@ class AcceleratedTrainer:
             with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"):  # (own memory pool: it may run beside the other graph)
                 marched, _ = self._march(*self._rays[g], mean_count=self._M)
             pool_m = gm.pool()
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
-                self._shade(marched, self._target)
-            pool = ga.pool()
+            ga = None
+            if self.group == 1:
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                    self._shade(marched, self._targets[g])
+                pool = ga.pool()
             graphs.append((gm, ga, marched))  # (the sample tensors stay alive: the second graph reads them)
+        self._groups = None
+        if self.group > 1:  # shade + backward + optimizer of `group` consecutive steps per graph
+            self._groups = []
+            for g0 in range(0, RING, self.group):
+                gg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gg, pool=pool, capture_error_mode="thread_local"):
+                    for g in range(g0, g0 + self.group):
+                        self._shade(graphs[g][2], self._targets[g])
+                pool = gg.pool()
+                self._groups.append(gg)
         self._graphs = graphs
         r.local_step = keep_step % RING
 
-    def step(self, rays_o, rays_d, target, next_rays=None):
+    def _ensure_buffers(self, n_rays):
+        if self._rays is None:
+            self.n_rays = n_rays
+            self._ray_o = torch.empty(RING, n_rays, 3, dtype=torch.float32, device=self.dev)
+            self._ray_d = torch.empty(RING, n_rays, 3, dtype=torch.float32, device=self.dev)
+            self._rays = [(self._ray_o[g], self._ray_d[g]) for g in range(RING)]
+            self._targets = torch.empty(RING, n_rays, 3, dtype=torch.float32, device=self.dev)
+        assert n_rays == self.n_rays, "a captured step has a fixed batch size"
+
+    def _ring_end(self, ready):
+        """One read-back per 16 steps, as in the reference.  Every march of the ring has run by now, so with a second stream at hand the
+        read-back waits for the marches only, not for the last step's backward.  Nothing is marched ahead across the ring's end: that is
+        where the trainer updates the occupancy grid (nerf/utils.py:1011, before the next step), and a march started here would read the grid
+        while the update writes it."""
+        r = self.renderer
+        if ready is not None:
+            with torch.cuda.stream(self._side_stream()):
+                self._side.wait_event(ready)
+                r.update_mean_count()
+        else:
+            r.update_mean_count()
+        self._resize()
+
+    def step_group(self, rays_o, rays_d, target, next_rays=None):
+        """steps_per_call = k consecutive training steps in one call: rays_o / rays_d / target [k, N, 3] -- batch i is step i's (FRESH rays every
+        call: they are copied into the graphs' static buffers).  next_rays = (rays_o, rays_d) [k, N, 3] of the NEXT call: their k marches start
+        now, on the second stream, beside this group's kernels; the next call must pass those very tensors.  Same arithmetic as k calls of
+        `step`: the same kernels in the same order on the same data (tests/test_gpu_round4.py).  Returns the last step's loss (device scalar)."""
+        r, k = self.renderer, self.group
+        assert k > 1 and rays_o.shape[0] == k and rays_o.dim() == 3, "step_group: [steps_per_call, N, 3] rays (steps_per_call > 1)"
+        assert rays_o.is_contiguous() and rays_d.is_contiguous(), "step_group: rays_o / rays_d must be contiguous [k, N, 3] tensors"
+        self._ensure_buffers(rays_o.shape[1])
+        if not self.use_graph or self._primed < RING or self._warm < max(2, k):
+            # the reference's first steps (full-size buffers until the ring holds a mean count), then `k` eager steps at the size the graphs
+            # will be recorded with -- one by one, on the eager path; k of them so that the ring slot is a multiple of k when the graphs start
+            assert self._ahead is None
+            for i in range(k):
+                self.step(rays_o[i], rays_d[i], target[i], _eager=True)
+            return self.loss
+        assert r.local_step % k == 0, "step_group and step must not be mixed once the graphs run (the ring slot must stay a multiple of steps_per_call)"
+        if self._graphs is None:
+            self._capture()
+        g0 = r.local_step
+        main = torch.cuda.current_stream()
+        if self._ahead is not None and self._ahead == (g0, rays_o.data_ptr(), rays_d.data_ptr()):
+            main.wait_stream(self._side)  # marched beside the previous group
+        else:
+            if self._ahead is not None:
+                self._ahead = None
+                main.wait_stream(self._side)
+                raise AssertionError("next_rays of the previous call must be the rays of this call (same tensors)")
+            self._ray_o[g0:g0 + k].copy_(rays_o, non_blocking=True), self._ray_d[g0:g0 + k].copy_(rays_d, non_blocking=True)
+            for g in range(g0, g0 + k):
+                self._graphs[g][0].replay()
+        self._ahead = None
+        self._targets[g0:g0 + k].copy_(target, non_blocking=True)
+        last = g0 + k == RING
+        ready = None
+        if next_rays is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)  # everything enqueued so far (the production of the next rays, an occupancy update) -- NOT this group's kernels
+        self._groups[g0 // k].replay()
+        r.local_step = g0 + k
+        if not last:
+            if ready is not None:
+                no, nd = next_rays
+                assert no.shape == rays_o.shape and no.is_contiguous() and nd.is_contiguous(), "next_rays: contiguous [k, N, 3] tensors"
+                with torch.cuda.stream(self._side_stream()):
+                    self._side.wait_event(ready)
+                    self._ray_o[g0 + k:g0 + 2 * k].copy_(no, non_blocking=True), self._ray_d[g0 + k:g0 + 2 * k].copy_(nd, non_blocking=True)
+                    for g in range(g0 + k, g0 + 2 * k):
+                        self._graphs[g][0].replay()
+                self._ahead = (g0 + k, no.data_ptr(), nd.data_ptr())
+        else:
+            self._ring_end(ready)
+        return self.loss
+
+    def step(self, rays_o, rays_d, target, next_rays=None, _eager=False):
         """One training step on a batch of rays [N,3], [N,3] and their target colours [N,3] (device tensors; N fixed after the first call).
         next_rays = (rays_o, rays_d) of the batch the NEXT call will pass: its march starts now, beside this step (module docstring).
         Returns the loss as a device scalar that the NEXT call overwrites."""
@@ -121,27 +218,24 @@ class AcceleratedTrainer:
         # tensor would be a fresh copy with a fresh address every call)
         rays_o, rays_d, target = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), target.reshape(-1, 3)
         assert rays_o.is_contiguous() and rays_d.is_contiguous(), "accelerate().step: rays_o / rays_d must be contiguous [N,3] tensors"
-        if self._rays is None:
-            self.n_rays = rays_o.shape[0]
-            self._rays = [(torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev), torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev))
-                          for _ in range(RING)]
-            self._target = torch.empty(self.n_rays, 3, dtype=torch.float32, device=self.dev)
-        assert rays_o.shape[0] == self.n_rays, "a captured step has a fixed batch size"
+        self._ensure_buffers(rays_o.shape[0])
         main = torch.cuda.current_stream()
-        if not self.use_graph or self._primed < RING or self._warm < 2:
+        if _eager or not self.use_graph or self._primed < RING or self._warm < 2:
             # the reference's first steps: full-size sample buffers until the ring holds a mean count (its update_extra_state cadence);
             # then -- and after every change of the buffer size -- two eager steps at the size the graphs will be recorded with
             sized = self._primed >= RING  # (graph=False keeps the same buffer-size policy, launched eagerly)
             ro, rd = self._rays[r.local_step % RING]
-            ro.copy_(rays_o, non_blocking=True), rd.copy_(rays_d, non_blocking=True), self._target.copy_(target, non_blocking=True)
+            tg = self._targets[r.local_step % RING]
+            ro.copy_(rays_o, non_blocking=True), rd.copy_(rays_d, non_blocking=True), tg.copy_(target, non_blocking=True)
             marched, _ = self._march(ro, rd, mean_count=self._M if sized else None)
-            self._shade(marched, self._target)
+            self._shade(marched, tg)
             self._primed += 1
             self._warm += 1 if sized else 0
             if r.local_step == RING:
                 r.update_mean_count()
                 self._resize()
             return self.loss
+        assert self.group == 1, "this trainer was built with steps_per_call > 1: call step_group"
         if self._graphs is None:
             self._capture()
         g = r.local_step
@@ -156,7 +250,7 @@ class AcceleratedTrainer:
             self._rays[g][0].copy_(rays_o, non_blocking=True), self._rays[g][1].copy_(rays_d, non_blocking=True)
             gm.replay()
         self._ahead = None
-        self._target.copy_(target, non_blocking=True)
+        self._targets[g].copy_(target, non_blocking=True)
         last = g + 1 == RING
         ready = None
         if next_rays is not None:
@@ -168,17 +262,7 @@ class AcceleratedTrainer:
             if ready is not None:
                 self._march_ahead(g + 1, next_rays, ready)
         else:
-            # one read-back per 16 steps, as in the reference.  Every march of the ring has run by now, so with a second stream at hand the
-            # read-back waits for the marches only, not for this step's backward.  Nothing is marched ahead across the ring's end: that is
-            # where the trainer updates the occupancy grid (nerf/utils.py:1011, before the next step), and a march started here would read
-            # the grid while the update writes it
-            if ready is not None:
-                with torch.cuda.stream(self._side_stream()):
-                    self._side.wait_event(ready)
-                    r.update_mean_count()
-            else:
-                r.update_mean_count()
-            self._resize()
+            self._ring_end(ready)
         return self.loss
 
     def _side_stream(self):
@@ -208,9 +292,10 @@ class AcceleratedTrainer:
                 torch.cuda.synchronize()
                 check(lib.nerftex_release_workspaces())
             self._M = (r.mean_count + 4095) // 4096 * 4096 + 4096
-            self._graphs, self._warm = None, 0
+            self._graphs, self._groups, self._warm = None, None, 0
 
 
 def accelerate(renderer, **kw):
-    """See the module docstring.  Keyword arguments: rays_per_batch, lr, betas, eps, dt_gamma, bg_color, perturb, max_steps, amp_dtype, graph."""
+    """See the module docstring.  Keyword arguments: rays_per_batch, lr, betas, eps, dt_gamma, bg_color, perturb, max_steps, amp_dtype, graph,
+    steps_per_call (k > 1: `step_group` takes the batches of k consecutive steps and replays one graph for them)."""
     return AcceleratedTrainer(renderer, **kw)
