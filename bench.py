@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
     ap.add_argument("--infer-parts", type=int, default=3, help="ray ranges of the rendered frame, each on its own stream")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--warm-seconds", type=float, default=0.5, help="untimed steps (beyond --warmup) until this much wall time has passed under load, right before "
+                    "the timed region: the device's clocks after an idle phase")
     ap.add_argument("--no-replay-profile", action="store_true", help="skip the per-kernel timing of the REPLAYED step (a child run of this script under "
                     "rocprofv3 --kernel-trace --stats, ~40 s); roofline.avg_launch_ms then comes from the committed profile or from eager launches")
     ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
@@ -497,6 +499,16 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = split_graph = march_ahead = False
+    # clocks: a device that idled (process start-up, a graph capture, a profiler run in another process) needs a while under load before it
+    # runs at speed -- the first ring after an idle phase measured 30 % slow, a loop started right after 30 idle seconds 2x slow for 0.3 s.
+    # Untimed steps until --warm-seconds of wall time have passed (whole rings, so the ring bookkeeping below is unchanged)
+    t_w = time.perf_counter()
+    k_w = 0
+    while time.perf_counter() - t_w < args.warm_seconds:
+        for _ in range(RING):
+            graph_step(k_w) if use_graph else train_step(k_w, count=False)
+            k_w += 1
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     counted["rings"] = -partial_ring()  # the steps of the ring in progress that ran before the timed region
 
@@ -521,12 +533,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         spread = {"min": q[0], "median": q[len(q) // 2], "max": q[-1], "rings": len(q),
                   "note": "ms per step over each 16-step ring of the timed region (device events on the main stream)"}
     samples_timed = torch.tensor(counted["rings"] + partial_ring(), dtype=torch.int64, device=dev)
-    # ---- per-kernel durations INSIDE the replayed step.  hipEvent pairs cannot be read back from a replayed graph (and external event-record
-    # nodes fail to capture on this stack), so this very script runs once more as a child under `rocprofv3 --kernel-trace --stats`: same
-    # workload, same graphs, the marches of the next steps on the second stream -- the device durations rocprofv3 reports are the replay's own.
-    replay_us = {}
-    if time_grid_kernels and use_graph and world == 1 and not args.no_replay_profile:
-        replay_us = rocprof_replay(args, mlp, rays, dtype)
+    replay_us = {}  # (filled by main(): the rocprofv3 child runs after every timed loop of this process -- the device idles ~30 s meanwhile)
     kernel_us, all_kernel_us = {}, {}
     if time_grid_kernels:
         if use_graph:  # event pairs cannot be read back from a replayed graph: the same step, launched eagerly, right after the timed region
@@ -584,7 +591,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     if time_grid_kernels and not args.no_occupancy_timing:
         occupancy = measure_occupancy_update(renderer, use_amp, amp_dtype, elapsed / steps * 1e3, samples / steps / world)
     res = dict(replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
-               replay_us=replay_us, spread=spread, occupancy=occupancy,
+               replay_us=replay_us, spread=spread, occupancy=occupancy, graph_used=bool(use_graph),
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
                       (f"replayed HIP graphs: shade + backward + optimizer of {group} consecutive steps per graph, and on a second stream the marches of the next {group} steps (a march needs the rays and the occupancy grid, not the weights)") if march_ahead else
@@ -734,8 +741,11 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1):
     per_call = max(group, 1)
     for c in range((16 + 16 + 48) // per_call):  # priming (full-size buffers, mean count), warm steps, capture, past the first mean_count read-backs
         call(c)
-    while renderer.local_step != 0:  # start the timed region on a ring boundary (the sample count is read from whole rings)
-        call(c := c + 1)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.warm_seconds or renderer.local_step != 0:  # clocks (see measure_training); then on to a ring boundary
+        call(c := c + 1)                                                               # (the sample count is read from whole rings)
+        if renderer.local_step == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     base = c + 1
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps // 16 + 1)]
@@ -894,66 +904,6 @@ def main():
             print(f"[bench] fresh-ray loop failed ({type(e).__name__}: {e}); headline = the baked-pool loop", file=sys.stderr)
             fresh = None
 
-    # ---- roofline of the dominant hash-grid op, from the library's own per-kernel hipEvent pairs over the timed region
-    M_launch = renderer.mean_count + 128 - renderer.mean_count % 128  # rows per launch (padded like raymarching.py:198-201)
-    s_bytes = 2 if use_amp else 4
-    bytes_fwd = 12 + 8 * 16 * 2 * s_bytes + 16 * 2 * s_bytes  # SURVEY 8(d): 588 B (fp16) / 1164 B (fp32) per point
-    bytes_bwd = 12 + 16 * 2 * s_bytes + 8 * 16 * 2 * s_bytes
-    def per_op(prof):
-        kern = {}
-        for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
-            parts = {k: prof[k] for k in GRID_KERNELS[name] if k in prof}
-            if parts:
-                calls = max(v["calls"] for v in parts.values())
-                ms = sum(v["total_us"] for v in parts.values()) / calls * 1e-3
-                kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
-                              "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in parts.items()}}
-        return kern
-
-    # durations: from INSIDE the replayed step when they could be taken there (external event-record nodes in a copy of the step's graph, the
-    # next steps' marches running beside it as in the timed region), else from eager launches of the same step after the timed region
-    replay_us = dict(res.get("replay_us") or {})
-    child = replay_us.pop("_child", None)
-    source = "rocprofv3 --kernel-trace --stats over a child run of this script (same workload, %d replayed steps, child ms_per_step %.4f)" % (
-        child["steps"], child["ms_per_step"]) if child else None
-    if not replay_us and res["graph"] and os.path.exists(os.path.join(ROOT, COMMITTED_STATS)):  # no live profile: the committed one, labelled
-        replay_us = read_kernel_stats(os.path.join(ROOT, COMMITTED_STATS))
-        source = "CONSTANT from " + COMMITTED_STATS + " (rocprofv3 of the same command, committed): no live rocprofv3 run in this invocation"
-    res["replay_us"] = replay_us
-    in_replay = bool(replay_us)
-    kern = per_op(res["replay_us"] if in_replay else res["kernel_us"])
-    kern_eager = per_op(res["kernel_us"]) if in_replay else {}
-    # what bounds each op, by the counters (DESIGN.md 4): the gather is served by the L2s (94 % hits, 128-B lines for 8-B rows): it sits on the
-    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r03_pmc_sq_grid.txt) -- its algorithmic bytes are
-    # still priced against HBM, the nearest roof the contract names
-    BOUND = {"grid_encode_forward": ("l2_line", "the gather is bound by the L2 -> L1 line bandwidth (9.4x line amplification: 128 B moved per 8 B used, 94 % L2 hits; "
-                                                "profiles/r03_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
-             "grid_encode_backward": ("hbm", "priced against HBM as the contract asks; by the SQ counters both kernels sit on VALU issue (DESIGN.md 4.1)")}
-    dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
-    roofline = None
-    if dominant:
-        for k_, v_ in kern.items():
-            v_["bound"], v_["bound_note"] = BOUND[k_]
-            v_["frac_of_hbm_peak"] = v_["gbs"] / HBM_PEAK_GBS
-        roofline = {
-            "bound": BOUND[dominant][0], "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dominant),
-            "traffic_source": "CONSTANT, not measured in this run: PMC counters need their own rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE over "
-                              "tools/bench_kernels.py at this workload, summary in " + TRAFFIC_PROFILE + "; 2 x FETCH_SIZE + WRITE_SIZE as the guide's gfx950 "
-                              "correction prescribes for coalesced streams)",
-            "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
-            "kernels_avg_us": kern[dominant]["kernels_avg_us"],
-            "durations_from": ("the replayed step: " + source if in_replay else
-                               "eager launches of the same step after the timed region (hipEvent pairs)" if res["graph"] else "the timed region itself (hipEvent pairs)"),
-            "eager_avg_launch_ms": kern_eager.get(dominant, {}).get("ms"),
-            "other": {k: v for k, v in kern.items() if k != dominant},
-            "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted((res["replay_us"] if in_replay else res["all_kernel_us"]).items(),
-                                                                              key=lambda kv: -kv[1]["total_us"])},
-            "all_kernels_avg_us_eager": {k: round(v["avg_us"], 2) for k, v in sorted(res["all_kernel_us"].items(), key=lambda kv: -kv[1]["total_us"])} if in_replay else None,
-            "note": "avg_launch_ms = sum of the device durations of the kernels one C-ABI call launches (hipEvent pairs recorded by the library on the "
-                    "launch stream, names = rocprofv3 kernel names); the 24 MiB table is Infinity-Cache resident, see DESIGN.md 4/6",
-        }
-
     # ---- rendered Mpix/s: one 800x800 frame through the reference's inference loop (nerf/renderer.py:436-487)
     mpix = None
     if not args.no_infer and rank == 0:
@@ -1022,6 +972,74 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, bits, args.cpu_rays)
+
+    # ---- per-kernel durations INSIDE the replayed step.  hipEvent pairs cannot be read back from a replayed graph (and external event-record
+    # nodes fail to capture on this stack), so this very script runs once more as a child under `rocprofv3 --kernel-trace --stats`: same
+    # workload, same graphs, the marches of the next steps on the second stream -- the device durations rocprofv3 reports are the replay's own.
+    # LAST of everything this process measures: the device idles for ~30 s while rocprofv3 writes its tables, and a loop timed right after
+    # that runs on cold clocks (2x slow for a third of a second: tools/fresh_probe2.py).
+    if rank == 0 and not args.no_kernel_timing and res.get("graph_used") and world == 1 and not args.no_replay_profile:
+        res["replay_us"] = rocprof_replay(args, args.mlp, args.rays, res["dtype"])
+
+    # ---- roofline of the dominant hash-grid op, from the library's own per-kernel hipEvent pairs over the timed region
+    M_launch = renderer.mean_count + 128 - renderer.mean_count % 128  # rows per launch (padded like raymarching.py:198-201)
+    s_bytes = 2 if use_amp else 4
+    bytes_fwd = 12 + 8 * 16 * 2 * s_bytes + 16 * 2 * s_bytes  # SURVEY 8(d): 588 B (fp16) / 1164 B (fp32) per point
+    bytes_bwd = 12 + 16 * 2 * s_bytes + 8 * 16 * 2 * s_bytes
+    def per_op(prof):
+        kern = {}
+        for name, bpp in (("grid_encode_forward", bytes_fwd), ("grid_encode_backward", bytes_bwd)):
+            parts = {k: prof[k] for k in GRID_KERNELS[name] if k in prof}
+            if parts:
+                calls = max(v["calls"] for v in parts.values())
+                ms = sum(v["total_us"] for v in parts.values()) / calls * 1e-3
+                kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
+                              "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in parts.items()}}
+        return kern
+
+    # durations: from INSIDE the replayed step when they could be taken there (external event-record nodes in a copy of the step's graph, the
+    # next steps' marches running beside it as in the timed region), else from eager launches of the same step after the timed region
+    replay_us = dict(res.get("replay_us") or {})
+    child = replay_us.pop("_child", None)
+    source = "rocprofv3 --kernel-trace --stats over a child run of this script (same workload, %d replayed steps, child ms_per_step %.4f)" % (
+        child["steps"], child["ms_per_step"]) if child else None
+    if not replay_us and res["graph"] and os.path.exists(os.path.join(ROOT, COMMITTED_STATS)):  # no live profile: the committed one, labelled
+        replay_us = read_kernel_stats(os.path.join(ROOT, COMMITTED_STATS))
+        source = "CONSTANT from " + COMMITTED_STATS + " (rocprofv3 of the same command, committed): no live rocprofv3 run in this invocation"
+    res["replay_us"] = replay_us
+    in_replay = bool(replay_us)
+    kern = per_op(res["replay_us"] if in_replay else res["kernel_us"])
+    kern_eager = per_op(res["kernel_us"]) if in_replay else {}
+    # what bounds each op, by the counters (DESIGN.md 4): the gather is served by the L2s (94 % hits, 128-B lines for 8-B rows): it sits on the
+    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r03_pmc_sq_grid.txt) -- its algorithmic bytes are
+    # still priced against HBM, the nearest roof the contract names
+    BOUND = {"grid_encode_forward": ("l2_line", "the gather is bound by the L2 -> L1 line bandwidth (9.4x line amplification: 128 B moved per 8 B used, 94 % L2 hits; "
+                                                "profiles/r03_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
+             "grid_encode_backward": ("hbm", "priced against HBM as the contract asks; by the SQ counters both kernels sit on VALU issue (DESIGN.md 4.1)")}
+    dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
+    roofline = None
+    if dominant:
+        for k_, v_ in kern.items():
+            v_["bound"], v_["bound_note"] = BOUND[k_]
+            v_["frac_of_hbm_peak"] = v_["gbs"] / HBM_PEAK_GBS
+        roofline = {
+            "bound": BOUND[dominant][0], "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dominant),
+            "traffic_source": "CONSTANT, not measured in this run: PMC counters need their own rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE over "
+                              "tools/bench_kernels.py at this workload, summary in " + TRAFFIC_PROFILE + "; 2 x FETCH_SIZE + WRITE_SIZE as the guide's gfx950 "
+                              "correction prescribes for coalesced streams)",
+            "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
+            "kernels_avg_us": kern[dominant]["kernels_avg_us"],
+            "durations_from": ("the replayed step: " + source if in_replay else
+                               "eager launches of the same step after the timed region (hipEvent pairs)" if res["graph"] else "the timed region itself (hipEvent pairs)"),
+            "eager_avg_launch_ms": kern_eager.get(dominant, {}).get("ms"),
+            "other": {k: v for k, v in kern.items() if k != dominant},
+            "all_kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted((res["replay_us"] if in_replay else res["all_kernel_us"]).items(),
+                                                                              key=lambda kv: -kv[1]["total_us"])},
+            "all_kernels_avg_us_eager": {k: round(v["avg_us"], 2) for k, v in sorted(res["all_kernel_us"].items(), key=lambda kv: -kv[1]["total_us"])} if in_replay else None,
+            "note": "avg_launch_ms = sum of the device durations of the kernels one C-ABI call launches (hipEvent pairs recorded by the library on the "
+                    "launch stream, names = rocprofv3 kernel names); the 24 MiB table is Infinity-Cache resident, see DESIGN.md 4/6",
+        }
 
     if rank == 0:
         head = fresh if fresh is not None else res

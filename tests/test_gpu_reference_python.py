@@ -110,10 +110,22 @@ def test_occupancy_maintenance_matches_reference_python(dev):
         # repeated indices -- which duplicate wins is unspecified in the reference too (its own fixture changes from run to run) --
         # so cells sampled twice on both sides of an edge may differ.
         full = step < 2
-        assert (got != want).sum() <= (2 if full else 0.01 * got.size), (step, int((got != want).sum()))
-        assert abs(r.mean_density - float(g[f"mean_density_{step}"])) < (1e-4 if full else 2e-3)
-        flips = np.unpackbits(r.density_bitfield.cpu().numpy() ^ g[f"bitfield_{step}"]).sum()
-        assert flips <= (4 if full else 0.002 * 8 * g[f"bitfield_{step}"].size), (step, int(flips))
+        if full:
+            assert (got != want).sum() <= 2, (step, int((got != want).sum()))
+            assert abs(r.mean_density - float(g[f"mean_density_{step}"])) < 1e-4
+            flips = np.unpackbits(r.density_bitfield.cpu().numpy() ^ g[f"bitfield_{step}"]).sum()
+            assert flips <= 4, (step, int(flips))
+        else:
+            # the cells this update names at most ONCE are written exactly once in the reference too: those must agree like a full sweep's
+            # (round 4: this replaces a bar of 1 % of the probed cells / 0.2 % of the bits; the cells named several times are covered by
+            # tests/test_gpu_round3.py::test_occupancy_partial_update_is_exact_on_singly_drawn_cells, which knows which write wins)
+            per_cas = r.density_grid.shape[1]
+            times = torch.zeros(r.density_grid.numel(), dtype=torch.int32, device=dev)
+            for cas, idx in enumerate(r.last_partial_indices):
+                times.index_add_(0, idx + cas * per_cas, torch.ones_like(idx, dtype=torch.int32))
+            once = (times[probe] <= 1).cpu().numpy()
+            assert once.mean() > 0.5 and (got[once] != want[once]).sum() <= 2, (step, int((got[once] != want[once]).sum()), float(once.mean()))
+            assert abs(r.mean_density - float(g[f"mean_density_{step}"])) < 2e-3  # (a mean over all cells, the multiply-drawn ones included)
         assert r.mean_count == int(g[f"mean_count_{step}"]) and r.local_step == 0
 
 
