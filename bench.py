@@ -324,7 +324,9 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # ring's mean rounded up to 4096 + 4096); all graphs share one memory pool (they never run concurrently).
     RING = 16  # = the renderer's step-counter ring: graph g is step g of a 16-step cycle
     gstate = {"graphs": None, "M": 0, "marched": -1}
-    side_stream = torch.cuda.Stream(device=dev, priority=-1) if march_ahead else None  # high priority: its few, fat workgroups go first when slots free up
+    from ngp_harness.streams import side_stream as shared_side_stream
+
+    side_stream = shared_side_stream(dev) if march_ahead else None  # high priority; ONE per process (ngp_harness/streams.py: a later-created one may share a hardware queue)
 
     def body_march(g):
         renderer.local_step = g  # the step's counter is ring slot g, exactly as in the eager loop

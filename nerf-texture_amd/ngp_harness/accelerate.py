@@ -176,6 +176,14 @@ class AcceleratedTrainer:
             self._capture()
         g0 = r.local_step
         main = torch.cuda.current_stream()
+        _t = getattr(self, "_host_times", None)  # debugging aid: host seconds spent in each part of the call (tools/fresh_probe4.py)
+        _c = [__import__("time").perf_counter()] if _t is not None else None
+
+        def _lap(name):
+            if _t is not None:
+                now = __import__("time").perf_counter()
+                _t.setdefault(name, []).append(now - _c[0])
+                _c[0] = now
         if self._ahead is not None and self._ahead == (g0, rays_o.data_ptr(), rays_d.data_ptr()):
             main.wait_stream(self._side)  # marched beside the previous group
         else:
@@ -186,14 +194,18 @@ class AcceleratedTrainer:
             self._ray_o[g0:g0 + k].copy_(rays_o, non_blocking=True), self._ray_d[g0:g0 + k].copy_(rays_d, non_blocking=True)
             for g in range(g0, g0 + k):
                 self._graphs[g][0].replay()
+        _lap("wait_or_march")
         self._ahead = None
         self._targets[g0:g0 + k].copy_(target, non_blocking=True)
+        _lap("copy_targets")
         last = g0 + k == RING
         ready = None
         if next_rays is not None:
             ready = torch.cuda.Event()
             ready.record(main)  # everything enqueued so far (the production of the next rays, an occupancy update) -- NOT this group's kernels
+        _lap("ready")
         self._groups[g0 // k].replay()
+        _lap("group_replay")
         r.local_step = g0 + k
         if not last:
             if ready is not None:
@@ -205,8 +217,10 @@ class AcceleratedTrainer:
                     for g in range(g0 + k, g0 + 2 * k):
                         self._graphs[g][0].replay()
                 self._ahead = (g0 + k, no.data_ptr(), nd.data_ptr())
+            _lap("march_ahead")
         else:
             self._ring_end(ready)
+            _lap("ring_end")
         return self.loss
 
     def step(self, rays_o, rays_d, target, next_rays=None, _eager=False):
@@ -267,7 +281,9 @@ class AcceleratedTrainer:
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev, priority=-1)  # its few, fat workgroups go first when slots free up
+            from .streams import side_stream
+
+            self._side = side_stream(self.dev)  # the process-wide high-priority stream (streams.py: why it is shared)
         return self._side
 
     def _march_ahead(self, slot, next_rays, ready):

@@ -487,10 +487,9 @@ class Renderer(nn.Module):
             self.last_iters = part.i
             return part.image + (1 - part.weights_sum).unsqueeze(-1) * bg_color, part.depth, part.n_samples
         main = torch.cuda.current_stream()
-        streams = getattr(self, "_infer_streams", [])
-        while len(streams) < parts:
-            streams.append(torch.cuda.Stream(device=rays_o.device))
-        self._infer_streams = streams
+        from .streams import part_streams
+
+        streams = part_streams(rays_o.device, parts)  # process-wide (streams.py: a process should not keep creating streams)
         per = -(-N // parts)
         jobs = []
         for k in range(parts):
