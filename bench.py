@@ -255,6 +255,24 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     wire_dtype = torch.float32 if args.wire == "fp32" else (torch.float16 if dtype == "fp16" else None)
     reducer = dp.FlatGradAllReduce(trainable, average=False, big_comm_dtype=wire_dtype,
                                    big_numel=0 if fused_opt else 1 << 20)
+    # N > 1, --allreduce-chunks k > 1: the table gradient is finished and exchanged level group by level group (dp.TableGradChunks)
+    chunker = None
+    if world > 1 and args.allreduce_chunks > 1 and fused_opt and field.fused_field:
+        chunker = dp.TableGradChunks(field.encoder, args.allreduce_chunks)
+
+    def exchange(grads=None, state=None):
+        """One step's gradient exchange, start to finish (grads / state: the tensors and the per-group work of a captured backward)."""
+        if chunker is None:
+            reducer.all_reduce(grads=grads)
+            return
+        g = list(grads) if grads is not None else reducer.big_grads()
+        hs = []
+        for i in range(len(chunker)):
+            chunker.sum_chunk(i, state)  # rows of level group i are final ...
+            hs.append(reducer.start_tensor(chunker.view(i, g[0], state)))  # ... and go on the wire while the next group is summed
+        h2 = reducer.all_reduce_start([None] + g[1:])  # the two MLPs' gradients
+        reducer.finish_tensors(hs)
+        reducer.all_reduce_finish(h2)
     inv_world = 1.0 / world
     # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
     amp = FusedAmp(opt) if fused_amp else None
@@ -313,7 +331,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         ro, rd = pool[k % n_pool]
         reducer.zero_grad()
         counter = forward_backward(ro, rd, gt[k % n_pool])
-        reducer.all_reduce()
+        exchange()
         optimizer_step()
         if renderer.local_step == 16:  # update_extra_state cadence (nerf/utils.py:1011): mean_count read-back
             ring_end()
@@ -346,7 +364,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         with torch.cuda.stream(side):
             for g in range(3):  # allocator / library workspaces at this size, outside the capture
                 body_fb(g)
-                reducer.all_reduce()
+                exchange()
                 body_opt()
         torch.cuda.current_stream().wait_stream(side)
         graphs, mem, marches = [], None, [None] * RING
@@ -386,7 +404,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 try:
                     with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
                         body_fb(g, marches[g][1])
-                        reducer.all_reduce()
+                        exchange()
                         body_opt()
                     mem = ga.pool()
                     graphs.append((marches[g][0], ga, "in_graph", None))
@@ -406,7 +424,19 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             if split_graph:
                 gm = marches[g][0]
                 grads = reducer.big_grads()  # this graph's gradient tensors: A writes them, the all-reduce and B read them -- kept alive
-                reducer.all_reduce(grads=grads)
+                if chunker is not None:  # A only binned the table's contributions: one small graph per level group finishes its rows
+                    state = chunker.take()
+                    sums = []
+                    for i in range(len(chunker)):
+                        gs_ = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gs_, pool=mem, capture_error_mode="thread_local"):
+                            chunker.sum_chunk(i, state)
+                        mem = gs_.pool()
+                        sums.append(gs_)
+                    reducer.all_reduce(grads=grads)  # (as below: the collective sees these buffers once before the timed region; their contents are not used)
+                    grads = (grads, state, sums)
+                else:
+                    reducer.all_reduce(grads=grads)
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=mem, capture_error_mode="thread_local"):
                     body_opt()
@@ -459,10 +489,20 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             if gstate["marched"] != g:
                 gm.replay()
             ga.replay()
-            handle = reducer.all_reduce_start(grads)
+            if chunker is not None:
+                g_list, state, sums = grads
+                hs = []
+                for i, gs_ in enumerate(sums):
+                    gs_.replay()  # rows of level group i are final ...
+                    hs.append(reducer.start_tensor(chunker.view(i, g_list[0], state)))  # ... and on the wire while group i + 1 is summed
+                handle = reducer.all_reduce_start([None] + list(g_list[1:]))
+            else:
+                handle = reducer.all_reduce_start(grads)
             if g + 1 < RING:  # not across the ring's end: the mean_count read-back (and a possible re-capture) comes first there
                 gstate["graphs"][g + 1][0].replay()
                 gstate["marched"] = g + 1
+            if chunker is not None:
+                reducer.finish_tensors(hs)
             reducer.all_reduce_finish(handle)
             gb.replay()
         renderer.local_step = g + 1
@@ -573,11 +613,26 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             reducer.all_reduce(grads=grads)
         ev1.record()
         torch.cuda.synchronize()
+        chunk_us = None
+        if chunker is not None:  # each level group's all-reduce on its own
+            chunk_us = []
+            for i in range(len(chunker)):
+                a_, b_ = chunker.rows[i]
+                view = grads[0][a_:b_]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                dist.barrier()
+                e0.record()
+                for _ in range(10):
+                    reducer.finish_tensors([reducer.start_tensor(view)])
+                e1.record()
+                torch.cuda.synchronize()
+                chunk_us.append({"levels": list(chunker.levels[i]), "rows": b_ - a_, "us": e0.elapsed_time(e1) * 100.0})
         collective = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""), "world_size": dist.get_world_size(),
                       "wire_dtype": str(wire_dtype).replace("torch.", "") if wire_dtype is not None else "the gradient's dtype",
                       "bytes_per_step": int(sum(g.numel() * (torch.finfo(wire_dtype).bits // 8 if wire_dtype else g.element_size()) for g in grads if g is not None)),
                       "allreduce_us_per_step": ev0.elapsed_time(ev1) * 100.0,
-                      "allreduce_in_graph": bool(use_graph and ar_state["in_graph"])}
+                      "allreduce_in_graph": bool(use_graph and ar_state["in_graph"]),
+                      "table_gradient_chunks": len(chunker) if chunker is not None else 1, "per_chunk": chunk_us}
     param_l1 = float(sum(p.detach().double().abs().sum() for p in field.parameters()))
     replicas_identical = None
     if world > 1:  # data parallelism keeps full replicas: after the run every rank must hold the same bits (cheap: one checksum vector)
@@ -727,7 +782,9 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1):
         pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
     gt = torch.rand(n_pool, rays, 3, generator=torch.Generator().manual_seed(4321)).to(dev)
     field.train()
-    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group)
+    # (march_across_ring_end: the loop makes no occupancy update inside the timed region -- the metric excludes it -- so the next ring's first
+    # marches may start behind the ring's read-back, as they do in the baked-pool loop)
+    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1)
     if group > 1:
         assert n_pool % group == 0 and steps % group == 0
         po = [torch.stack([pool[c * group + i][0] for i in range(group)]).contiguous() for c in range(n_pool // group)]

@@ -290,6 +290,20 @@ int nerftex_grid_encode_backward_amp(const void* grad, const float* inputs, cons
                                      int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                      int dtype, int layout, float in_add, float in_mul, float* found_inf, void* stream);
 
+/* Extension (round 4): the table gradient in PARTS, for a data-parallel caller that exchanges it level group by level group: the
+ * all-reduce of the rows of levels [lo, hi) can start as soon as those levels are summed, while the later levels are still being summed
+ * (replaces the single gradient exchange after the backward pass; the reference only has the dormant DDP wrap, nerf/utils.py:439-441).
+ *   phase 1: bin the contributions of EVERY level (the first kernel of the large-batch backward); grad_embeddings is not written;
+ *   phase 2: sum (and combine) the tiles of levels [level_lo, level_hi): rows offsets[lo] .. offsets[hi] of grad_embeddings are final;
+ *   phase 3: both.  Same arguments as nerftex_grid_encode_backward_affine without the input gradient.
+ * The phase-2 calls read the scratch the phase-1 call left: same stream (or everything inside stream captures), same B, no other
+ * hash-grid backward of this library in between.  Large-batch path only (C = 2, B >= 16384, a registered level table): anything
+ * else is NERFTEX_ERR_INVALID -- the caller falls back to the one-call backward.  Same bits as the one-call backward. */
+int nerftex_grid_encode_backward_phase(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                       void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                       uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul, int phase,
+                                       uint32_t level_lo, uint32_t level_hi, void* stream);
+
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).
  *   feats_lbc [16, B, 2] half (nerftex_grid_encode_forward*, NERFTEX_LAYOUT_LBC), sigma_weights as nerftex_field_forward's,

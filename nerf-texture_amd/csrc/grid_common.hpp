@@ -27,6 +27,11 @@ struct LevelConsts {
     // optional (backward): GradScaler's non-finite scan rides on the kernels that write the table gradient -- *found_inf = 1 when a written
     // element is inf / nan, never cleared (nerftex_grid_encode_backward_amp)
     float* found_inf;
+    // optional (backward, large-batch path only): run a PART of the table gradient -- phase bit 0 = bin every level's contributions (K3d),
+    // bit 1 = sum + combine the tiles of levels [level_lo, level_hi) (K4d, combine): a caller that exchanges the gradient level group by
+    // level group starts each group's all-reduce while the next group is still being summed (nerftex_grid_encode_backward_phase).
+    // phase 0 = everything (the default).
+    uint32_t bwd_phase, level_lo, level_hi;
 };
 
 // coordinate d of point b as the kernels see it (identity unless the caller folded its normalisation in)

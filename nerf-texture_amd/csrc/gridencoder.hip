@@ -834,6 +834,17 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
     const long force = knob(kKnobGridBwd);  // 1 atomic | 2 owner: A/B switch for profiling
     bool owner = C == 2 && (force ? force == 2 : (B >= kOwnerMinBatch));
     int rc = NERFTEX_OK;
+    if (lc.bwd_phase != 0) {  // a part of the table gradient (nerftex_grid_encode_backward_phase): the binned path or nothing
+        if constexpr (C == 2) {
+            if (owner && !knob(kKnobGridBwdSweep) && !calc_grad) {
+                rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, overwrite, st);
+                if (rc >= 0) return rc;
+            }
+        }
+        set_error("grid_encode_backward_phase: the phased table gradient exists on the large-batch path only (C = 2, B >= %u, no input "
+                  "gradient, a level table the library knows: nerftex_grid_register_offsets)", kOwnerMinBatch);
+        return NERFTEX_ERR_INVALID;
+    }
     if constexpr (C == 2) {
         if (owner) {  // every level through the LDS tile owners, no per-sample global atomics at all
             if (!knob(kKnobGridBwdSweep)) {  // grid_bwd_sweep = 1 keeps the tile-owner sweep; default = binning
@@ -974,7 +985,8 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
                        int layout, bool affine, float in_add, float in_mul, void* stream, const int32_t* units_dev = nullptr, uint32_t rows_per_unit = 0);
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf = nullptr);
+                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf = nullptr,
+                        uint32_t phase = 0, uint32_t level_lo = 0, uint32_t level_hi = 0);
 }  // namespace
 
 extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
@@ -1029,6 +1041,21 @@ extern "C" int nerftex_grid_encode_backward_amp(const void* grad, const float* i
                                align_corners, dtype, layout, true, in_add, in_mul, stream, found_inf);
 }
 
+extern "C" int nerftex_grid_encode_backward_phase(const void* grad, const float* inputs, const void* embeddings,
+                                                  const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                                  uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype, int layout,
+                                                  float in_add, float in_mul, int phase, uint32_t level_lo, uint32_t level_hi, void* stream) {
+    (void)embeddings;
+    clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    if (phase < 1 || phase > 3 || level_lo > level_hi || level_hi > L) {
+        set_error("grid_encode_backward_phase: phase must be 1 (bin), 2 (sum levels [lo, hi)) or 3 (both), 0 <= lo <= hi <= L");
+        return NERFTEX_ERR_INVALID;
+    }
+    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype, align_corners, dtype, layout,
+                               true, in_add, in_mul, stream, nullptr, (uint32_t)phase, level_lo, level_hi);
+}
+
 namespace {
 int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
@@ -1048,7 +1075,8 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
 
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf) {
+                        int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf, uint32_t phase,
+                        uint32_t level_lo, uint32_t level_hi) {
     if (!affine) clear_error();
     const bool overwrite = (layout & NERFTEX_LAYOUT_GRAD_OVERWRITE) != 0;
     layout &= ~NERFTEX_LAYOUT_GRAD_OVERWRITE;
@@ -1056,6 +1084,9 @@ int grid_backward_entry(const void* grad, const float* inputs, const int32_t* of
     if (rc != NERFTEX_OK) return rc;
     LevelConsts lc = make_level_consts(L, S, H, affine, in_add, in_mul);
     lc.found_inf = found_inf;
+    lc.bwd_phase = phase;
+    lc.level_lo = level_lo;
+    lc.level_hi = level_hi;
     if (dtype == NERFTEX_F32)
         return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
                                         grad_inputs, gridtype, align_corners != 0, layout, overwrite, as_stream(stream));

@@ -492,13 +492,14 @@ __device__ __forceinline__ bool adds_nothing(const Rec<T>& r) {  // a pad record
 
 // which (tile, chunk range) a K4d workgroup owns
 struct SumItem { uint32_t level, t, slices, item, c_lo, c_hi, nrows; size_t dst_row; };
-__device__ __forceinline__ bool sum_item(const DirTable& tab, uint32_t L, uint32_t nchunks, uint32_t rows_per_tile, SumItem& it) {
+__device__ __forceinline__ bool sum_item(const DirTable& tab, uint32_t L, uint32_t nchunks, uint32_t rows_per_tile, SumItem& it, uint32_t item_offset) {
+    const uint32_t id = blockIdx.x + item_offset;  // (a launch may cover the items of a level range only)
     uint32_t level = 0;
-    while (level + 1 < L && blockIdx.x >= tab.item_base[level + 1]) level++;
-    if (blockIdx.x >= tab.item_base[L]) return false;
+    while (level + 1 < L && id >= tab.item_base[level + 1]) level++;
+    if (id >= tab.item_base[L]) return false;
     it.level = level;
     it.slices = tab.slices[level];
-    const uint32_t local = blockIdx.x - tab.item_base[level];
+    const uint32_t local = id - tab.item_base[level];
     it.t = local / it.slices;
     const uint32_t item = local % it.slices, per = div_up(nchunks, it.slices);
     it.item = item;
@@ -571,10 +572,10 @@ template <typename T>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
                                                                    const bool overwrite, unsigned long long* __restrict__ partials,
-                                                                   const int* __restrict__ offsets, const uint32_t probe) {
+                                                                   const int* __restrict__ offsets, const uint32_t probe, const uint32_t item_offset) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SumItem it;
-    if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it)) return;
+    if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it, item_offset)) return;
     if (!table_matches(tab, offsets, it.level)) return;  // K3d wrote no directory for this level either
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     constexpr uint32_t kWaves = kSumThreads / kWave;
@@ -649,10 +650,10 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
 constexpr uint32_t kCombineRows = kWave, kCombineWaves = 4, kCombineThreads = kCombineRows * kCombineWaves;
 __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const unsigned long long* __restrict__ partials, const DirTable tab, uint32_t L,
                                                                        half_t* __restrict__ grad_grid, const bool overwrite,
-                                                                       const int* __restrict__ offsets) {
+                                                                       const int* __restrict__ offsets, const uint32_t first_split_tile) {
     __shared__ unsigned long long s_sum[kCombineWaves][kCombineRows][2];
     constexpr uint32_t kRows = rows_per_tile<half_t>(), kSegs = kRows / kCombineRows;
-    const uint32_t split_tile = blockIdx.x / kSegs, seg = blockIdx.x % kSegs;
+    const uint32_t split_tile = first_split_tile + blockIdx.x / kSegs, seg = blockIdx.x % kSegs;
     uint32_t level = 0;  // the split level this tile belongs to: split_base is non-decreasing and steps only at split levels
     for (uint32_t l = 0; l < L; l++)
         if (tab.slices[l] > 1 && tab.split_base[l] <= split_tile) level = l;
@@ -834,7 +835,11 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     const long mk = knob(kKnobGridBwdNoMerge);
     const uint32_t merge = mk == 1 ? 0u : (mk > 1 ? (uint32_t)mk : kMergeMaxResolution);
     const uint32_t probe = (uint32_t)knob(kKnobGridBwdProbe);
-    {
+    // a part of the work only (LevelConsts::bwd_phase): the scratch of the fill is what the later sum calls read -- same stream (or all inside
+    // captures), same B, nothing else of this library's hash-grid backward in between
+    const bool do_fill = lc.bwd_phase == 0 || (lc.bwd_phase & 1u), do_sum = lc.bwd_phase == 0 || (lc.bwd_phase & 2u);
+    const uint32_t lv_lo = lc.bwd_phase == 0 ? 0u : std::min(lc.level_lo, L), lv_hi = lc.bwd_phase == 0 ? L : std::min(lc.level_hi, L);
+    if (do_fill) {
         auto fill = blc ? bin_fill_dir_kernel<T, D, true> : bin_fill_dir_kernel<T, D, false>;
         const size_t lds = sizeof(Rec<T>) * (size_t)kStageRecords;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
@@ -843,18 +848,22 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
                            align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr, probe);
     }
     if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
-    {
+    if (!do_sum || lv_lo >= lv_hi) return NERFTEX_OK;
+    const uint32_t item_lo = dt.item_base[lv_lo], item_hi = dt.item_base[lv_hi];
+    if (item_hi > item_lo) {
         auto kernel = sum_tiles_dir_kernel<T>;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
         KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(kernel, dim3(items), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials, offsets_dev, probe);
+        hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials,
+                           offsets_dev, probe, item_lo);
     }
     if ((rc = check_launch("grid_encode_backward(sum)")) != NERFTEX_OK) return rc;
     if constexpr (sizeof(T) == 2) {
-        if (split_tiles) {
+        const uint32_t split_lo = dt.split_base[lv_lo], split_hi = lv_hi < L ? dt.split_base[lv_hi] : split_tiles;
+        if (split_hi > split_lo) {
             KernelTimer kt("combine_tiles_kernel", st, kTimeGrid);
-            hipLaunchKernelGGL(combine_tiles_kernel, dim3(split_tiles * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
-                               reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev);
+            hipLaunchKernelGGL(combine_tiles_kernel, dim3((split_hi - split_lo) * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
+                               reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev, split_lo);
         }
         return check_launch("grid_encode_backward(combine)");
     }

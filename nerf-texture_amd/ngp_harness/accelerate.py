@@ -41,7 +41,7 @@ RING = 16
 
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
-                 amp_dtype=torch.float16, graph=True, steps_per_call=1):
+                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False):
         from .model import NGPField
 
         field = renderer.field
@@ -68,6 +68,10 @@ class AcceleratedTrainer:
         # steps_per_call = k > 1: `step_group` takes the batches of k consecutive steps at once and replays ONE graph for their shade + backward +
         # optimizer (the hand-over between two graph launches idles the device ~10 us: bench.py's --steps-per-graph), their k marches being
         # graphs of their own that run ahead on the second stream when the caller hands the NEXT group's rays over
+        # march_across_ring_end: at the ring's last call, `next_rays` are marched ahead as well (right behind the mean_count read-back) instead
+        # of inline at the start of the next ring.  That march reads the occupancy grid while this call's steps still run: a trainer that
+        # updates the grid every 16 steps (nerf/utils.py:1011) must then do so BEFORE the ring's last call, not after it.  Off by default.
+        self.march_across_ring_end = bool(march_across_ring_end)
         self.group = int(steps_per_call)
         assert self.group in (1, 2, 4, 8, 16), "steps_per_call must divide the 16-entry step-counter ring"
         self._groups = None
@@ -207,19 +211,24 @@ class AcceleratedTrainer:
         self._groups[g0 // k].replay()
         _lap("group_replay")
         r.local_step = g0 + k
+        def march_ahead(slot0):
+            no, nd = next_rays
+            assert no.shape == rays_o.shape and no.is_contiguous() and nd.is_contiguous(), "next_rays: contiguous [k, N, 3] tensors"
+            with torch.cuda.stream(self._side_stream()):
+                self._side.wait_event(ready)
+                self._ray_o[slot0:slot0 + k].copy_(no, non_blocking=True), self._ray_d[slot0:slot0 + k].copy_(nd, non_blocking=True)
+                for g in range(slot0, slot0 + k):
+                    self._graphs[g][0].replay()
+            self._ahead = (slot0, no.data_ptr(), nd.data_ptr())
+
         if not last:
             if ready is not None:
-                no, nd = next_rays
-                assert no.shape == rays_o.shape and no.is_contiguous() and nd.is_contiguous(), "next_rays: contiguous [k, N, 3] tensors"
-                with torch.cuda.stream(self._side_stream()):
-                    self._side.wait_event(ready)
-                    self._ray_o[g0 + k:g0 + 2 * k].copy_(no, non_blocking=True), self._ray_d[g0 + k:g0 + 2 * k].copy_(nd, non_blocking=True)
-                    for g in range(g0 + k, g0 + 2 * k):
-                        self._graphs[g][0].replay()
-                self._ahead = (g0 + k, no.data_ptr(), nd.data_ptr())
+                march_ahead(g0 + k)
             _lap("march_ahead")
         else:
             self._ring_end(ready)
+            if ready is not None and self.march_across_ring_end and self._graphs is not None:  # (graphs dropped: the buffer size changed)
+                march_ahead(0)
             _lap("ring_end")
         return self.loss
 
@@ -313,5 +322,5 @@ class AcceleratedTrainer:
 
 def accelerate(renderer, **kw):
     """See the module docstring.  Keyword arguments: rays_per_batch, lr, betas, eps, dt_gamma, bg_color, perturb, max_steps, amp_dtype, graph,
-    steps_per_call (k > 1: `step_group` takes the batches of k consecutive steps and replays one graph for them)."""
+    steps_per_call (k > 1: `step_group` takes the batches of k consecutive steps and replays one graph for them), march_across_ring_end."""
     return AcceleratedTrainer(renderer, **kw)

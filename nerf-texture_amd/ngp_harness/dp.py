@@ -180,6 +180,28 @@ class FlatGradAllReduce:
             works.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True))
         return works, post
 
+    def start_tensor(self, t):
+        """Asynchronous sum of ONE tensor (a chunk of a big gradient) across the ranks, on the wire dtype of the big gradients; returns a
+        handle for `finish_tensors`."""
+        if world_size() == 1:
+            return None
+        if self.big_comm_dtype is not None and t.dtype != self.big_comm_dtype:
+            wire = t.to(self.big_comm_dtype)
+            return (dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True), t, wire)
+        return (dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t, None)
+
+    def finish_tensors(self, handles):
+        w = world_size()
+        for h in handles:
+            if h is None:
+                continue
+            work, t, wire = h
+            work.wait()
+            if wire is not None:
+                t.copy_(wire)
+            if self.average:
+                t.div_(w)
+
     def all_reduce_finish(self, handle):
         """Make the current stream wait for the exchange started by `all_reduce_start`, then the local epilogue (widen / average)."""
         if handle is None:
@@ -206,6 +228,67 @@ class FlatGradAllReduce:
         if extra is not None:
             dist.all_reduce(extra, op=dist.ReduceOp.SUM)
         return extra
+
+
+class TableGradChunks:
+    """The hash table's gradient exchanged level group by level group: the large-batch backward first bins every level's
+    contributions (one kernel), then sums them tile by tile, level by level -- so the rows of the first levels are final long before the
+    last ones, and their all-reduce can be on the wire while the rest is still being summed, instead of everything starting after the
+    backward pass (the table gradient is the LAST thing the backward produces and the first the optimizer needs: nothing else of the step
+    can hide the exchange).
+
+        chunks = TableGradChunks(field.encoder, k)      # attaches itself: the fused field's backward now only bins (ngp_harness/fused.py)
+        loss.backward()
+        for i in range(len(chunks)):
+            chunks.sum_chunk(i)                          # finishes rows chunks.rows[i] of the table gradient (current stream)
+            handles.append(reducer.start_tensor(chunks.view(i, table_leaf.grad)))
+        ...; reducer.finish_tensors(handles)
+
+    Level groups hold about equal numbers of rows, in level order.  Same gradient bits as the one-call backward (the sums are exact)."""
+
+    def __init__(self, encoder, chunks):
+        off = encoder.offsets.detach().cpu().tolist()
+        L = len(off) - 1
+        chunks = max(1, min(int(chunks), L))
+        bounds, lo = [], 0
+        for c in range(chunks):
+            if c == chunks - 1:
+                hi = L
+            else:
+                want = off[-1] * (c + 1) / chunks
+                hi = lo + 1
+                while hi < L - (chunks - 1 - c) and off[hi] < want:
+                    hi += 1
+            bounds.append((lo, hi))
+            lo = hi
+        self.levels = bounds
+        self.rows = [(off[a], off[b]) for a, b in bounds]
+        self.grad_ptr, self._run, self._keep = None, None, None
+        encoder.grad_chunker = self
+
+    def __len__(self):
+        return len(self.levels)
+
+    def begin(self, grad, run, keep):
+        """Called by the backward: `grad` the table-gradient tensor being produced (only its ADDRESS is kept: a second reference would make
+        autograd copy the gradient instead of handing the tensor itself to `.grad`), run(level_lo, level_hi) finishes a level range (None:
+        the gradient is complete already), keep: what must stay alive until the last range has run."""
+        self.grad_ptr, self._run, self._keep = grad.data_ptr(), run, keep
+
+    def take(self):
+        """(address of the gradient, run, keep) of the backward that just ran, for a caller that records the per-group work itself (graph capture)."""
+        return self.grad_ptr, self._run, self._keep
+
+    def sum_chunk(self, i, state=None):
+        run = (state or self.take())[1]
+        if run is not None:
+            run(*self.levels[i])
+
+    def view(self, i, grad, state=None):
+        """Rows of level group i of `grad` -- the tensor autograd put into `.grad`, which must be the one the backward produced."""
+        assert grad.data_ptr() == (state or self.take())[0], "the table gradient in .grad is not the tensor the backward wrote (was it copied or accumulated?)"
+        a, b = self.rows[i]
+        return grad[a:b]
 
 
 def all_reduce_max_int(value, device):

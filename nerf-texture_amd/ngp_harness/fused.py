@@ -118,6 +118,7 @@ class _ngp_field(Function):
             ctx.save_for_backward(x, table_h, offsets, ws_h, wc_h, x_rows, h, cin, rgbs)
             ctx.meta = (S, H, gridtype, align, affine, table.dtype, ws.dtype, wc.dtype)
             ctx.amp_sink = getattr(enc, "amp_sink", None)  # optim.FusedAmp.attach: the backward's kernels raise found_inf themselves
+            ctx.grad_chunker = getattr(enc, "grad_chunker", None)  # dp.TableGradChunks: the table gradient is finished level group by level group
         else:
             check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
         ctx.set_materialize_grads(False)
@@ -152,6 +153,18 @@ class _ngp_field(Function):
             check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws_h), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
         grad_table = torch.empty_like(table_h)
         dummy = torch.empty(1, **half)
+        chunker = ctx.grad_chunker if sink is None else None
+        if chunker is not None:
+            # data parallelism: only BIN the contributions here; the caller sums the level groups one by one (chunker.sum_chunk) and starts each
+            # group's all-reduce while the next one is being summed.  grad_table is complete once every group has been summed.
+            L = offsets.shape[0] - 1
+            args = (ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, L, S, H, gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE,
+                    affine[0], affine[1])
+            if lib.nerftex_grid_encode_backward_phase(*args, 1, 0, L, stream()) == 0:
+                chunker.begin(grad_table, lambda lo, hi: check(lib.nerftex_grid_encode_backward_phase(*args, 2, lo, hi, stream())),
+                              keep=(grad_x, x, table_h, offsets, dummy))
+                return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None
+            chunker.begin(grad_table, None, keep=None)  # (small batch / unknown table: the one-call backward below; the groups are complete already)
         if sink is not None:
             check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H,
                                                        0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],

@@ -123,7 +123,9 @@ def test_occupancy_maintenance_matches_reference_python(dev):
             times = torch.zeros(r.density_grid.numel(), dtype=torch.int32, device=dev)
             for cas, idx in enumerate(r.last_partial_indices):
                 times.index_add_(0, idx + cas * per_cas, torch.ones_like(idx, dtype=torch.int32))
-            once = (times[probe] <= 1).cpu().numpy()
+            # (a cell named several times in an EARLIER partial update may carry another of its candidate values into this one's EMA)
+            multi = (times > 1) if step == 2 else (multi | (times > 1))
+            once = (~multi[probe]).cpu().numpy()
             assert once.mean() > 0.5 and (got[once] != want[once]).sum() <= 2, (step, int((got[once] != want[once]).sum()), float(once.mean()))
             assert abs(r.mean_density - float(g[f"mean_density_{step}"])) < 2e-3  # (a mean over all cells, the multiply-drawn ones included)
         assert r.mean_count == int(g[f"mean_count_{step}"]) and r.local_step == 0

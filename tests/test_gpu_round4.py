@@ -536,3 +536,60 @@ def test_step_group_trains_like_single_steps(dev):
         assert torch.equal(p1, p4), n1
     with pytest.raises(AssertionError):
         t4.step(*pool[0], gt[0])  # once the grouped graphs run, single steps are refused
+
+
+# ------------------------------------------------------------------------------------------------- table gradient in parts (5b)
+def test_phased_grid_backward_equals_the_one_call_backward(dev, oracle):
+    """nerftex_grid_encode_backward_phase: bin once (phase 1), then sum level groups in any grouping (phase 2) == the one-call backward, bit
+    for bit; rows of a group are final after its call (later groups untouched); small batches are refused with a message."""
+    from nerftex_hip import F16, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, check, lib, ptr, stream
+
+    off_np, rows = oracle.grid_offsets(3, 16, 1.447269, 16, 19, True)
+    off = torch.from_numpy(off_np).to(dev)
+    check(lib.nerftex_grid_register_offsets(ptr(off), 16, off_np.ctypes.data))
+    torch.manual_seed(3)
+    B = 50000
+    x = torch.rand(B, 3, device=dev) * 4 - 2
+    grad = (torch.randn(B, 32, device=dev) * 1e-2).half()
+    S = float(np.log2(1.447269))
+    want = torch.full((rows, 2), float("nan"), dtype=torch.float16, device=dev)
+    args = lambda out: (ptr(grad), ptr(x), None, ptr(off), ptr(out), B, 3, 2, 16, S, 16)  # noqa: E731
+    check(lib.nerftex_grid_encode_backward_affine(*args(want), 0, None, None, 0, 1, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25, stream()))
+    assert torch.isfinite(want).all()
+    for groups in ([(0, 16)], [(0, 5), (5, 11), (11, 16)], [(8, 16), (0, 8)], [(i, i + 1) for i in range(16)]):
+        got = torch.full((rows, 2), float("nan"), dtype=torch.float16, device=dev)
+        tail = (0, 1, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25)
+        check(lib.nerftex_grid_encode_backward_phase(*args(got), *tail, 1, 0, 16, stream()))
+        assert torch.isnan(got).all(), "binning writes no gradient row"
+        done = torch.zeros(rows, dtype=torch.bool, device=dev)
+        for lo, hi in groups:
+            check(lib.nerftex_grid_encode_backward_phase(*args(got), *tail, 2, lo, hi, stream()))
+            done[int(off_np[lo]):int(off_np[hi])] = True
+            assert torch.equal(got[done].view(torch.int16), want[done].view(torch.int16)) and torch.isnan(got[~done]).all(), (lo, hi)
+    small = torch.zeros(rows, 2, dtype=torch.float16, device=dev)
+    rc = lib.nerftex_grid_encode_backward_phase(ptr(grad), ptr(x), None, ptr(off), ptr(small), 3000, 3, 2, 16, S, 16, 0, 1, F16, LAYOUT_BLC, 2.0, 0.25, 3, 0, 16, stream())
+    assert rc != 0 and b"large-batch path only" in lib.nerftex_last_error()
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-graph"]], ids=["split-graphs", "eager"])
+def test_chunked_gradient_exchange_trains_bit_identically(extra):
+    """bench.py --gpus 2 --allreduce-chunks 3 (the table gradient finished and exchanged in three level groups, each all-reduce started while
+    the next group is being summed) against --allreduce-chunks 1 on the two-ranks-on-one-GPU rig: the sums are exact and every row is
+    exchanged exactly once either way, so the parameters after the run are the same bits."""
+    import json
+    import subprocess
+    import sys
+
+    res = []
+    for chunks in (1, 3):
+        env = dict(os.environ, NERFTEX_DP_SHARE_GPU="1")
+        env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4", "--rays", "8192", "--no-cpu-baseline", "--no-other",
+               "--no-infer", "--no-kernel-timing", "--warm-seconds", "0", "--allreduce-chunks", str(chunks)] + extra
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b = res
+    assert a["config"]["replicas_identical_after_run"] is True and b["config"]["replicas_identical_after_run"] is True
+    assert b["config"]["collective"]["table_gradient_chunks"] == 3 and len(b["config"]["collective"]["per_chunk"]) == 3
+    assert a["config"]["param_l1_after_run"] == b["config"]["param_l1_after_run"], (a["config"]["param_l1_after_run"], b["config"]["param_l1_after_run"])
