@@ -571,11 +571,55 @@ def test_phased_grid_backward_equals_the_one_call_backward(dev, oracle):
     assert rc != 0 and b"large-batch path only" in lib.nerftex_last_error()
 
 
+def test_table_grad_chunks_give_the_one_call_gradient_through_the_fused_field(dev):
+    """dp.TableGradChunks attached to the encoder: the fused field's backward only bins, `sum_chunk(i)` finishes level group i, and `.grad` of
+    the table leaf (the very tensor the backward produced: `view` checks the address) ends up bit-identical to the plain backward's."""
+    from ngp_harness import dp
+    from ngp_harness.model import NGPField
+    from ngp_harness.optim import HalfLeafAdam
+
+    torch.manual_seed(2)
+    f = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
+    f.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    opt = HalfLeafAdam([(f.encoder, "embeddings"), (f.sigma_net, "weights"), (f.color_net, "weights")])
+    B = 128 * 256
+    x = ((torch.rand(B, 3, device=dev) * 2 - 1) * 1.9).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
+    gs, gc = torch.randn(B, device=dev) * 1e-2, torch.randn(B, 3, device=dev)
+
+    def backward():
+        for leaf in opt.leaves:
+            leaf.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, color, _ = f(x, d)
+        torch.autograd.backward([sigma, color], [gs, gc])
+        return [leaf.grad for leaf in opt.leaves]
+
+    want = [g.clone() for g in backward()]
+    chunks = dp.TableGradChunks(f.encoder, 3)
+    assert len(chunks) == 3 and chunks.levels[0][0] == 0 and chunks.levels[-1][1] == 16 and all(a[1] == b[0] for a, b in zip(chunks.levels[:-1], chunks.levels[1:]))
+    got = backward()
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    covered = 0
+    for i in range(len(chunks)):
+        chunks.sum_chunk(i)
+        v = chunks.view(i, got[0])
+        a, b = chunks.rows[i]
+        assert torch.equal(v.view(torch.int16), want[0][a:b].view(torch.int16)), i
+        covered += b - a
+    assert covered == want[0].shape[0] and torch.equal(got[0].view(torch.int16), want[0].view(torch.int16))
+    del f.encoder.grad_chunker
+    again = backward()
+    assert torch.equal(again[0].view(torch.int16), want[0].view(torch.int16))
+
+
 @pytest.mark.parametrize("extra", [[], ["--no-graph"]], ids=["split-graphs", "eager"])
-def test_chunked_gradient_exchange_trains_bit_identically(extra):
-    """bench.py --gpus 2 --allreduce-chunks 3 (the table gradient finished and exchanged in three level groups, each all-reduce started while
-    the next group is being summed) against --allreduce-chunks 1 on the two-ranks-on-one-GPU rig: the sums are exact and every row is
-    exchanged exactly once either way, so the parameters after the run are the same bits."""
+def test_chunked_gradient_exchange_keeps_replicas_identical(extra):
+    """bench.py --gpus 2 --allreduce-chunks 3 on the two-ranks-on-one-GPU rig (the table gradient finished and exchanged in three level groups,
+    each all-reduce started while the next group is being summed): replicas bit-identical after the run, per-group figures reported, and the
+    parameters where the one-exchange run leaves them (two runs of THIS rig differ in the last digits even with equal flags -- both ranks
+    time-share one GPU through gloo -- so the comparison of the two runs is to 1e-3 of the L1 norm; bit-equality of the gradient itself is
+    test_table_grad_chunks_give_the_one_call_gradient_through_the_fused_field)."""
     import json
     import subprocess
     import sys
@@ -592,4 +636,27 @@ def test_chunked_gradient_exchange_trains_bit_identically(extra):
     a, b = res
     assert a["config"]["replicas_identical_after_run"] is True and b["config"]["replicas_identical_after_run"] is True
     assert b["config"]["collective"]["table_gradient_chunks"] == 3 and len(b["config"]["collective"]["per_chunk"]) == 3
-    assert a["config"]["param_l1_after_run"] == b["config"]["param_l1_after_run"], (a["config"]["param_l1_after_run"], b["config"]["param_l1_after_run"])
+    la, lb = a["config"]["param_l1_after_run"], b["config"]["param_l1_after_run"]
+    assert abs(la - lb) <= 1e-3 * la, (la, lb)
+
+
+def test_lds_staged_levels_give_the_same_features(dev, knobs):
+    """knob grid_fwd_lds = 2 (experiment: levels 0 and 1 of the fox table gathered from an LDS copy of their slice, the XCD-pinned kernel
+    skipping them) against the default forward: the same [B, L*C] rows, bit for bit, fp16 and fp32 tables, out-of-range points included."""
+    import gridencoder
+
+    torch.manual_seed(8)
+    enc = gridencoder.GridEncoder(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096, align_corners=True).to(dev)
+    enc.embeddings.data.uniform_(-1, 1)
+    B = 40000
+    x = (torch.rand(B, 3, device=dev) * 2 - 1) * 2.02
+    with torch.no_grad():
+        want32 = enc(x, bound=2.0)
+        with torch.autocast("cuda", dtype=torch.float16):
+            want16 = enc(x, bound=2.0)
+        knobs(grid_fwd_lds=2)
+        with torch.autocast("cuda", dtype=torch.float16):
+            got16 = enc(x, bound=2.0)
+        got32 = enc(x, bound=2.0)  # fp32: level 1 is 13824 rows x 8 B = 108 KiB > the 64 KiB patch -- read where it lies, same values
+    assert want16.dtype == torch.float16 and torch.equal(got16.view(torch.int16), want16.view(torch.int16))
+    assert torch.equal(got32, want32)
