@@ -67,7 +67,6 @@ enum Knob {
     kKnobFfmlpWgPerCu,   // forward: workgroups per CU (0 = default)
     kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
     kKnobMarchLean,      // 1: the training march's count pass compiled for 64 registers (spills; slower alone, a better neighbour on a shared CU)
-    kKnobGridFwdLds,     // n > 0: EXPERIMENT -- the first n levels of the large-batch forward are gathered from an LDS copy of their table slice (each <= 64 KiB)
     kKnobFfmlpBwdTr,     // 1: fused MLP backward builds its weight-gradient operands with ds_read_b64_tr_b16 instead of selection-matrix MFMAs (slower: A/B)
     kKnobCount
 };

@@ -32,8 +32,6 @@ struct LevelConsts {
     // level group starts each group's all-reduce while the next group is still being summed (nerftex_grid_encode_backward_phase).
     // phase 0 = everything (the default).
     uint32_t bwd_phase, level_lo, level_hi;
-    // forward experiment (knob grid_fwd_lds): the first fwd_skip_levels levels are served by the LDS-staged kernel, the XCD-pinned kernel skips them
-    uint32_t fwd_skip_levels;
 };
 
 // coordinate d of point b as the kernels see it (identity unless the caller folded its normalisation in)

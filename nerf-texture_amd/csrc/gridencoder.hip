@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     // XCD 7 carried 110 of the 706 us, with (x, 15 - x) the heaviest pair is 93.
     const uint32_t round = q / nchunks;
     const uint32_t level = round * kXcds + ((round & 1u) ? kXcds - 1u - xcd : xcd);
-    if (level >= L || level < lc.fwd_skip_levels) return;
+    if (level >= L) return;
     const uint32_t b = (q % nchunks) * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if (lc.units_dev && b >= (uint32_t)lc.units_dev[0] * lc.rows_per_unit) return;
@@ -287,74 +287,6 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
             }
             store_row<T, C>(dyd + gd * C, rg);
         }
-    }
-}
-
-// EXPERIMENT (knob grid_fwd_lds = n, VERDICT r3 item 9, north_star's "LDS-staged per-level features"): the first n levels -- the small dense
-// ones whose whole slice fits LDS (fox table, fp16: level 0 = 16 KiB, level 1 = 54 KiB) -- gathered from an LDS copy instead of through
-// the vector memory pipe.  A workgroup stages one level's slice once (16-byte copies) and then walks its share of ALL points; no XCD
-// pinning is needed (nothing is re-read from L2).  Same index arithmetic, same fmaf chain: bit-identical features.  No dy_dx.
-// Measured: see DESIGN.md 4 (G1) -- the launch ends with the XCD that carries levels 7 + 8, which this does not touch.
-template <typename T, int D, int C>
-__global__ __launch_bounds__(256) void grid_forward_lds_kernel(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
-                                                               T* __restrict__ out_lbc, const uint32_t B, const LevelConsts lc, const uint32_t gridtype,
-                                                               const bool align_corners, const uint32_t workers) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* table = reinterpret_cast<T*>(smem);
-    const uint32_t level = blockIdx.x / workers, worker = blockIdx.x % workers;
-    const uint32_t off = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-    const bool fits = (size_t)hashmap_size * C * sizeof(T) <= 64 * 1024;  // a slice larger than the patch is read where it lies (same values)
-    if (fits) {
-        const float4_t* src = reinterpret_cast<const float4_t*>(grid + (size_t)off * C);  // rows are multiples of 8: 16-byte pieces
-        float4_t* dst = reinterpret_cast<float4_t*>(smem);
-        const uint32_t n16 = hashmap_size * C * (uint32_t)sizeof(T) / 16u;
-        for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
-        __syncthreads();
-    } else {
-        table = const_cast<T*>(grid + (size_t)off * C);
-    }
-    const float scale = lc.scale[level];
-    const IndexFn<D> index_of(gridtype, align_corners, hashmap_size, lc.resolution[level]);
-    const uint32_t live = lc.units_dev ? min(B, (uint32_t)lc.units_dev[0] * lc.rows_per_unit) : B;
-    for (uint32_t b = worker * 256 + threadIdx.x; b < live; b += workers * 256) {
-        float x[D];
-        bool oob = false;
-        load_coords<D>(lc, inputs, (size_t)b, x);
-#pragma unroll
-        for (int d = 0; d < D; d++)
-            if (!(x[d] >= 0 && x[d] <= 1)) oob = true;
-        T* out = out_lbc + ((size_t)level * B + b) * C;
-        float r[C];
-#pragma unroll
-        for (int c = 0; c < C; c++) r[c] = 0.0f;
-        if (!oob) {
-            float pos[D];
-            uint32_t pos_grid[D];
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
-                pos_grid[d] = (uint32_t)floorf(pos[d]);
-                pos[d] -= (float)pos_grid[d];
-            }
-            uint32_t term[D][2];
-            index_of.terms(pos_grid, term);
-#pragma unroll
-            for (int idx = 0; idx < (1 << D); idx++) {  // corners and weights in the level kernel's order: idx = 2q + (x bit)
-                float wi = 1;
-#pragma unroll
-                for (int d = 0; d < D; d++) wi *= (idx & (1 << d)) ? pos[d] : 1 - pos[d];
-                uint32_t yz = 0;
-#pragma unroll
-                for (int d = 1; d < D; d++) yz = index_of.combine(yz, term[d][(idx >> d) & 1]);
-                const uint32_t row = index_of.wrap(index_of.combine(term[0][idx & 1], yz));
-                float g[C];
-                load_row<T, C>(table + (size_t)row * C, g);
-#pragma unroll
-                for (int c = 0; c < C; c++) r[c] = fmaf(wi, g[c], r[c]);
-            }
-        }
-        store_row<T, C>(out, r);
     }
 }
 
@@ -842,20 +774,10 @@ int launch_forward(const float* inputs, const T* emb, const int* offsets, T* out
             if (!lbc) return NERFTEX_ERR_HIP;
         }
         const uint32_t nchunks = div_up(B, 256u);
-        LevelConsts lcl = lc;
-        const uint32_t n_lds = (uint32_t)knob(kKnobGridFwdLds);
-        if (n_lds > 0 && n_lds <= L && !calc_grad) {  // experiment: the first n_lds levels from an LDS copy (the caller vouches that they fit 64 KiB)
-            auto kernel = grid_forward_lds_kernel<T, D, C>;
-            NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024), "hipFuncSetAttribute");
-            const uint32_t workers = std::max(1u, 2u * (uint32_t)device_cus() / n_lds);
-            KernelTimer kt("grid_forward_lds_kernel", st, kTimeGrid);
-            hipLaunchKernelGGL(kernel, dim3(n_lds * workers), dim3(256), 64 * 1024, st, inputs, emb, offsets, lbc, B, lc, gridtype, align, workers);
-            lcl.fwd_skip_levels = n_lds;
-        }
         {
             KernelTimer kt("grid_forward_level_kernel", st, kTimeGrid);
             hipLaunchKernelGGL((grid_forward_level_kernel<T, D, C>), dim3(kXcds * nchunks * div_up(L, kXcds)), dim3(256), 0, st, inputs, emb, offsets,
-                               lbc, B, L, lcl, calc_grad, dy_dx, gridtype, align, nchunks);
+                               lbc, B, L, lc, calc_grad, dy_dx, gridtype, align, nchunks);
         }
         int rc = check_launch("grid_encode_forward");
         if (rc != NERFTEX_OK || layout != NERFTEX_LAYOUT_BLC) return rc;

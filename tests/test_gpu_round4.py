@@ -638,25 +638,3 @@ def test_chunked_gradient_exchange_keeps_replicas_identical(extra):
     assert b["config"]["collective"]["table_gradient_chunks"] == 3 and len(b["config"]["collective"]["per_chunk"]) == 3
     la, lb = a["config"]["param_l1_after_run"], b["config"]["param_l1_after_run"]
     assert abs(la - lb) <= 1e-3 * la, (la, lb)
-
-
-def test_lds_staged_levels_give_the_same_features(dev, knobs):
-    """knob grid_fwd_lds = 2 (experiment: levels 0 and 1 of the fox table gathered from an LDS copy of their slice, the XCD-pinned kernel
-    skipping them) against the default forward: the same [B, L*C] rows, bit for bit, fp16 and fp32 tables, out-of-range points included."""
-    import gridencoder
-
-    torch.manual_seed(8)
-    enc = gridencoder.GridEncoder(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096, align_corners=True).to(dev)
-    enc.embeddings.data.uniform_(-1, 1)
-    B = 40000
-    x = (torch.rand(B, 3, device=dev) * 2 - 1) * 2.02
-    with torch.no_grad():
-        want32 = enc(x, bound=2.0)
-        with torch.autocast("cuda", dtype=torch.float16):
-            want16 = enc(x, bound=2.0)
-        knobs(grid_fwd_lds=2)
-        with torch.autocast("cuda", dtype=torch.float16):
-            got16 = enc(x, bound=2.0)
-        got32 = enc(x, bound=2.0)  # fp32: level 1 is 13824 rows x 8 B = 108 KiB > the 64 KiB patch -- read where it lies, same values
-    assert want16.dtype == torch.float16 and torch.equal(got16.view(torch.int16), want16.view(torch.int16))
-    assert torch.equal(got32, want32)
