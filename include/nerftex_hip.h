@@ -47,6 +47,11 @@ extern "C" {
 /* opaque handle of a triangle mesh + its BVH on the device (the RayTracer section below) */
 typedef struct nerftex_raytracer nerftex_raytracer;
 
+/* Test aid: bit mask of the library scratch slots (march 0, compaction 1, MLP 2 / 8, hash grid 3 / 4 / 5, occupancy 6 / 7) that calls have
+ * asked for since this function was last called.  Two replayed graphs may run concurrently only if their masks are disjoint
+ * (INTEGRATION.md "Scratch memory and streams"). [extension] */
+unsigned nerftex_workspace_slots_touched(void);
+
 /* thread-local text of the last error on this thread ("" if none) */
 const char* nerftex_last_error(void);
 /* library / build identification: "nerftex_hip <ver> gfx950" */

@@ -73,7 +73,10 @@ std::vector<void*> g_retired;  // outgrown buffers: kept until release_workspace
 std::mutex g_ws_mutex;
 }  // namespace
 
+unsigned g_ws_touched = 0;
+
 void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
+    g_ws_touched |= 1u << (unsigned)slot;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
         set_error("workspace: bad device");
@@ -216,6 +219,13 @@ int nerftex_release_workspaces(void) {
 long nerftex_tune_get(const char* name) {
     const int k = name ? nerftex::knob_index(name, strlen(name)) : -1;
     return k < 0 ? -1 : nerftex::g_knobs[k];
+}
+
+// test aid: bit mask of the scratch slots (csrc/workspace.hpp WorkspaceSlot) library calls have asked for since the last call of this function
+unsigned nerftex_workspace_slots_touched(void) {
+    const unsigned m = nerftex::g_ws_touched;
+    nerftex::g_ws_touched = 0;
+    return m;
 }
 
 const char* nerftex_last_error(void) { return nerftex::g_err; }

@@ -93,7 +93,7 @@ _SIGNATURES = {
     "nerftex_knn_query": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "nerftex_raytracer_trace": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
 }
-EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get"] + list(_SIGNATURES)
+EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get", "nerftex_workspace_slots_touched"] + list(_SIGNATURES)
 
 
 def _load():
@@ -107,6 +107,8 @@ def _load():
     lib.nerftex_version.restype = C.c_char_p
     lib.nerftex_tune_get.argtypes = [C.c_char_p]
     lib.nerftex_tune_get.restype = C.c_long
+    lib.nerftex_workspace_slots_touched.argtypes = []
+    lib.nerftex_workspace_slots_touched.restype = C.c_uint
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == a symbol the header declares is not exported
         fn.argtypes = args

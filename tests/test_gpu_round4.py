@@ -638,3 +638,38 @@ def test_chunked_gradient_exchange_keeps_replicas_identical(extra):
     assert b["config"]["collective"]["table_gradient_chunks"] == 3 and len(b["config"]["collective"]["per_chunk"]) == 3
     la, lb = a["config"]["param_l1_after_run"], b["config"]["param_l1_after_run"]
     assert abs(la - lb) <= 1e-3 * la, (la, lb)
+
+
+def test_concurrent_graphs_use_disjoint_scratch_slots(dev):
+    """csrc/workspace.hpp: all stream captures share one scratch set per device, so two replayed graphs may run side by side only if their
+    kernels use disjoint slots.  The two graph kinds bench.py / accelerate() DO replay concurrently -- the march of the next step, and a
+    training step behind its march -- are held to that: march = slot 0 only, the step never slot 0."""
+    from nerftex_hip import lib
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer
+    from ngp_harness.optim import FusedAmp, HalfLeafAdam
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
+    r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+    r.set_occupancy(torch.from_numpy(grid).to(dev))
+    opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights"), (field.color_net, "weights")])
+    amp = FusedAmp(opt).attach(field.encoder)
+    o, d = scene.train_batch(4096, seed=1)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    tgt = torch.rand(4096, 3, device=dev)
+    lib.nerftex_workspace_slots_touched()
+    with torch.autocast("cuda", dtype=torch.float16):
+        marched, _ = r.march_train(ro, rd, dt_gamma=1 / 128, perturb=True, mean_count=240000)
+    march_slots = lib.nerftex_workspace_slots_touched()
+    with torch.autocast("cuda", dtype=torch.float16):
+        _, _, loss, scaled = r.shade_train(marched, 1, target=tgt, scale=amp.scale)
+    scaled.backward(torch.ones((), device=dev))
+    amp.step()
+    step_slots = lib.nerftex_workspace_slots_touched()
+    torch.cuda.synchronize()
+    assert march_slots == 0b1, bin(march_slots)
+    assert step_slots != 0 and step_slots & march_slots == 0, (bin(step_slots), bin(march_slots))
+    assert step_slots & ~0b100111100 == 0, bin(step_slots)  # MLP (2, 8) and hash-grid (3, 4, 5) slots only
