@@ -697,7 +697,7 @@ def rocprof_replay(args, mlp, rays, dtype, steps=416):
     try:
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
                "--steps", str(steps), "--warmup", str(args.warmup), "--rays", str(rays), "--mlp", mlp, "--dtype", dtype, "--bound", str(args.bound),
-               "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer", "--no-kernel-timing"]
+               "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer", "--no-kernel-timing", "--baked-pool"]
         for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb"):
             if getattr(args, flag):
                 cmd.append("--" + flag.replace("_", "-"))

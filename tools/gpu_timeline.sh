@@ -5,7 +5,7 @@ tag=${1:-timeline}
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --no-kernel-timing --no-cpu-baseline --no-other --no-infer ${EXTRA} > $out/bench.json 2> $out/err.log )
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --warm-seconds 0 --baked-pool --no-kernel-timing --no-cpu-baseline --no-other --no-infer ${EXTRA} > $out/bench.json 2> $out/err.log )
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
 python - "$f" > $out/step.txt <<'PY'
 import csv, re, sys, collections
