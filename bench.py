@@ -36,11 +36,11 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
 # Memory-side bytes per launch of the default workload's hash-grid ops (fp16 table, ~459 k samples), from separate rocprofv3 PMC
-# passes (FETCH_SIZE, WRITE_SIZE; profiles/r03_pmc_grid.txt).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
+# passes (FETCH_SIZE, WRITE_SIZE; profiles/r04_pmc_grid.txt).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
 # MI355X_MICROARCH.md for wide coalesced streams: here the 8-B record stream) + WRITE_SIZE.  Forward: FETCH_SIZE as reported
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
 TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 578.0e6}
-TRAFFIC_PROFILE = "profiles/r03_pmc_grid.txt"
+TRAFFIC_PROFILE = "profiles/r04_pmc_grid.txt"
 COMMITTED_STATS = "profiles/r04_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
@@ -1070,10 +1070,10 @@ def main():
     kern = per_op(res["replay_us"] if in_replay else res["kernel_us"])
     kern_eager = per_op(res["kernel_us"]) if in_replay else {}
     # what bounds each op, by the counters: the gather is served by the L2s (94 % hits, 128-B lines for 8-B rows): it sits on the
-    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r03_pmc_sq_grid.txt) -- its algorithmic bytes are
+    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r04_pmc_sq_grid.txt) -- its algorithmic bytes are
     # still priced against HBM, the nearest roof the contract names
     BOUND = {"grid_encode_forward": ("l2_line", "the gather is bound by the L2 -> L1 line bandwidth (9.4x line amplification: 128 B moved per 8 B used, 94 % L2 hits; "
-                                                "profiles/r03_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
+                                                "profiles/r04_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
              "grid_encode_backward": ("hbm", "priced against HBM as the contract asks; by the SQ counters both kernels sit on VALU issue (DESIGN.md 4.1)")}
     dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
     roofline = None
