@@ -332,7 +332,7 @@ def test_checkpoint_after_device_occupancy_update_holds_plain_numbers(dev, tmp_p
 
 
 # ------------------------------------------------------------------------------------------------- N4: the curved field, end to end
-BAR_CURVED = {"sigma net": 4e-2, "colour net": 4e-2, "table L1": 5e-2}  # (set from the measurement printed by the test below)
+BAR_CURVED = {"sigma net": 4e-2, "colour net": 4e-2, "table L1": 1e-3}  # (from the measurement the test below prints)
 
 
 def _curved_field(g, p, dev):
@@ -395,9 +395,9 @@ def test_curved_field_matches_the_reference_modules_executed(dev):
     rows = torch.from_numpy(g["g_table_rows"]).long().to(dev)
     measured["table rows"] = float(np.abs(gt[rows].float().cpu().numpy() - g["g_table_vals"]).max() / np.abs(g["g_table_vals"]).max())
     print("curved field, gradient errors vs the reference's modules executed (max |diff| / max |want|; L1 relative):", {k: round(v, 5) for k, v in measured.items()})
-    # bars = twice what is measured on an MI355X (round 4: sigma net 4.6e-3, colour net 6.3e-3, table L1 2.0e-3; they were 4e-2, 4e-2, 5e-2).
-    # What is left is the fp16 MLP (the reference's fully-fused kernels accumulate in half) and the samples whose projection picked the
-    # neighbouring triangle (< 1 %).
+    # measured on an MI355X (round 4): sigma net 3.5e-2, colour net 3.4e-2 of the largest entry, table L1 1.5e-4 relative, sampled table rows
+    # 7.3e-2 of the largest.  The weight-gradient figures are what a handful of samples cost whose projection picked the neighbouring triangle
+    # (< 1 %: another surface point, other features) on top of the fp16 MLP -- their bar stays 4e-2; the table's L1 bar goes 5e-2 -> 1e-3.
     assert measured["sigma net"] < BAR_CURVED["sigma net"] and measured["colour net"] < BAR_CURVED["colour net"], measured
     assert measured["table L1"] < BAR_CURVED["table L1"], measured
 
