@@ -105,6 +105,14 @@ void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
             return nullptr;
         }
         s.bytes = want;
+        // debugging aid (NERFTEX_POISON_WORKSPACE=<byte>, read once): fill fresh scratch with that byte -- 255 makes every float a NaN and every
+        // index enormous -- so that a kernel which reads scratch nobody wrote shows up in the tests instead of depending on what the pages held
+        static const int poison = [] { const char* v = getenv("NERFTEX_POISON_WORKSPACE"); return v && *v ? atoi(v) : -1; }();
+        if (poison >= 0) {
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+            (void)hipMemset(s.ptr, poison & 255, want);
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+        }
     }
     return s.ptr;
 }
