@@ -21,7 +21,7 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas(extra):
     port = 29600 + os.getpid() % 200 + (0 if not extra else 7 if extra[0] == "--no-fused-opt" else 13)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4", "--rays", "2048", "--no-cpu-baseline",
-           "--no-other", "--no-infer", "--no-kernel-timing"] + extra
+           "--no-other", "--no-infer", "--no-kernel-timing", "--warm-seconds", "0"] + extra
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -36,7 +36,7 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas(extra):
 
 def _bench(n_ranks, rays, extra, port):
     env = dict(os.environ, NERFTEX_DP_SHARE_GPU="1")
-    common = ["--steps", "12", "--warmup", "4", "--rays", str(rays), "--no-cpu-baseline", "--no-other", "--no-infer", "--no-kernel-timing", "--no-perturb"] + extra
+    common = ["--steps", "12", "--warmup", "4", "--rays", str(rays), "--no-cpu-baseline", "--no-other", "--no-infer", "--no-kernel-timing", "--no-perturb", "--warm-seconds", "0"] + extra
     if n_ranks == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--graph-split"] + common
     else:
@@ -76,7 +76,7 @@ def test_march_one_step_ahead_trains_bit_identically():
     out = []
     for extra in ([], ["--no-march-ahead"]):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "4", "--rays", "2048", "--no-cpu-baseline", "--no-other",
-               "--no-infer", "--no-kernel-timing"] + extra
+               "--no-infer", "--no-kernel-timing", "--warm-seconds", "0"] + extra
         run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert run.returncode == 0, run.stderr[-2000:]
         out.append(json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1]))
