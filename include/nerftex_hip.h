@@ -52,6 +52,11 @@ typedef struct nerftex_raytracer nerftex_raytracer;
  * (INTEGRATION.md "Scratch memory and streams"). [extension] */
 unsigned nerftex_workspace_slots_touched(void);
 
+/* Debugging aid: where the library's scratch of `slot` for `stream` (NULL = the default stream) currently sits and how large it is (*ptr = NULL,
+ * *bytes = 0 if none has been allocated).  Nothing is allocated.  The contents are whatever the last call that used the slot left -- for slot 5
+ * (hash-grid backward) the directory, the partial tiles and the record regions, in that order (csrc/gridencoder_binned.hip). [extension] */
+int nerftex_debug_workspace(int slot, void* stream, void** ptr, size_t* bytes);
+
 /* thread-local text of the last error on this thread ("" if none) */
 const char* nerftex_last_error(void);
 /* library / build identification: "nerftex_hip <ver> gfx950" */

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
                                                                   const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
                                                                   uint32_t gridtype, bool align_corners, const DirTable tab,
                                                                   uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, uint32_t merge_res,
-                                                                  uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe) {
+                                                                  uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe, const uint32_t stage_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1];
     constexpr int NP = Sample<T, D>::NP;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
         const uint32_t t = row / kRows;
         const uint32_t at = lbase[t] + rank;
         const Rec<T> r = make_record<T>(row - t * kRows, code, sm.p, p16s, v);
-        if (at < kStageRecords) stage[at] = __builtin_bit_cast(Bits, r);
+        if (at < stage_cap) stage[at] = __builtin_bit_cast(Bits, r);
         else region[at] = r;
     };
     if (sm.live) {
@@ -417,13 +417,13 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
         const float zero2[2] = {0.0f, 0.0f};
         const Rec<T> r = make_record<T>(0u, kSingle, 0.0f, 0u, zero2);
         for (uint32_t at = lbase[threadIdx.x] + real; at < lbase[threadIdx.x] + padded; at++) {
-            if (at < kStageRecords) stage[at] = __builtin_bit_cast(Bits, r);
+            if (at < stage_cap) stage[at] = __builtin_bit_cast(Bits, r);
             else region[at] = r;
         }
     }
     __syncthreads();
     if (probe == 3) return;  // ablation: + placement in LDS
-    const uint32_t total = min(lbase[kMaxTilesPerLevel], kStageRecords);
+    const uint32_t total = min(lbase[kMaxTilesPerLevel], stage_cap);
     // one contiguous block, tile order preserved; 16 bytes per lane (two fp16 records / one fp32 record) while they last
     constexpr uint32_t kPer = 16 / sizeof(Bits);
     typedef u32x4_t __attribute__((address_space(3))) LdsQuad;
@@ -841,11 +841,14 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     const uint32_t lv_lo = lc.bwd_phase == 0 ? 0u : std::min(lc.level_lo, L), lv_hi = lc.bwd_phase == 0 ? L : std::min(lc.level_hi, L);
     if (do_fill) {
         auto fill = blc ? bin_fill_dir_kernel<T, D, true> : bin_fill_dir_kernel<T, D, false>;
-        const size_t lds = sizeof(Rec<T>) * (size_t)kStageRecords;
+        // grid_bwd_stage: LDS slots of a fill workgroup (a multiple of 16 records = whole 128-byte lines, at most the region)
+        const long sk = knob(kKnobGridBwdStage);
+        const uint32_t stage_cap = sk > 0 ? std::min<uint32_t>(((uint32_t)sk + 15u) & ~15u, kRegionRecords / 16u * 16u) : kStageRecords;
+        const size_t lds = sizeof(Rec<T>) * (size_t)stage_cap;
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         KernelTimer kt("bin_fill_dir_kernel", st, kTimeGrid);
         hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), dim3(kBinSamples), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype,
-                           align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr, probe);
+                           align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr, probe, stage_cap);
     }
     if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
     if (!do_sum || lv_lo >= lv_hi) return NERFTEX_OK;

@@ -27,7 +27,7 @@ long g_knobs[kKnobCount] = {0};
 namespace {
 const char* const kKnobNames[kKnobCount] = {"grid_fwd", "grid_bwd", "grid_bwd_sweep", "grid_bwd_items", "grid_bwd_slice", "grid_bwd_nomerge",
                                             "grid_bwd_probe", "march", "march_serial", "ffmlp_wg_per_cu",
-                                            "ffmlp_bwd_split", "march_lean", "ffmlp_bwd_tr"};
+                                            "ffmlp_bwd_split", "march_lean", "ffmlp_bwd_tr", "grid_bwd_stage"};
 int knob_index(const char* name, size_t n) {
     for (int k = 0; k < kKnobCount; k++)
         if (strlen(kKnobNames[k]) == n && strncmp(kKnobNames[k], name, n) == 0) return k;
@@ -115,6 +115,16 @@ void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
         }
     }
     return s.ptr;
+}
+
+bool peek_workspace(int slot, hipStream_t stream, void** ptr, size_t* bytes) {
+    int dev = 0;
+    if (slot < 0 || slot >= kWsSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws[dev].find(stream);
+    *ptr = it == g_ws[dev].end() ? nullptr : it->second.slot[slot].ptr;
+    *bytes = it == g_ws[dev].end() ? 0 : it->second.slot[slot].bytes;
+    return true;
 }
 
 void release_workspaces() {
@@ -234,6 +244,15 @@ unsigned nerftex_workspace_slots_touched(void) {
     const unsigned m = nerftex::g_ws_touched;
     nerftex::g_ws_touched = 0;
     return m;
+}
+
+int nerftex_debug_workspace(int slot, void* stream, void** ptr, size_t* bytes) {
+    nerftex::clear_error();
+    if (!ptr || !bytes || !nerftex::peek_workspace(slot, static_cast<hipStream_t>(stream), ptr, bytes)) {
+        nerftex::set_error("nerftex_debug_workspace: bad slot / device / output pointers");
+        return NERFTEX_ERR_INVALID;
+    }
+    return NERFTEX_OK;
 }
 
 const char* nerftex_last_error(void) { return nerftex::g_err; }

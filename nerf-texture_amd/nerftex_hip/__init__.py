@@ -91,6 +91,7 @@ _SIGNATURES = {
     "nerftex_knn_create": [_vp, _u32, C.POINTER(_vp)],
     "nerftex_knn_destroy": [_vp],
     "nerftex_knn_query": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "nerftex_debug_workspace": [C.c_int, _vp, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "nerftex_raytracer_trace": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
 }
 EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get", "nerftex_workspace_slots_touched"] + list(_SIGNATURES)

@@ -6,7 +6,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libnerftex_hip.so")
+# NERFTEX_HIP_LIB: another build of the same library (A/B experiments on compiler flags); the default is the in-tree build
+LIB_PATH = os.environ.get("NERFTEX_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libnerftex_hip.so")
 
 
 def build(force=False, verbose=False):

@@ -66,6 +66,7 @@ import os
 # False (NERFTEX_FIELD_BACKWARD=split): the six launches (glue, MLP + reduce, glue, MLP + reduce) nerftex_field_backward's three replace --
 # same gradients, for A/B
 FIELD_BACKWARD_FUSED = os.environ.get("NERFTEX_FIELD_BACKWARD", "fused") != "split"
+DEBUG_TAP = None  # debugging aid (tools/determinism_probe.py): a callable that is shown the field backward's intermediate gradients
 
 
 class _ngp_field(Function):
@@ -151,6 +152,8 @@ class _ngp_field(Function):
             grad_h = torch.empty(B, 16, **half)
             check(lib.nerftex_field_mid_backward(ptr(grad_sigma), ptr(grad_cin), ptr(h), B, ptr(grad_h), stream()))
             check(lib.nerftex_ffmlp_backward(ptr(grad_h), ptr(x_rows), ptr(ws_h), None, B, 32, 16, 64, 2, 0, 6, 1, None, ptr(grad_x), ptr(grad_ws), stream()))
+        if DEBUG_TAP is not None:
+            DEBUG_TAP(grad_x=grad_x, x=x, grad_sigma=grad_sigma, grad_rgbs=grad_rgbs, grad_cin=grad_cin, meta=(S, H, gridtype, align, affine))
         grad_table = torch.empty_like(table_h)
         dummy = torch.empty(1, **half)
         chunker = ctx.grad_chunker if sink is None else None

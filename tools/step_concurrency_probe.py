@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""GPU probe: is every kernel of the training step bit-reproducible while another PROCESS (or nothing) keeps the GPU busy?
+
+    python tools/step_concurrency_probe.py --neighbour none|process [--iters N]
+
+One eager training step without the optimizer update (march -> hash grid + field forward -> compositing + loss -> backward: compositing, field,
+hash grid) is repeated on the SAME rays and weights; exact checksums of every stage's outputs are compared with the first iteration's.  A stage that
+differs names the kernel family that is not reproducible under co-scheduling (round 4: the hash-grid backward's record builder, when compiled with
+packed-fp32 instructions -- csrc/Makefile).  Prints one JSON line; exit code 1 if anything differed."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--neighbour", choices=["none", "process"], default="process")
+    ap.add_argument("--iters", type=int, default=300)
+    args = ap.parse_args()
+    import torch
+    from determinism_probe import cs
+
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer
+
+    dev = torch.device("cuda:0")
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+    r.set_occupancy(torch.from_numpy(grid).to(dev))
+    leaves = [field.encoder.embeddings, field.sigma_net.weights, field.color_net.weights]
+    o, d = scene.train_batch(8192, seed=100, n_views=4)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    gt = torch.rand(8192, 3, generator=torch.Generator().manual_seed(4321)).to(dev)
+    one = torch.ones((), device=dev)
+    scale = torch.full((), 65536.0, device=dev)
+
+    def step():
+        for leaf in leaves:
+            leaf.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            marched, counter = r.march_train(ro, rd, dt_gamma=1 / 128, perturb=False, mean_count=462848)
+            nears, fars, xyzs, dirs, deltas, rays = marched
+            image, depth, loss, scaled = r.shade_train(marched, 1, target=gt, loss_mul=1.0, scale=scale)
+        scaled.backward(one)
+        return {"march": (cs(xyzs), cs(deltas), cs(rays), tuple(counter.tolist())), "forward": (cs(image), cs(loss.reshape(1))),
+                "backward_mlp": (cs(leaves[1].grad), cs(leaves[2].grad)), "backward_table": (cs(leaves[0].grad),)}
+
+    first = step()
+    again = step()
+    assert first == again, "two quiet-GPU iterations disagree"
+    child = None
+    if args.neighbour == "process":
+        ready = os.path.join(tempfile.mkdtemp(), "ready")
+        env = dict(os.environ, STEPS=str(max(100, args.iters * 3)), READY_FILE=ready)
+        env.pop("RECHECK", None)
+        child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "determinism_probe.py"), "neighbour"], env=env, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL)
+        t0 = time.time()
+        while not os.path.exists(ready) and child.poll() is None and time.time() - t0 < 180:
+            time.sleep(0.05)
+        assert os.path.exists(ready), "the neighbour process did not come up"
+    differing = {k: 0 for k in first}
+    done = beside = 0
+    for i in range(args.iters):
+        got = step()
+        done += 1
+        beside += int(child is not None and child.poll() is None)
+        for k in first:
+            differing[k] += int(got[k] != first[k])
+        if child is not None and child.poll() is not None:
+            break
+    if child is not None:
+        child.kill() if child.poll() is None else None
+        child.wait()
+    print(json.dumps({"neighbour": args.neighbour, "library": os.environ.get("NERFTEX_HIP_LIB", "in-tree"), "iterations": done, "beside_the_neighbour": beside,
+                      "iterations_differing_by_stage": differing}))
+    return 1 if any(differing.values()) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
