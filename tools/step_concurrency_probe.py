@@ -48,7 +48,7 @@ def main():
     one = torch.ones((), device=dev)
     scale = torch.full((), 65536.0, device=dev)
 
-    def step():
+    def step_():
         for leaf in leaves:
             leaf.grad = None
         with torch.autocast("cuda", dtype=torch.float16):
@@ -58,6 +58,34 @@ def main():
         scaled.backward(one)
         return {"march": (cs(xyzs), cs(deltas), cs(rays), tuple(counter.tolist())), "forward": (cs(image), cs(loss.reshape(1))),
                 "backward_mlp": (cs(leaves[1].grad), cs(leaves[2].grad)), "backward_table": (cs(leaves[0].grad),)}
+
+    io, idr = scene.train_batch(65536, seed=7, n_views=1)
+    iro, ird = torch.from_numpy(io).to(dev), torch.from_numpy(idr).to(dev)
+    grid0, bits0, iter0 = r.density_grid.clone(), r.density_bitfield.clone(), r.iter_density
+
+    def train_step():
+        return step_()
+
+    def step():
+        out = step_()
+        # a rendered frame: 64k rays through the pipelined inference loop in two parts on two streams (march, compaction, hash grid, field, compositing)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            img, depth, n = r.render_infer_pipelined(iro, ird, dt_gamma=1 / 128, slots_per_ray=4, parts=2)
+        out["inference"] = (cs(img), cs(depth), int(n))
+        # the occupancy update, full sweep and partial update, from the same grid and seed every time
+        occ = []
+        for it in (0, 20):
+            r.density_grid.copy_(grid0)
+            r.density_bitfield.copy_(bits0)
+            r.iter_density = it
+            with torch.no_grad():
+                r.update_extra_state_device(seed=5)
+            occ.append((cs(r.density_grid), cs(r.density_bitfield), cs(r.mean_density.reshape(1))))
+        r.density_grid.copy_(grid0)
+        r.density_bitfield.copy_(bits0)
+        r.iter_density = iter0
+        out["occupancy"] = tuple(occ)
+        return out
 
     first = step()
     again = step()
