@@ -208,6 +208,58 @@ __device__ __forceinline__ void load_row_pair(const T* __restrict__ p, float (&a
     }
 }
 
+// the same loads WITHOUT unpacking: a row stays the vector the load returned (for fp16 C = 2: one dword).  A gather kernel issues all its row
+// loads first and unpacks / converts afterwards, so that the wait for the first row does not sit in front of the request for the second (the
+// compiler places a load's wait at the first instruction that touches the data -- an element extract counts)
+template <typename T, int C> struct RowVec { using type = typename Vec<T, C>::type; };
+template <> struct RowVec<float, 8> { struct type { float4_t lo, hi; }; };
+template <typename T, int C>
+__device__ __forceinline__ typename RowVec<T, C>::type load_row_packed(const T* __restrict__ p) {
+    if constexpr (C == 8 && sizeof(T) == 4) {
+        return {*reinterpret_cast<const float4_t*>(p), *reinterpret_cast<const float4_t*>(p + 4)};
+    } else {
+        using V = typename Vec<T, C>::type;
+        return *reinterpret_cast<const V*>(p);
+    }
+}
+template <typename T, int C>
+__device__ __forceinline__ void load_row_pair_packed(const T* __restrict__ p, typename RowVec<T, C>::type& a, typename RowVec<T, C>::type& b) {
+    using V = typename Vec<T, 2 * C>::type;
+    typedef V __attribute__((aligned(C * sizeof(T)))) VU;
+    const V v = *reinterpret_cast<const VU*>(p);
+    if constexpr (C == 1) {
+        a = v[0];
+        b = v[1];
+    } else if constexpr (C == 2) {
+        a = __builtin_shufflevector(v, v, 0, 1);
+        b = __builtin_shufflevector(v, v, 2, 3);
+    } else {
+        a = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+        b = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+    }
+}
+template <typename T, int C>
+__device__ __forceinline__ void unpack_row(const typename RowVec<T, C>::type& r, float (&v)[C]) {
+    if constexpr (C == 8 && sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = r.lo[i]; v[4 + i] = r.hi[i]; }
+    } else if constexpr (C == 1) {
+        v[0] = (float)r;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; i++) v[i] = (float)r[i];
+    }
+}
+
+// the value a 16-bit store rounds: pinned in a register as fp32 first.  Without this the compiler folds the last fmaf of an interpolation and
+// the conversion into ONE v_fma_mix{lo,hi}_f16, which rounds the exact sum to half once -- the contract here (and the oracle) is
+// half(fp32 result): two roundings (seen as soon as the SLP vectorizer, which happened to stand in the way of that fold, was turned off)
+template <typename T>
+__device__ __forceinline__ T rounded_from_fp32(float v) {
+    if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(v));
+    return (T)v;
+}
+
 template <typename T, int C>
 __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]) {
     if constexpr (C == 8 && sizeof(T) == 4) {
@@ -217,12 +269,12 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&v)[C]
         *reinterpret_cast<float4_t*>(p) = a;
         *reinterpret_cast<float4_t*>(p + 4) = b;
     } else if constexpr (C == 1) {
-        p[0] = (T)v[0];
+        p[0] = rounded_from_fp32<T>(v[0]);
     } else {
         using V = typename Vec<T, C>::type;
         V a;
 #pragma unroll
-        for (int i = 0; i < C; i++) a[i] = (T)v[i];
+        for (int i = 0; i < C; i++) a[i] = rounded_from_fp32<T>(v[i]);
         *reinterpret_cast<V*>(p) = a;
     }
 }

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
         pos[d] -= (float)pos_grid[d];
     }
     float g[1 << D][C];
+    typename RowVec<T, C>::type raw[1 << D];
     float w[1 << D];
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {  // weights in the reference's dimension order (gridencoder.cu:150-164)
@@ -238,16 +239,19 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
         const uint32_t rb = index_of.wrap(index_of.combine(term[0][1], yz));
         if constexpr (kHasPairLoad<T, C>) {
             if (rb == ra + 1) {
-                load_row_pair<T, C>(table + (size_t)ra * C, g[2 * q], g[2 * q + 1]);
+                load_row_pair_packed<T, C>(table + (size_t)ra * C, raw[2 * q], raw[2 * q + 1]);
             } else {
-                load_row<T, C>(table + (size_t)ra * C, g[2 * q]);
-                load_row<T, C>(table + (size_t)rb * C, g[2 * q + 1]);
+                raw[2 * q] = load_row_packed<T, C>(table + (size_t)ra * C);
+                raw[2 * q + 1] = load_row_packed<T, C>(table + (size_t)rb * C);
             }
         } else {
-            load_row<T, C>(table + (size_t)ra * C, g[2 * q]);
-            load_row<T, C>(table + (size_t)rb * C, g[2 * q + 1]);
+            raw[2 * q] = load_row_packed<T, C>(table + (size_t)ra * C);
+            raw[2 * q + 1] = load_row_packed<T, C>(table + (size_t)rb * C);
         }
     }
+    // all eight rows requested; only now the values are looked at (one wait for the lot, whatever the vectorizer does or does not do)
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) unpack_row<T, C>(raw[idx], g[idx]);
     float r[C];
 #pragma unroll
     for (int c = 0; c < C; c++) r[c] = 0.0f;
@@ -337,6 +341,7 @@ constexpr uint32_t kOwnerLdsBytes = kOwnerAccBytes + kOwnerWaves * kQueueCap * 1
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
 __device__ __forceinline__ void atomic_add_h2(half_t* addr, float a, float b) {
+    asm volatile("" : "+v"(a), "+v"(b));  // (the shares are fp32 values rounded to half: no fused multiply-convert, grid_common.hpp rounded_from_fp32)
     __half2 v = __floats2half2_rn(a, b);
     unsafeAtomicAdd(reinterpret_cast<__half2*>(addr), v);
 }
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(const T* __restrict_
                 assumed = old;
                 unsigned short hs = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
                 half_t hv = __builtin_bit_cast(half_t, hs);
-                hv = (half_t)((float)hv + v[idx][0]);
+                hv = rounded_from_fp32<half_t>((float)hv + v[idx][0]);
                 unsigned short ns = __builtin_bit_cast(unsigned short, hv);
                 unsigned int repl = hi ? ((assumed & 0xffffu) | ((unsigned int)ns << 16)) : ((assumed & 0xffff0000u) | ns);
                 old = atomicCAS(base, assumed, repl);
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(kOwnerThreads) void grid_backward_owner_kernel(cons
                         const uint32_t slot = q_count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         Entry e;
                         e.rel = rel[idx];
-                        if constexpr (sizeof(T) == 2) e.v = half2_t{(half_t)(wi * g[0]), (half_t)(wi * g[1])};
+                        if constexpr (sizeof(T) == 2) e.v = half2_t{rounded_from_fp32<half_t>(wi * g[0]), rounded_from_fp32<half_t>(wi * g[1])};
                         else { e.v0 = wi * g[0]; e.v1 = wi * g[1]; }
                         queue[slot] = e;
                     }
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(256) void grid_input_backward_kernel(const T* __res
 #pragma unroll
         for (int c = 0; c < C; c++) result = fmaf((float)gp[c], (float)dyd[(size_t)l * D * C + d * C + c], result);
     }
-    grad_inputs[t] = (T)result;
+    grad_inputs[t] = rounded_from_fp32<T>(result);
 }
 
 // ------------------------------------------------------------------------------------------------

