@@ -76,7 +76,7 @@ def main():
     child, ready = None, None
     if args.neighbour == "process":
         ready = os.path.join(tempfile.mkdtemp(), "ready")
-        env = dict(os.environ, STEPS=str(max(60, args.launches // 2)), READY_FILE=ready)
+        env = dict(os.environ, STEPS=str(max(60, args.launches * 2)), READY_FILE=ready)
         env.pop("RECHECK", None)
         child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "determinism_probe.py"), "neighbour"], env=env, stdout=subprocess.DEVNULL,
                                  stderr=subprocess.DEVNULL)
@@ -117,6 +117,8 @@ def main():
     torch.cuda.synchronize()
     secs = time.time() - t0
     if child is not None:
+        if child.poll() is None:
+            child.kill()
         child.wait()
     print(json.dumps({"neighbour": args.neighbour, "library": os.environ.get("NERFTEX_HIP_LIB", "in-tree"), "launches": done,
                       "launches_beside_the_neighbour": overlapped if child is not None else (done if side is not None else 0), "B": B,

@@ -93,7 +93,7 @@ def main():
     child = None
     if args.neighbour == "process":
         ready = os.path.join(tempfile.mkdtemp(), "ready")
-        env = dict(os.environ, STEPS=str(max(100, args.iters * 3)), READY_FILE=ready)
+        env = dict(os.environ, STEPS=str(max(100, args.iters * 12)), READY_FILE=ready)
         env.pop("RECHECK", None)
         child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "determinism_probe.py"), "neighbour"], env=env, stdout=subprocess.DEVNULL,
                                  stderr=subprocess.DEVNULL)
