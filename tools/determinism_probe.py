@@ -1,7 +1,22 @@
 #!/usr/bin/env python3
-"""Debug probe (GPU): checksums after every stage of a few eager training steps.  Run several copies CONCURRENTLY on one GPU and diff their
-outputs: single-process runs are bit-reproducible, but processes that time-share the device were seen to end 1e-6 apart (round 4) -- which
-stage is the first to differ?"""
+"""Debug probe (GPU): exact checksums after every stage of a few eager training steps, and -- round 4 -- the instruments that found out why
+two-rank runs on one GPU differed from run to run.  Plain use: run several copies concurrently (or under torchrun with
+NERFTEX_DP_SHARE_GPU=1: the two-ranks-on-one-GPU rig) and diff gpurun_out/detprobe/run_<tag>.txt.  Environment switches:
+
+  STEPS=n            steps (default 10); the first two size their buffers by the count, later ones use the fresh-ray march
+  RECHECK=1          after every backward, recompute the table gradient three times from the tapped inputs (ngp_harness.fused.DEBUG_TAP) and
+                     say how many elements of autograd's result differ; then a second SUM over the scratch autograd's launch left
+                     (phase 2 only: same wrong bits => the fill kernel wrote wrong records); PHASE_REPS / AGAIN_REPS repeat the
+                     bin-once-sum-twice and the one-call forms; FRESH_OUT=1|2 gives every repetition freshly allocated output memory
+  SIDE_AGAIN=1       the recomputations run on another stream (their own scratch set): when autograd's launch is the odd one out its
+                     scratch is still intact and is compared with a good launch's -- directory words, then the record regions as multisets,
+                     then which samples of the chunk the odd records belong to (nerftex_debug_workspace)
+  SNAPSHOT=1         the same comparison from copies taken right after the backward (perturbs the timing: the failure went away)
+  DUMP=prefix        torch.save the table gradient and the tapped inputs of step DUMP_STEP; DUMP_FAIL=1: of the first failing steps
+  TIMESYNC=seconds   processes without a collective between them start their steps on a common wall-clock grid
+  USE_STREAM=1       everything on an explicit stream instead of the legacy null stream; EXTRA_STREAMS=1: staged copies on a pool stream
+  READY_FILE=path    touch it at step 2 (tools/*_concurrency_probe.py use this script as the neighbour that keeps the GPU busy)
+  LOSS_MUL, NO_ATTACH, SYNC_AFTER, RELEASE: single switches of the data-parallel step, for bisecting"""
 import os
 import sys
 
