@@ -1,4 +1,5 @@
 """Build-level pins that need no GPU."""
+import glob
 import os
 import re
 import shutil
@@ -9,24 +10,77 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf-texture_amd", "csrc")
+SOURCES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(CSRC, "*.hip")))
+# one kernel per translation unit that must show up in the assembly (proves the file was really compiled for the device)
+KERNEL_OF = {
+    "gridencoder_binned": "bin_fill_dir_kernel", "gridencoder": "grid_forward_level_kernel", "raymarching": "march_count_parallel_kernel",
+    "raytracer": "raytrace_kernel", "shencoder": "sh_forward_kernel", "occupancy": "kernel", "trainstep": "adam_half_kernel",
+    "fieldglue": "kernel", "knn": "knn_query_kernel", "ffmlp": "ffmlp_backward_fused_kernel", "runtime": None,
+}
+# every packed-fp32 opcode gfx950 has (the `packed-fp32-ops` target feature): v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32, v_pk_mov_b32
+PACKED_FP32 = re.compile(r"\bv_pk_(?:[a-z]+_f32|mov_b32)\b")
 
 
-@pytest.mark.parametrize("source, kernel", [("gridencoder_binned", "bin_fill_dir_kernel"), ("gridencoder", "grid_forward_level_kernel")])
-def test_hash_grid_kernels_are_compiled_without_packed_fp32(source, kernel):
-    """csrc/Makefile: the hash-grid sources must not contain v_pk_*_f32 instructions (round 4: with them the backward's record builder and the
-    gather's input-gradient branch are not reproducible when other kernels share the GPU -- tests/test_gpu_dp_shared_gpu.py has the GPU side).  Compiles the file to assembly with the Makefile's own
-    command line and looks."""
-    if shutil.which("hipcc") is None:
-        pytest.skip("needs hipcc")
-    dry = subprocess.run(["make", "-C", CSRC, "-n", "-W", f"{source}.hip", f"../lib/obj/{source}.o"], capture_output=True, text=True, check=True).stdout
-    cmd = [ln for ln in dry.splitlines() if f" {source}.hip" in ln and " -c " in ln][-1].split()
-    assert "-fno-slp-vectorize" in cmd and "-disable-vector-combine" in cmd, cmd
+def _device_assembly(source):
+    """The file compiled to gfx950 assembly with the Makefile's own command line (dry run of the object's rule, -c swapped for -S)."""
+    cmd = _compile_line(source)  # (the rule filters the host compile's "not a recognized feature" note from stderr)
     with tempfile.TemporaryDirectory() as tmp:
-        asm = os.path.join(tmp, "binned.s")
+        asm = os.path.join(tmp, source + ".s")
         i = cmd.index("-c")
         cmd[i:i + 1] = ["--cuda-device-only", "-S"]
         cmd[cmd.index("-o") + 1] = asm
         subprocess.run(cmd, cwd=CSRC, check=True, capture_output=True)
-        text = open(asm).read()
-    assert kernel in text
-    assert not re.search(r"\bv_pk_[a-z]+_f32\b", text)
+        return cmd, open(asm).read()
+
+
+def test_the_makefile_covers_every_source():
+    assert set(SOURCES) == set(KERNEL_OF), "a new csrc/*.hip needs a row in KERNEL_OF (and inherits the library-wide flags)"
+
+
+def _compile_line(source):
+    dry = subprocess.run(["make", "-C", CSRC, "-n", "-W", f"{source}.hip", f"../lib/obj/{source}.o"], capture_output=True, text=True, check=True).stdout
+    return [ln for ln in dry.splitlines() if f" {source}.hip" in ln and " -c " in ln][-1].split(" 2>")[0].split()
+
+
+@pytest.mark.parametrize("source", SOURCES)
+def test_every_translation_unit_is_compiled_with_the_packed_fp32_feature_off(source):
+    """the command line `make` would run for each file (no compile: fast; the MFMA file, minutes to compile, is covered here and by the
+    disassembly of the built library below)"""
+    cmd = _compile_line(source)
+    assert "-target-feature -Xclang -packed-fp32-ops" in " ".join(cmd), cmd
+    assert ("-fno-slp-vectorize" in cmd and "-disable-vector-combine" in cmd) == (source != "ffmlp"), cmd
+
+
+def test_the_built_library_contains_no_packed_fp32_instruction():
+    """what ships: every gfx950 code object inside nerf-texture_amd/lib/libnerftex_hip.so, disassembled (build() has run: conftest / the driver)."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "nerf-texture_amd", "lib", "libnerftex_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(lib)):
+        pytest.skip("needs llvm-objdump and the built library")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(lib, tmp)
+        subprocess.run([objdump, "--offloading", "libnerftex_hip.so"], cwd=tmp, check=True, capture_output=True)
+        objs = sorted(glob.glob(os.path.join(tmp, "*gfx950")))
+        assert len(objs) >= len(SOURCES) - 1, objs  # one code object per file with device code (runtime.hip has none)
+        n_inst = 0
+        for o in objs:
+            text = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+            n_inst += text.count("\n")
+            hits = PACKED_FP32.findall(text)
+            assert not hits, f"{os.path.basename(o)}: {len(hits)} packed-fp32 instructions, e.g. {sorted(set(hits))}"
+        assert n_inst > 1_000_000  # (the disassembly really is the library's: ~1.5 M instructions)
+
+
+@pytest.mark.parametrize("source", [s for s in SOURCES if s != "ffmlp"])
+def test_no_translation_unit_contains_packed_fp32(source):
+    """csrc/Makefile: NO v_pk_*_f32 / v_pk_mov_b32 anywhere in the library.  Round 4: with them the hash-grid backward's record builder and the
+    gather's input-gradient branch were not reproducible when other kernels shared the GPU (tests/test_gpu_dp_shared_gpu.py has the GPU side);
+    round 5: the cause is not known to be specific to those kernels, so the target feature is off for every file (and the two IR passes that form
+    <2 x float> arithmetic are off everywhere but the MFMA file).  Compiles each file to assembly with the Makefile's own command line and looks."""
+    if shutil.which("hipcc") is None:
+        pytest.skip("needs hipcc")
+    cmd, text = _device_assembly(source)
+    if KERNEL_OF[source]:
+        assert KERNEL_OF[source] in text
+    hits = PACKED_FP32.findall(text)
+    assert not hits, f"{source}.hip: {len(hits)} packed-fp32 instructions, e.g. {sorted(set(hits))}"
