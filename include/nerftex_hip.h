@@ -291,7 +291,14 @@ int nerftex_field_backward(const float* grad_sigma, const float* grad_rgbs, cons
  * the same calls as nerftex_field_backward / nerftex_grid_encode_backward_affine, and *found_inf (a device float) is set to 1.0f when an
  * element of grad_sigma_weights / grad_color_weights, resp. of grad_embeddings, comes out inf or nan.  Never cleared here (the
  * optimizer step clears it: nerftex_adam_half_step_amp); found_inf NULL = the plain call.  Paths of the hash-grid backward whose
- * stores cannot carry the test (small batches: atomics) scan the finished table in one more launch -- the contract holds for all. */
+ * stores cannot carry the test (small batches: atomics) scan the finished table in one more launch -- the contract holds for all.
+ * Two limits a C caller must know (the Python harness satisfies both):
+ *   - the scan covers the values THIS call writes.  With NERFTEX_LAYOUT_GRAD_OVERWRITE every row is written by the call, so it covers the
+ *     whole table; in ACCUMULATE mode (the reference's pre-zeroed buffer, the default layout) rows whose contribution from this call is
+ *     zero are not rewritten and an inf / nan ALREADY in grad_embeddings there is not seen -- scan an accumulated gradient with
+ *     nerftex_amp_check_half instead;
+ *   - *found_inf is sticky until an optimizer step (nerftex_adam_half_step_amp) or nerftex_amp_update clears it: a caller that DISCARDS a
+ *     backward pass without stepping must zero it itself, or the next, unrelated step is skipped.                                      */
 int nerftex_field_backward_amp(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
                                const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                                void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream);

@@ -2,6 +2,8 @@
 #include "common.hpp"
 #include "workspace.hpp"
 
+#include <atomic>
+
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -73,10 +75,10 @@ std::vector<void*> g_retired;  // outgrown buffers: kept until release_workspace
 std::mutex g_ws_mutex;
 }  // namespace
 
-unsigned g_ws_touched = 0;
+std::atomic<unsigned> g_ws_touched{0};
 
 void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
-    g_ws_touched |= 1u << (unsigned)slot;
+    g_ws_touched.fetch_or(1u << (unsigned)slot, std::memory_order_relaxed);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
         set_error("workspace: bad device");
@@ -241,8 +243,7 @@ long nerftex_tune_get(const char* name) {
 
 // test aid: bit mask of the scratch slots (csrc/workspace.hpp WorkspaceSlot) library calls have asked for since the last call of this function
 unsigned nerftex_workspace_slots_touched(void) {
-    const unsigned m = nerftex::g_ws_touched;
-    nerftex::g_ws_touched = 0;
+    const unsigned m = nerftex::g_ws_touched.exchange(0u, std::memory_order_relaxed);
     return m;
 }
 

@@ -16,6 +16,7 @@
 //     step read the scratch their phase-1 call left, in that order.
 // tests/test_gpu_round4.py::test_concurrent_graphs_use_disjoint_scratch_slots holds the two graph kinds to this list.
 #pragma once
+#include <atomic>
 #include "common.hpp"
 
 namespace nerftex {
@@ -26,6 +27,6 @@ enum WorkspaceSlot { kWsMarch = 0, kWsCompact = 1, kWsMlp = 2, kWsGrid = 3, kWsG
 void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream);
 void release_workspaces();
 // which slots have been handed out for `stream` (a capturing stream: the shared capture set) since the last reset: bit s = slot s (tests)
-extern unsigned g_ws_touched;
+extern std::atomic<unsigned> g_ws_touched;  // (callers on different threads use different per-stream scratch: the mask is the one shared word)
 
 }  // namespace nerftex

@@ -180,14 +180,6 @@ class AcceleratedTrainer:
             self._capture()
         g0 = r.local_step
         main = torch.cuda.current_stream()
-        _t = getattr(self, "_host_times", None)  # debugging aid: host seconds spent in each part of the call (tools/fresh_probe4.py)
-        _c = [__import__("time").perf_counter()] if _t is not None else None
-
-        def _lap(name):
-            if _t is not None:
-                now = __import__("time").perf_counter()
-                _t.setdefault(name, []).append(now - _c[0])
-                _c[0] = now
         if self._ahead is not None and self._ahead == (g0, rays_o.data_ptr(), rays_d.data_ptr()):
             main.wait_stream(self._side)  # marched beside the previous group
         else:
@@ -198,18 +190,14 @@ class AcceleratedTrainer:
             self._ray_o[g0:g0 + k].copy_(rays_o, non_blocking=True), self._ray_d[g0:g0 + k].copy_(rays_d, non_blocking=True)
             for g in range(g0, g0 + k):
                 self._graphs[g][0].replay()
-        _lap("wait_or_march")
         self._ahead = None
         self._targets[g0:g0 + k].copy_(target, non_blocking=True)
-        _lap("copy_targets")
         last = g0 + k == RING
         ready = None
         if next_rays is not None:
             ready = torch.cuda.Event()
             ready.record(main)  # everything enqueued so far (the production of the next rays, an occupancy update) -- NOT this group's kernels
-        _lap("ready")
         self._groups[g0 // k].replay()
-        _lap("group_replay")
         r.local_step = g0 + k
         def march_ahead(slot0):
             no, nd = next_rays
@@ -224,12 +212,10 @@ class AcceleratedTrainer:
         if not last:
             if ready is not None:
                 march_ahead(g0 + k)
-            _lap("march_ahead")
         else:
             self._ring_end(ready)
             if ready is not None and self.march_across_ring_end and self._graphs is not None:  # (graphs dropped: the buffer size changed)
                 march_ahead(0)
-            _lap("ring_end")
         return self.loss
 
     def step(self, rays_o, rays_d, target, next_rays=None, _eager=False):

@@ -327,22 +327,26 @@ class CurvedField(torch.nn.Module):
         sigma, geo = self._sigma(embed)
         return {"sigma": torch.where(h_mask, sigma, torch.zeros_like(sigma)), "geo_feat": geo}
 
-    def density_gradient(self, x, lambda_=5e-2):
+    def density_gradient(self, x, lambda_=5e-2, create_graph=False):
         """network_curvedfield.py:236-254: sigma and d sigma_remap / dx, sigma_remap = (1 - exp(-lambda sigma)) / lambda, through the whole
         chain -- sigma net backward (with input gradients), FreqEncoder(height) and the hash table's input gradient (G3), the projection's
-        `diff_project_layer`.  -> (sigma [N], gradient [N,3], h_mask [N]); the unmasked sigma, as the reference's branch has it there."""
+        `diff_project_layer`.  -> (sigma [N], gradient [N,3], h_mask [N]); the unmasked sigma, as the reference's branch has it there.
+        create_graph: the reference asks autograd for a differentiable gradient (:253, create_graph=True -- its tcnn networks have second
+        derivatives).  The backward kernels behind this chain (G3, the FFMLP input gradient, the projection layer) are first-order, as
+        torch-ngp's own `_grid_encode.backward` is (`once_differentiable`, gridencoder/grid.py:56): with create_graph=True the returned
+        gradient carries the graph of the framework ops only (sigma_remap's exp, the height ladder) and sigma stays attached."""
         with torch.enable_grad():
             x = x.detach().requires_grad_(True)
             embed, _, h_mask = self.embed(x, requires_grad_xyz=True)
             sigma, _ = self._sigma(embed)
             sigma_remap = 1 / lambda_ * (1 - torch.exp(-lambda_ * sigma))
-            grad = torch.autograd.grad(sigma_remap, x, torch.ones_like(sigma), create_graph=False)[0]
-        return sigma.detach(), grad, h_mask
+            grad = torch.autograd.grad(sigma_remap, x, torch.ones_like(sigma), create_graph=create_graph, retain_graph=create_graph)[0]
+        return (sigma if create_graph else sigma.detach()), grad, h_mask
 
-    def density_normal(self, x, lambda_=5e-2):
+    def density_normal(self, x, lambda_=5e-2, create_graph=False):
         """network_curvedfield.py:236-259: the normal from sigma's gradient, n = -d sigma_remap / dx normalised; samples whose gradient is
         not a number leave the mask.  -> (sigma [N], normal_grad [N,3], h_mask [N])."""
-        sigma, grad, h_mask = self.density_gradient(x, lambda_)
+        sigma, grad, h_mask = self.density_gradient(x, lambda_, create_graph)
         normal_grad = -grad
         normal_grad = normal_grad / (normal_grad.norm(dim=-1, keepdim=True) + 1e-5)
         h_mask = torch.logical_and(h_mask, torch.logical_not(normal_grad.isnan()).all(dim=-1))

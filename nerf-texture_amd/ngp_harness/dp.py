@@ -263,7 +263,8 @@ class TableGradChunks:
             lo = hi
         self.levels = bounds
         self.rows = [(off[a], off[b]) for a, b in bounds]
-        self.grad_ptr, self._run, self._keep = None, None, None
+        self.grad_ptr, self._run, self._keep, self._summed = None, None, None, None
+        self.encoder = encoder
         encoder.grad_chunker = self
 
     def __len__(self):
@@ -273,7 +274,12 @@ class TableGradChunks:
         """Called by the backward: `grad` the table-gradient tensor being produced (only its ADDRESS is kept: a second reference would make
         autograd copy the gradient instead of handing the tensor itself to `.grad`), run(level_lo, level_hi) finishes a level range (None:
         the gradient is complete already), keep: what must stay alive until the last range has run."""
+        leaf = getattr(self.encoder, "half_leaf", None)
+        if run is not None and leaf is not None and leaf.grad is not None:
+            raise RuntimeError("TableGradChunks: the table leaf already has a .grad -- autograd would ACCUMULATE the still unfinished gradient into it and the "
+                               "level groups summed afterwards would never reach it; clear it first (leaf.grad = None / zero_grad(set_to_none=True))")
         self.grad_ptr, self._run, self._keep = grad.data_ptr(), run, keep
+        self._summed = set() if run is not None else None
 
     def take(self):
         """(address of the gradient, run, keep) of the backward that just ran, for a caller that records the per-group work itself (graph capture)."""
@@ -283,6 +289,13 @@ class TableGradChunks:
         run = (state or self.take())[1]
         if run is not None:
             run(*self.levels[i])
+            if state is None and self._summed is not None:
+                self._summed.add(i)
+
+    def complete(self):
+        """True once every level group of the last backward has been summed (eager use; a caller that replays recorded sums keeps its own
+        books): an optimizer step before that would read rows the backward left uninitialised."""
+        return self._summed is None or len(self._summed) == len(self.levels)
 
     def view(self, i, grad, state=None):
         """Rows of level group i of `grad` -- the tensor autograd put into `.grad`, which must be the one the backward produced."""

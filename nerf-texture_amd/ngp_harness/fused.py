@@ -156,7 +156,9 @@ class _ngp_field(Function):
             DEBUG_TAP(grad_x=grad_x, x=x, grad_sigma=grad_sigma, grad_rgbs=grad_rgbs, grad_cin=grad_cin, meta=(S, H, gridtype, align, affine))
         grad_table = torch.empty_like(table_h)
         dummy = torch.empty(1, **half)
-        chunker = ctx.grad_chunker if sink is None else None
+        # (the chunked form hands autograd a gradient that is FINISHED LATER, in place: only valid when `.grad` becomes this very tensor --
+        # an fp16 leaf, so that `.to(t_dtype)` below is the identity, and no earlier `.grad` to accumulate into: TableGradChunks.begin checks)
+        chunker = ctx.grad_chunker if (sink is None and t_dtype == torch.float16) else None
         if chunker is not None:
             # data parallelism: only BIN the contributions here; the caller sums the level groups one by one (chunker.sum_chunk) and starts each
             # group's all-reduce while the next one is being summed.  grad_table is complete once every group has been summed.

@@ -1,7 +1,7 @@
 """ONE high-priority side stream per device for the whole process.
 
 The march of the next step(s) runs on a second, high-priority HIP stream beside the current step (bench.py, ngp_harness/accelerate.py).
-Measured on MI355X / ROCm 7.2 (round 4, tools/fresh_probe6.py): the runtime multiplexes HIP streams onto a handful of hardware queues
+Measured on MI355X / ROCm 7.2 (round 4, tools/side_stream_queue_probe.py): the runtime multiplexes HIP streams onto a handful of hardware queues
 (GPU_MAX_HW_QUEUES, 4 by default), and which queue a NEW stream lands on depends on how many streams the process has created before --
 graph captures create some too.  The first high-priority stream of a process got a queue of its own; one created later, after a training
 loop with its captures had run, shared a queue with other work, and the same replayed step took 1.11 ms instead of 0.57 ms (kernel
