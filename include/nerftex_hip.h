@@ -307,6 +307,17 @@ int nerftex_grid_encode_backward_amp(const void* grad, const float* inputs, cons
                                      int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                      int dtype, int layout, float in_add, float in_mul, float* found_inf, void* stream);
 
+/* Extension (round 5): the fused ngp field with its two networks in bf16 (BASELINE configs[2] names bf16; the reference's ffmlp is fp16-only,
+ * ffmlp/src/utils.h:23).  Same arguments as nerftex_field_forward / nerftex_field_backward_amp with these types: feats_lbc stays fp16 (the hash
+ * table is fp16 under any autocast) and is narrowed to bf16 on load; weights, x_rows, h, cin, hc, grad_cin and the two weight gradients are
+ * bf16; grad_x -- the hash-grid backward's input -- is fp16 (each element rounded to bf16 first: what autograd's cast back through the
+ * unfused chain's `.to(bfloat16)` produces); sigma, rgbs, grad_sigma, grad_rgbs fp32.  found_inf may be NULL.                            */
+int nerftex_field_forward_bf16(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                               uint32_t B, float* sigma, float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream);
+int nerftex_field_backward_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream);
+
 /* Extension (round 4): the table gradient in PARTS, for a data-parallel caller that exchanges it level group by level group: the
  * all-reduce of the rows of levels [lo, hi) can start as soon as those levels are summed, while the later levels are still being summed
  * (replaces the single gradient exchange after the backward pass; the reference only has the dormant DDP wrap, nerf/utils.py:439-441).
@@ -582,6 +593,19 @@ int nerftex_adam_half_step_amp(int count, float* const* params, float* const* ex
                                double lr, double beta1, double beta2, double eps, float* scale, int32_t* growth_tracker,
                                float* found_inf, uint32_t* ticket, double growth_factor, double backoff_factor,
                                int growth_interval, void* stream);
+/* Extension (round 5): the three calls above with a 16-bit type PER TENSOR -- bit t of bf16_mask set: tensor t's gradient and its narrowed
+ * copy are bf16 (round to nearest even, as tensor.to(torch.bfloat16)), clear: fp16.  A bf16 field (BASELINE configs[2]) keeps its hash table
+ * and the table's gradient in fp16 (gridencoder/grid.py:38-41 casts the table to half under ANY autocast) and its MLP weights in bf16: one
+ * launch updates all of them.  bf16_mask 0 == the _half forms.                                                                        */
+int nerftex_adam_mixed_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                            const void* const* grads16, void* const* params16, const uint64_t* n, uint32_t bf16_mask, const float* step,
+                            float step_offset, double lr, double beta1, double beta2, double eps, const float* grad_scale,
+                            const float* found_inf, void* stream);
+int nerftex_adam_mixed_step_amp(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                const void* const* grads16, void* const* params16, const uint64_t* n, uint32_t bf16_mask, float* step,
+                                double lr, double beta1, double beta2, double eps, float* scale, int32_t* growth_tracker, float* found_inf,
+                                uint32_t* ticket, double growth_factor, double backoff_factor, int growth_interval, void* stream);
+int nerftex_amp_check_mixed(int count, const void* const* grads16, const uint64_t* n, uint32_t bf16_mask, float* found_inf, void* stream);
 int nerftex_amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, double growth_factor,
                        double backoff_factor, int growth_interval, void* stream);
 

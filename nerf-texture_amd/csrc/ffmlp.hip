@@ -36,6 +36,7 @@ namespace nerftex {
 namespace ffmlp_f16 {
 namespace {
 using elem_t = half_t;
+constexpr bool kElemIsHalf = true;
 using elem4_t = half4_t;
 using elem8_t = half8_t;
 __device__ __forceinline__ float4_t mfma16(const elem8_t& a, const elem8_t& b, const float4_t& c) {
@@ -48,6 +49,7 @@ __device__ __forceinline__ float4_t mfma16(const elem8_t& a, const elem8_t& b, c
 namespace ffmlp_bf16 {
 namespace {
 using elem_t = __bf16;
+constexpr bool kElemIsHalf = false;
 typedef __bf16 elem4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 elem8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float4_t mfma16(const elem8_t& a, const elem8_t& b, const float4_t& c) {
@@ -98,6 +100,16 @@ extern "C" int nerftex_field_backward_amp(const float* grad_sigma, const float* 
                                           void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream) {
     return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                            grad_sigma_weights, grad_color_weights, found_inf, stream);
+}
+extern "C" int nerftex_field_forward_bf16(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
+                                          float* sigma, float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream) {
+    return ffmlp_bf16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, x_rows, h, cin, hc, nullptr, 0, stream);
+}
+extern "C" int nerftex_field_backward_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                           const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                           void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream) {
+    return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                            grad_sigma_weights, grad_color_weights, found_inf, stream);
 }
 extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
                                           float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {

@@ -132,6 +132,24 @@ struct AdamTensors {
     uint64_t n[kMaxTensors];
     uint32_t block_end[kMaxTensors];  // blocks [block_end[t-1], block_end[t]) work on tensor t
     int count;
+    uint32_t bf16_mask;  // bit t: tensor t's 16-bit gradient and 16-bit copy are bf16 (the MLP weights of a bf16 field), else fp16
+};
+
+// the 16-bit side of one Adam tensor: gradient in, narrowed parameter out
+template <bool BF16> struct Half16;
+template <> struct Half16<false> {
+    using vec8 = half8_t;
+    static __device__ __forceinline__ float widen(const vec8& g, int j) { return (float)g[j]; }
+    static __device__ __forceinline__ void narrow(vec8& h, int j, float p) { h[j] = (half_t)p; }
+    static __device__ __forceinline__ float widen1(const half_t* g, uint64_t i) { return (float)g[i]; }
+    static __device__ __forceinline__ void narrow1(half_t* h, uint64_t i, float p) { h[i] = (half_t)p; }
+};
+template <> struct Half16<true> {
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ float widen(const vec8& g, int j) { return (float)g[j]; }
+    static __device__ __forceinline__ void narrow(vec8& h, int j, float p) { h[j] = (__bf16)p; }  // round to nearest even, as tensor.to(bfloat16)
+    static __device__ __forceinline__ float widen1(const half_t* g, uint64_t i) { return (float)reinterpret_cast<const __bf16*>(g)[i]; }
+    static __device__ __forceinline__ void narrow1(half_t* h, uint64_t i, float p) { reinterpret_cast<__bf16*>(h)[i] = (__bf16)p; }
 };
 
 // amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count
@@ -166,6 +184,51 @@ struct AmpTail {
     int growth_interval;
 };
 
+template <bool BF16>
+__device__ __forceinline__ void adam_tensor(float* __restrict__ param, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, const half_t* __restrict__ grad,
+                                            half_t* __restrict__ param_half, const uint64_t n, const uint32_t block, const uint32_t nblocks, const AdamConsts& k,
+                                            const bool unscale, const double scale, const float step_size, const float bc2_sqrt) {
+    using H = Half16<BF16>;
+    using V8 = typename H::vec8;
+    const uint64_t groups = n / kAdamVec;
+    for (uint64_t i = (uint64_t)block * kAdamThreads + threadIdx.x; i < groups; i += (uint64_t)nblocks * kAdamThreads) {
+        float4 p[2], m[2], v[2];
+        p[0] = reinterpret_cast<const float4*>(param)[2 * i];
+        p[1] = reinterpret_cast<const float4*>(param)[2 * i + 1];
+        m[0] = reinterpret_cast<const float4*>(exp_avg)[2 * i];
+        m[1] = reinterpret_cast<const float4*>(exp_avg)[2 * i + 1];
+        v[0] = reinterpret_cast<const float4*>(exp_avg_sq)[2 * i];
+        v[1] = reinterpret_cast<const float4*>(exp_avg_sq)[2 * i + 1];
+        const V8 g = __builtin_nontemporal_load(reinterpret_cast<const V8*>(grad) + i);
+        float* pf = reinterpret_cast<float*>(p);
+        float* mf = reinterpret_cast<float*>(m);
+        float* vf = reinterpret_cast<float*>(v);
+        V8 h;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            adam_one(pf[j], mf[j], vf[j], H::widen(g, j), k, unscale, scale, step_size, bc2_sqrt);
+            H::narrow(h, j, pf[j]);
+        }
+        reinterpret_cast<float4*>(param)[2 * i] = p[0];
+        reinterpret_cast<float4*>(param)[2 * i + 1] = p[1];
+        reinterpret_cast<float4*>(exp_avg)[2 * i] = m[0];
+        reinterpret_cast<float4*>(exp_avg)[2 * i + 1] = m[1];
+        reinterpret_cast<float4*>(exp_avg_sq)[2 * i] = v[0];
+        reinterpret_cast<float4*>(exp_avg_sq)[2 * i + 1] = v[1];
+        reinterpret_cast<V8*>(param_half)[i] = h;
+    }
+    // ragged end (n not a multiple of 8): the tensor's first block, first lanes
+    const uint64_t rest = groups * kAdamVec + threadIdx.x;
+    if (block == 0 && rest < n) {
+        float p = param[rest], m = exp_avg[rest], v = exp_avg_sq[rest];
+        adam_one(p, m, v, H::widen1(grad, rest), k, unscale, scale, step_size, bc2_sqrt);
+        param[rest] = p;
+        exp_avg[rest] = m;
+        exp_avg_sq[rest] = v;
+        H::narrow1(param_half, rest, p);
+    }
+}
+
 // up to 8 tensors per launch (the table and the MLP weight vectors): a block finds its tensor, then grid-strides inside it
 __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTensors tens, const float* step, const float step_offset,
                                                                  const AdamConsts k, const float* grad_scale, const float* found_inf,
@@ -190,43 +253,8 @@ __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTenso
     const bool unscale = grad_scale != nullptr;
     const double scale = unscale ? (double)*grad_scale : 1.0;
 
-    const uint64_t groups = n / kAdamVec;
-    for (uint64_t i = (uint64_t)block * kAdamThreads + threadIdx.x; i < groups; i += (uint64_t)nblocks * kAdamThreads) {
-        float4 p[2], m[2], v[2];
-        p[0] = reinterpret_cast<const float4*>(param)[2 * i];
-        p[1] = reinterpret_cast<const float4*>(param)[2 * i + 1];
-        m[0] = reinterpret_cast<const float4*>(exp_avg)[2 * i];
-        m[1] = reinterpret_cast<const float4*>(exp_avg)[2 * i + 1];
-        v[0] = reinterpret_cast<const float4*>(exp_avg_sq)[2 * i];
-        v[1] = reinterpret_cast<const float4*>(exp_avg_sq)[2 * i + 1];
-        const half8_t g = __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(grad) + i);
-        float* pf = reinterpret_cast<float*>(p);
-        float* mf = reinterpret_cast<float*>(m);
-        float* vf = reinterpret_cast<float*>(v);
-        half8_t h;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            adam_one(pf[j], mf[j], vf[j], (float)g[j], k, unscale, scale, step_size, bc2_sqrt);
-            h[j] = (half_t)pf[j];
-        }
-        reinterpret_cast<float4*>(param)[2 * i] = p[0];
-        reinterpret_cast<float4*>(param)[2 * i + 1] = p[1];
-        reinterpret_cast<float4*>(exp_avg)[2 * i] = m[0];
-        reinterpret_cast<float4*>(exp_avg)[2 * i + 1] = m[1];
-        reinterpret_cast<float4*>(exp_avg_sq)[2 * i] = v[0];
-        reinterpret_cast<float4*>(exp_avg_sq)[2 * i + 1] = v[1];
-        reinterpret_cast<half8_t*>(param_half)[i] = h;
-    }
-    // ragged end (n not a multiple of 8): the tensor's first block, first lanes
-    const uint64_t rest = groups * kAdamVec + threadIdx.x;
-    if (block == 0 && rest < n) {
-        float p = param[rest], m = exp_avg[rest], v = exp_avg_sq[rest];
-        adam_one(p, m, v, (float)grad[rest], k, unscale, scale, step_size, bc2_sqrt);
-        param[rest] = p;
-        exp_avg[rest] = m;
-        exp_avg_sq[rest] = v;
-        param_half[rest] = (half_t)p;
-    }
+    if ((tens.bf16_mask >> t) & 1u) adam_tensor<true>(param, exp_avg, exp_avg_sq, grad, param_half, n, block, nblocks, k, unscale, scale, step_size, bc2_sqrt);
+    else adam_tensor<false>(param, exp_avg, exp_avg_sq, grad, param_half, n, block, nblocks, k, unscale, scale, step_size, bc2_sqrt);
     }
     if (tail.scale != nullptr) {
         __syncthreads();
@@ -248,9 +276,10 @@ struct CheckTensors {
     uint64_t n[kMaxTensors];
     uint32_t block_end[kMaxTensors];
     int count;
+    uint32_t bf16_mask;  // bit t: tensor t is bf16 (exponent field 0x7f80), else fp16 (0x7c00)
 };
 
-// *found_inf = 1 if any fp16 gradient is inf / nan (exponent field all ones); never cleared here
+// *found_inf = 1 if any 16-bit gradient is inf / nan (exponent field all ones); never cleared here
 __global__ __launch_bounds__(256) void amp_check_half_kernel(const CheckTensors tens, float* __restrict__ found_inf) {
     int t = 0;
     while (t + 1 < tens.count && blockIdx.x >= tens.block_end[t]) t++;
@@ -259,16 +288,17 @@ __global__ __launch_bounds__(256) void amp_check_half_kernel(const CheckTensors 
     const uint64_t n = tens.n[t];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(tens.grad[t]);
     const uint64_t quads = n / 8;  // 16 bytes = 8 halves
+    const uint32_t em = ((tens.bf16_mask >> t) & 1u) ? 0x7f80u : 0x7c00u, em_hi = em << 16;
     bool bad = false;
     for (uint64_t i = (uint64_t)block * 256 + threadIdx.x; i < quads; i += (uint64_t)nblocks * 256) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w) + i);
         const uint32_t x[4] = {q[0], q[1], q[2], q[3]};
 #pragma unroll
-        for (int j = 0; j < 4; j++) bad |= ((x[j] & 0x7c00u) == 0x7c00u) | ((x[j] & 0x7c000000u) == 0x7c000000u);
+        for (int j = 0; j < 4; j++) bad |= ((x[j] & em) == em) | ((x[j] & em_hi) == em_hi);
     }
     const uint64_t tail = quads * 8 + threadIdx.x;
-    if (block == 0 && tail < n) bad |= (reinterpret_cast<const uint16_t*>(w)[tail] & 0x7c00u) == 0x7c00u;
+    if (block == 0 && tail < n) bad |= (reinterpret_cast<const uint16_t*>(w)[tail] & em) == em;
     if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
 }
 
@@ -324,7 +354,7 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) !=
 namespace {
 int adam_half_launch(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, const void* const* grads_half,
                      void* const* params_half, const uint64_t* n, const float* step, float step_offset, double lr, double beta1, double beta2,
-                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream);
+                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream, uint32_t bf16_mask = 0);
 }  // namespace
 
 extern "C" int nerftex_adam_half_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
@@ -350,10 +380,33 @@ extern "C" int nerftex_adam_half_step_amp(int count, float* const* params, float
                             tail, stream);
 }
 
+// the two calls above with a 16-bit type PER TENSOR (bit t of bf16_mask: tensor t's gradient and narrowed copy are bf16): a bf16 field keeps
+// its hash table -- and the table's gradient -- in fp16 (gridencoder/grid.py:38-41) and its MLP weights in bf16, all in ONE launch
+extern "C" int nerftex_adam_mixed_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                       const void* const* grads16, void* const* params16, const uint64_t* n, uint32_t bf16_mask, const float* step,
+                                       float step_offset, double lr, double beta1, double beta2, double eps, const float* grad_scale,
+                                       const float* found_inf, void* stream) {
+    return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads16, params16, n, step, step_offset, lr, beta1, beta2, eps, grad_scale, found_inf,
+                            AmpTail{}, stream, bf16_mask);
+}
+extern "C" int nerftex_adam_mixed_step_amp(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                           const void* const* grads16, void* const* params16, const uint64_t* n, uint32_t bf16_mask, float* step,
+                                           double lr, double beta1, double beta2, double eps, float* scale, int32_t* growth_tracker, float* found_inf,
+                                           uint32_t* ticket, double growth_factor, double backoff_factor, int growth_interval, void* stream) {
+    if (!scale || !growth_tracker || !found_inf || !step || !ticket) {
+        clear_error();
+        set_error("adam_mixed_step_amp: scale, growth_tracker, found_inf, step and ticket must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval};
+    return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads16, params16, n, step, 1.0f, lr, beta1, beta2, eps, scale, found_inf, tail,
+                            stream, bf16_mask);
+}
+
 namespace {
 int adam_half_launch(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, const void* const* grads_half,
                      void* const* params_half, const uint64_t* n, const float* step, float step_offset, double lr, double beta1, double beta2,
-                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream) {
+                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream, uint32_t bf16_mask) {
     clear_error();
     if (count < 0 || count > kMaxTensors) {
         set_error("adam_half_step: at most 8 tensors per call");
@@ -374,6 +427,7 @@ int adam_half_launch(int count, float* const* params, float* const* exp_avgs, fl
         tens.grad[k] = static_cast<const half_t*>(grads_half[t]);
         tens.param_half[k] = static_cast<half_t*>(params_half[t]);
         tens.n[k] = n[t];
+        tens.bf16_mask |= ((bf16_mask >> t) & 1u) << k;
         blocks += blocks_for(n[t] / kAdamVec, kAdamThreads);
         tens.block_end[k] = blocks;
     }
@@ -403,6 +457,10 @@ extern "C" int nerftex_table_adam_step(float* param, float* exp_avg, float* exp_
 }
 
 extern "C" int nerftex_amp_check_half(int count, const void* const* grads_half, const uint64_t* n, float* found_inf, void* stream) {
+    return nerftex_amp_check_mixed(count, grads_half, n, 0u, found_inf, stream);
+}
+
+extern "C" int nerftex_amp_check_mixed(int count, const void* const* grads_half, const uint64_t* n, uint32_t bf16_mask, float* found_inf, void* stream) {
     clear_error();
     if (count < 0 || count > kMaxTensors) {
         set_error("amp_check_half: at most 8 tensors per call");
@@ -419,6 +477,7 @@ extern "C" int nerftex_amp_check_half(int count, const void* const* grads_half, 
         const int k = tens.count++;
         tens.grad[k] = static_cast<const half_t*>(grads_half[t]);
         tens.n[k] = n[t];
+        tens.bf16_mask |= ((bf16_mask >> t) & 1u) << k;
         blocks += blocks_for(n[t] / 8, 256 * 4);
         tens.block_end[k] = blocks;
     }
