@@ -197,7 +197,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     from ngp_harness.model import NGPField, Renderer
 
     torch.manual_seed(0)
-    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=not (args.no_fused_glue or no_ext or dtype == "bf16"),
+    # (bf16: NGPField has no bf16 glue kernels -- fused_glue then selects the one-kernel bf16 field, nerftex_field_*_bf16, round 5)
+    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=not (args.no_fused_glue or no_ext),
                      mlp_dtype=torch.bfloat16 if dtype == "bf16" else torch.float16).to(dev)
     torch.manual_seed(1)  # FFMLP.reset_parameters reseeds with 42; give the table its own stream
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
@@ -242,14 +243,15 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
             group //= 2
     use_amp = dtype in ("fp16", "bf16")
     amp_dtype = torch.bfloat16 if dtype == "bf16" else torch.float16
-    fused_opt = dtype == "fp16" and mlp == "ffmlp" and not (args.no_fused_opt or no_ext)
+    fused_opt = dtype in ("fp16", "bf16") and mlp == "ffmlp" and not (args.no_fused_opt or no_ext)
     fused_tail = not (args.no_fused_tail or no_ext)
     fused_amp = fused_opt and not args.no_fused_amp
     dp.broadcast([p.data for p in field.parameters()])
     if fused_opt:  # same Adam; every parameter's fp16 copy is the autograd leaf, its fp16 gradient consumed as produced (ngp_harness/optim.py)
         from ngp_harness.optim import FusedAmp, HalfLeafAdam
 
-        opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights"), (field.color_net, "weights")], lr=1e-2,
+        mlp_dt = torch.bfloat16 if dtype == "bf16" else torch.float16  # (the table's copy and gradient are fp16 either way)
+        opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights", mlp_dt), (field.color_net, "weights", mlp_dt)], lr=1e-2,
                            betas=(0.9, 0.99), eps=1e-15)
         trainable = opt.trainable()
     else:
@@ -793,7 +795,7 @@ def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_
              renderer.local_step, renderer.step_counter.clone())
     out = {}
     try:
-        for name, it in (("full", 0), ("partial", 16)):
+        for name, it, strat in (("full", 0, True), ("partial", 16, True), ("partial_iid_draws", 16, False)):
             ms = []
             for rep in range(reps + 1):
                 renderer.iter_density = it
@@ -802,7 +804,7 @@ def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 with torch.autocast("cuda", dtype=amp_dtype, enabled=use_amp):
-                    renderer.update_extra_state_device(seed=rep)
+                    renderer.update_extra_state_device(seed=rep, stratified=strat)
                 e1.record()
                 torch.cuda.synchronize()
                 if rep:  # (first repetition: allocator / workspace growth)
@@ -819,11 +821,13 @@ def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_
     out["ms_per_step_including_update"] = ms_per_step + out["ms_partial"] / 16
     out["value_including_occupancy_update_per_gpu"] = samples_per_step / (out["ms_per_step_including_update"] * 1e-3)
     out["note"] = ("update_extra_state every 16 steps (nerf/utils.py:1011), excluded from `value` as SURVEY 8(d) defines the metric; steady state = the partial "
-                   "update; device time of Renderer.update_extra_state_device (occupancy kernels + hash-grid gather + sigma net over the sampled cells)")
+                   "update; device time of Renderer.update_extra_state_device (occupancy kernels + hash-grid gather + sigma net over the sampled cells).  "
+                   "ms_partial: the stratified draw (round 5: one cell per run of 4 consecutive Morton indices + one entry per slice of the occupied list -- rows in "
+                   "Morton order, the gather sees the full sweep's locality); ms_partial_iid_draws: the reference's N iid draws with replacement (renderer.py:611-621)")
     return out
 
 
-def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1):
+def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"):
     """A training loop that feeds FRESH rays every step through ngp_harness.accelerate (the one call a trainer adds to the drop-in
     packages: graph replay + fused field + HalfLeafAdam / FusedAmp, or torch's capturable Adam + GradScaler for nn.Linear MLPs).
     group = k > 1: `step_group` -- the loop has the batches of k consecutive steps at a time ([k, N, 3] tensors, copied into the graphs'
@@ -834,7 +838,8 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1):
     from ngp_harness.model import NGPField, Renderer
 
     torch.manual_seed(0)
-    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=True).to(dev)
+    amp_dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    field = NGPField(bound=args.bound, mlp=mlp, fused_glue=True, mlp_dtype=amp_dt).to(dev)
     torch.manual_seed(1)
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
     renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
@@ -848,7 +853,7 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1):
     field.train()
     # (march_across_ring_end: the loop makes no occupancy update inside the timed region -- the metric excludes it -- so the next ring's first
     # marches may start behind the ring's read-back, as they do in the baked-pool loop)
-    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1)
+    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1, amp_dtype=amp_dt)
     if group > 1:
         assert n_pool % group == 0 and steps % group == 0
         po = [torch.stack([pool[c * group + i][0] for i in range(group)]).contiguous() for c in range(n_pool // group)]
@@ -1070,7 +1075,8 @@ def main():
                 # the step the UNMODIFIED reference callers would run: drop-in packages only, eager launches, torch.optim.Adam + GradScaler
                 ("configs[2] through the drop-in API only (reference callers unchanged: no graph, no field-glue / render-tail kernels, torch Adam + GradScaler)",
                  "ffmlp", 8192, "fp16", True, False),
-                ("configs[2] with bf16 FFMLPs (bf16 autocast, torch fused Adam + GradScaler: the table gradient stays fp16), one replayed HIP graph per step", "ffmlp", 8192, "bf16", False, True)]
+                ("configs[2] with bf16 networks (BASELINE's dtype for this config): bf16 autocast, the one-kernel bf16 field over the fp16 table, HalfLeafAdam with bf16 MLP leaves + FusedAmp "
+                 "(the loss scaler stays: the table gradient is fp16), one replayed HIP graph per step, baked ray pool", "ffmlp", 8192, "bf16", False, True)]
         for label, mlp_k, rays_k, dt_k, dropin, graph_k in runs:
             r2, _, _ = measure_training(args, mlp_k, rays_k, 16, 16, dev, rank, world, sc, grid, bits, False, graph=graph_k, dtype=dt_k, dropin_only=dropin)
             other.append({"workload": label if "configs[2]" in label and len(label) > 12 else WORKLOADS[mlp_k], "rays_per_batch": rays_k, "dtype": dt_k,
@@ -1087,6 +1093,14 @@ def main():
                               "loss_after_run": r3["loss"]})
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
                 print(f"[bench] accelerate() measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
+        try:  # the headline's loop (fresh rays, 4 steps per call) with bf16 networks
+            r4 = measure_accelerated(args, "ffmlp", 8192, 64, dev, grid, group=4, dtype="bf16")
+            other.append({"workload": "configs[2] in bf16 through ngp_harness.accelerate(renderer, steps_per_call=4, amp_dtype=torch.bfloat16).step_group: the headline's loop "
+                                      "(fresh rays every call) with bf16 networks over the fp16 table", "rays_per_batch": 8192, "dtype": "bf16", "value": r4["value"],
+                          "unit": "ray-samples/s", "ms_per_step": r4["ms_per_step"], "steps": 64, "launch": "one replayed HIP graph per 4 steps + their marches ahead on the second stream",
+                          "loss_after_run": r4["loss"]})
+        except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
+            print(f"[bench] bf16 accelerate() measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
         try:
             other.append(measure_curved(dev))
         except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void occ_write_kernel(const float* __restri
 __global__ __launch_bounds__(kBlock) void sample_partial_kernel(uint32_t cascade, uint32_t H, uint32_t N, CascadeConsts cc, const int32_t* __restrict__ list,
                                                                 const uint32_t* __restrict__ n_occ, const int32_t* __restrict__ rand_coords,
                                                                 const int32_t* __restrict__ rand_pick, const float* __restrict__ noise, uint64_t seed,
-                                                                int32_t* __restrict__ indices, float* __restrict__ xyzs) {
+                                                                int32_t* __restrict__ indices, float* __restrict__ xyzs, const uint32_t stratified) {
     const uint32_t H3 = H * H * H;
     const uint32_t row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= cascade * 2 * N) return;
@@ -162,7 +162,13 @@ __global__ __launch_bounds__(kBlock) void sample_partial_kernel(uint32_t cascade
     if (j < N) {
         const size_t r = ((size_t)cas * N + j) * 3;
         if (rand_coords) { cx = (uint32_t)rand_coords[r]; cy = (uint32_t)rand_coords[r + 1]; cz = (uint32_t)rand_coords[r + 2]; }
-        else {
+        else if (stratified) {
+            // row j draws ONE cell of the j-th run of H^3 / N consecutive Morton indices: the rows come out in ascending Morton order -- the
+            // density query behind this (a hash-grid gather over 2 N positions) sees the locality of the full sweep instead of none
+            const uint32_t per = H3 / N;
+            const uint32_t m = j * per + min(per - 1, (uint32_t)(uniform01(seed ^ 0xA5A5u, (uint64_t)row * 3 + 0) * (float)per));
+            cx = compact_bits(m); cy = compact_bits(m >> 1); cz = compact_bits(m >> 2);
+        } else {
             cx = min(H - 1, (uint32_t)(uniform01(seed ^ 0xA5A5u, (uint64_t)row * 3 + 0) * (float)H));
             cy = min(H - 1, (uint32_t)(uniform01(seed ^ 0xA5A5u, (uint64_t)row * 3 + 1) * (float)H));
             cz = min(H - 1, (uint32_t)(uniform01(seed ^ 0xA5A5u, (uint64_t)row * 3 + 2) * (float)H));
@@ -175,7 +181,10 @@ __global__ __launch_bounds__(kBlock) void sample_partial_kernel(uint32_t cascade
             xyzs[(size_t)row * 3] = xyzs[(size_t)row * 3 + 1] = xyzs[(size_t)row * 3 + 2] = 0.0f;
             return;
         }
-        const uint32_t k = rand_pick ? (uint32_t)rand_pick[(size_t)cas * N + (j - N)] : min(n - 1, (uint32_t)(uniform01(seed ^ 0x5A5Au, row) * (float)n));
+        // stratified: row j' of the N draws from the j'-th of N equal slices of the occupied list (ascending cell order): ascending rows again
+        const uint32_t k = rand_pick ? (uint32_t)rand_pick[(size_t)cas * N + (j - N)]
+                           : stratified ? min(n - 1, (uint32_t)(((uint64_t)(j - N) * n + (uint64_t)(uniform01(seed ^ 0x5A5Au, row) * (float)n)) / N))
+                                        : min(n - 1, (uint32_t)(uniform01(seed ^ 0x5A5Au, row) * (float)n));
         index = list[(size_t)cas * H3 + k];
         cx = compact_bits((uint32_t)index); cy = compact_bits((uint32_t)index >> 1); cz = compact_bits((uint32_t)index >> 2);
     }
@@ -301,7 +310,17 @@ extern "C" int nerftex_occupancy_sample_full(float* xyzs, uint32_t cascade, uint
 extern "C" int nerftex_occupancy_sample_partial(const float* density_grid, uint32_t cascade, uint32_t H, float bound, uint32_t N, const int32_t* rand_coords,
                                                 const int32_t* rand_pick, const float* noise, uint64_t seed, int32_t* indices, float* xyzs,
                                                 uint32_t* n_occupied, void* stream) {
+    return nerftex_occupancy_sample_partial_ordered(density_grid, cascade, H, bound, N, rand_coords, rand_pick, noise, seed, indices, xyzs, n_occupied, 0, stream);
+}
+
+extern "C" int nerftex_occupancy_sample_partial_ordered(const float* density_grid, uint32_t cascade, uint32_t H, float bound, uint32_t N,
+                                                        const int32_t* rand_coords, const int32_t* rand_pick, const float* noise, uint64_t seed,
+                                                        int32_t* indices, float* xyzs, uint32_t* n_occupied, int stratified, void* stream) {
     clear_error();
+    if (stratified && N != 0 && (H * H * H) % N != 0) {
+        set_error("occupancy_sample_partial_ordered: the stratified draw needs N to divide H^3");
+        return NERFTEX_ERR_INVALID;
+    }
     int rc = check_shape(cascade, H);
     if (rc != NERFTEX_OK) return rc;
     if (N == 0) return NERFTEX_OK;
@@ -324,7 +343,7 @@ extern "C" int nerftex_occupancy_sample_partial(const float* density_grid, uint3
     {
         KernelTimer kt("occupancy_sample_partial_kernel", st);
         hipLaunchKernelGGL(sample_partial_kernel, dim3(div_up(cascade * 2 * N, kBlock)), dim3(kBlock), 0, st, cascade, H, N, cascade_consts(cascade, H, bound), list,
-                           n_occ, rand_coords, rand_pick, noise, seed, indices, xyzs);
+                           n_occ, rand_coords, rand_pick, noise, seed, indices, xyzs, stratified ? 1u : 0u);
     }
     return check_launch("occupancy_sample_partial");
 }

@@ -45,6 +45,11 @@ _SIGNATURES = {
     "nerftex_amp_check_half": [_i, _vp, _vp, _vp, _vp],
     "nerftex_adam_half_step_amp": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
     "nerftex_amp_update": [_vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
+    "nerftex_adam_mixed_step": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _f32, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
+    "nerftex_adam_mixed_step_amp": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
+    "nerftex_amp_check_mixed": [_i, _vp, _vp, _u32, _vp, _vp],
+    "nerftex_field_forward_bf16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_backward_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_table_adam_step": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "nerftex_tune_set": [C.c_char_p, C.c_long],
     "nerftex_profile_enable": [_i],
@@ -76,6 +81,7 @@ _SIGNATURES = {
     "nerftex_compact_rays_dev": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_occupancy_sample_full": [_vp, _u32, _u32, _f32, _vp, _u64, _vp],
     "nerftex_occupancy_sample_partial": [_vp, _u32, _u32, _f32, _u32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp],
+    "nerftex_occupancy_sample_partial_ordered": [_vp, _u32, _u32, _f32, _u32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _vp],
     "nerftex_occupancy_update": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _i, _f32, _vp, _vp, _vp],
     "nerftex_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "nerftex_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],

@@ -52,13 +52,17 @@ class AcceleratedTrainer:
         self.dt_gamma, self.bg_color, self.perturb, self.max_steps = dt_gamma, bg_color, perturb, max_steps
         self.amp_dtype = amp_dtype
         self.use_graph = bool(graph)
-        self.fused = field.mlp == "ffmlp" and field.fused_glue and amp_dtype == torch.float16
+        bf16 = amp_dtype == torch.bfloat16 and getattr(field, "fused_field_bf16", False)  # bf16 networks over the fp16 table (round 5)
+        self.fused = field.mlp == "ffmlp" and ((field.fused_glue and amp_dtype == torch.float16) or bf16)
         if self.fused:
             from .optim import FusedAmp, HalfLeafAdam
 
-            self.opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights"), (field.color_net, "weights")], lr=lr, betas=betas, eps=eps)
+            mlp_dt = torch.bfloat16 if bf16 else torch.float16
+            self.opt = HalfLeafAdam([(field.encoder, "embeddings"), (field.sigma_net, "weights", mlp_dt), (field.color_net, "weights", mlp_dt)], lr=lr,
+                                    betas=betas, eps=eps)
+            # bf16 keeps the loss scaler: the table gradient is fp16 and unscaled gradients of ~1e-6 sit in its subnormals (profiles/r04_precision.json)
             self.amp, self.scaler = FusedAmp(self.opt), None
-            if field.fused_field:
+            if field.fused_field or bf16:
                 self.amp.attach(field.encoder)  # found_inf raised by the kernels that write the gradients: no separate scan launch
         else:
             self.opt = torch.optim.Adam(field.get_params(lr), betas=betas, eps=eps, fused=True, capturable=self.use_graph)

@@ -76,7 +76,7 @@ class _ngp_field(Function):
     tests/test_gpu_field_glue.py)."""
 
     @staticmethod
-    def forward(ctx, x, dirs, table, offsets, ws, wc, enc, training, live=None):
+    def forward(ctx, x, dirs, table, offsets, ws, wc, enc, training, live=None, mlp_dtype=torch.float16):
         import numpy as np
 
         from nerftex_hip import F16, LAYOUT_LBC
@@ -90,8 +90,13 @@ class _ngp_field(Function):
         assert (L, C, D) == (16, 2, 3) and B % 128 == 0
         register_offsets(offsets, L)
         table_h = table if table.dtype == torch.float16 else table.to(torch.float16)
-        ws_h = ws if ws.dtype == torch.float16 else ws.to(torch.float16)
-        wc_h = wc if wc.dtype == torch.float16 else wc.to(torch.float16)
+        # mlp_dtype bf16 (round 5): the two networks, their saved rows and their weight gradients are bf16 (nerftex_field_*_bf16); the table, the
+        # gathered features and dL/dfeatures stay fp16 (the table is fp16 under any autocast, gridencoder/grid.py:38-41)
+        bf16 = mlp_dtype == torch.bfloat16
+        assert mlp_dtype in (torch.float16, torch.bfloat16) and not (bf16 and live is not None)
+        ws_h = ws if ws.dtype == mlp_dtype else ws.to(mlp_dtype)
+        wc_h = wc if wc.dtype == mlp_dtype else wc.to(mlp_dtype)
+        field_forward = lib.nerftex_field_forward_bf16 if bf16 else lib.nerftex_field_forward
         S, H, gridtype, align, bound = float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id), int(bool(enc.align_corners)), enc_bound(enc)
         dev = x.device
         feats = torch.empty(L, B, C, dtype=torch.float16, device=dev)
@@ -111,17 +116,17 @@ class _ngp_field(Function):
         check(lib.nerftex_grid_encode_forward_affine(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, 0, ptr(dummy), gridtype, align, F16,
                                                      LAYOUT_LBC, affine[0], affine[1], stream()))
         if training:
-            x_rows = torch.empty(B, 32, dtype=torch.float16, device=dev)
-            h = torch.empty(B, 16, dtype=torch.float16, device=dev)
-            cin = torch.empty(B, 32, dtype=torch.float16, device=dev)
-            check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), None,
-                                            stream()))
+            x_rows = torch.empty(B, 32, dtype=mlp_dtype, device=dev)
+            h = torch.empty(B, 16, dtype=mlp_dtype, device=dev)
+            cin = torch.empty(B, 32, dtype=mlp_dtype, device=dev)
+            check(field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), None, stream()))
             ctx.save_for_backward(x, table_h, offsets, ws_h, wc_h, x_rows, h, cin, rgbs)
             ctx.meta = (S, H, gridtype, align, affine, table.dtype, ws.dtype, wc.dtype)
+            ctx.mlp_dtype = mlp_dtype
             ctx.amp_sink = getattr(enc, "amp_sink", None)  # optim.FusedAmp.attach: the backward's kernels raise found_inf themselves
             ctx.grad_chunker = getattr(enc, "grad_chunker", None)  # dp.TableGradChunks: the table gradient is finished level group by level group
         else:
-            check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
+            check(field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
         ctx.set_materialize_grads(False)
         return sigma, rgbs
 
@@ -133,13 +138,18 @@ class _ngp_field(Function):
         S, H, gridtype, align, affine, t_dtype, ws_dtype, wc_dtype = ctx.meta
         B, dev = x.shape[0], x.device
         half = dict(dtype=torch.float16, device=dev)
+        mlp_dtype = ctx.mlp_dtype
+        bf16 = mlp_dtype == torch.bfloat16
         grad_sigma = torch.zeros(B, dtype=torch.float32, device=dev) if grad_sigma is None else grad_sigma.contiguous().float()
         grad_rgbs = torch.zeros(B, 3, dtype=torch.float32, device=dev) if grad_rgbs is None else grad_rgbs.contiguous().float()
-        grad_cin, grad_wc = torch.empty(B, 32, **half), torch.empty_like(wc_h)
-        grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)
-        sink = ctx.amp_sink if (FIELD_BACKWARD_FUSED and t_dtype == ws_dtype == wc_dtype == torch.float16) else None
+        grad_cin, grad_wc = torch.empty(B, 32, dtype=mlp_dtype, device=dev), torch.empty_like(wc_h)
+        grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)  # (grad_x feeds the hash-grid backward: the TABLE's type, fp16)
+        sink = ctx.amp_sink if ((FIELD_BACKWARD_FUSED or bf16) and t_dtype == torch.float16 and ws_dtype == wc_dtype == mlp_dtype) else None
         found = ptr(sink.found_inf) if sink is not None else None
-        if sink is not None:  # GradScaler's non-finite scan rides on the stores of the three gradients (no amp_check launch this step)
+        if bf16:  # one entry point, found_inf optional (no split / unfused form of the bf16 field backward exists)
+            check(lib.nerftex_field_backward_bf16(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B,
+                                                  ptr(grad_cin), ptr(grad_x), ptr(grad_ws), ptr(grad_wc), found, stream()))
+        elif sink is not None:  # GradScaler's non-finite scan rides on the stores of the three gradients (no amp_check launch this step)
             check(lib.nerftex_field_backward_amp(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B,
                                                  ptr(grad_cin), ptr(grad_x), ptr(grad_ws), ptr(grad_wc), found, stream()))
         elif FIELD_BACKWARD_FUSED:  # the two glue kernels ride on the MLP backward kernels' load stage, one reduction for both networks
@@ -168,7 +178,7 @@ class _ngp_field(Function):
             if lib.nerftex_grid_encode_backward_phase(*args, 1, 0, L, stream()) == 0:
                 chunker.begin(grad_table, lambda lo, hi: check(lib.nerftex_grid_encode_backward_phase(*args, 2, lo, hi, stream())),
                               keep=(grad_x, x, table_h, offsets, dummy))
-                return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None
+                return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None, None
             chunker.begin(grad_table, None, keep=None)  # (small batch / unknown table: the one-call backward below; the groups are complete already)
         if sink is not None:
             check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H,
@@ -181,7 +191,7 @@ class _ngp_field(Function):
             check(lib.nerftex_grid_encode_backward_affine(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S,
                                                           H, 0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],
                                                           affine[1], stream()))
-        return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None
+        return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None, None
 
 
 _INFER_CACHE = {}
@@ -253,11 +263,12 @@ def enc_bound(enc):
     return getattr(enc, "_field_bound", 1.0)
 
 
-def ngp_field(x, dirs, encoder, sigma_net, color_net, bound, training, live=None):
-    """sigma [B] fp32, rgbs [B,3] fp32 of the --ff field for B % 128 == 0 points, fp16 kernels (call under autocast).
-    live = (int32 device tensor, rows per unit), inference only: just the first live[0][0] * live[1] points are evaluated."""
+def ngp_field(x, dirs, encoder, sigma_net, color_net, bound, training, live=None, mlp_dtype=torch.float16):
+    """sigma [B] fp32, rgbs [B,3] fp32 of the --ff field for B % 128 == 0 points, 16-bit kernels (call under autocast): fp16 networks, or
+    bf16 networks (mlp_dtype=torch.bfloat16, round 5) over the fp16 hash table.
+    live = (int32 device tensor, rows per unit), fp16 inference only: just the first live[0][0] * live[1] points are evaluated."""
     encoder._field_bound = float(bound)
-    return _ngp_field.apply(x, dirs, encoder._table(), encoder.offsets, sigma_net._weights(), color_net._weights(), encoder, bool(training), live)
+    return _ngp_field.apply(x, dirs, encoder._table(), encoder.offsets, sigma_net._weights(), color_net._weights(), encoder, bool(training), live, mlp_dtype)
 
 
 class _render_tail(Function):

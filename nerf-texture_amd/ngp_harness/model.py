@@ -96,6 +96,11 @@ class NGPField(nn.Module):
         self.fused_glue = bool(fused_glue) and mlp == "ffmlp" and geo_feat_dim == 15 and mlp_dtype == torch.float16  # the glue kernels are fp16
         # fused_field (on top of fused_glue): everything behind the hash-grid gather as ONE kernel forward (nerftex_field_forward)
         self.fused_field = self.fused_glue and bool(fused_field) and (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64)
+        # the same one-kernel field with bf16 networks over the fp16 table (round 5; BASELINE configs[2] names bf16): nerftex_field_*_bf16.  There are
+        # no bf16 glue kernels: a bf16 field that cannot take the fused kernel (B % 128 != 0, other shapes) runs the framework-op chain
+        self.fused_field_bf16 = (bool(fused_glue) and bool(fused_field) and mlp == "ffmlp" and geo_feat_dim == 15 and mlp_dtype == torch.bfloat16
+                                 and (num_layers, hidden_dim, num_layers_color, hidden_dim_color) == (2, 64, 3, 64))
+        self.mlp_dtype = mlp_dtype
         self.geo_feat_dim = geo_feat_dim
         self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                                    desired_resolution=2048 * bound, gridtype="hash", align_corners=True)
@@ -141,6 +146,13 @@ class NGPField(nn.Module):
         return sigma, fused.color_out(hc), {}
 
     def forward(self, x, d, **kwargs):
+        if (self.fused_field_bf16 and x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and kwargs.get("live") is None):
+            from . import fused
+
+            sigma, rgbs = fused.ngp_field(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, self.training and torch.is_grad_enabled(),
+                                          mlp_dtype=torch.bfloat16)
+            return sigma, rgbs, {}
         if self.fused_glue and x.shape[0] % 128 == 0 and x.shape[0] > 0 and torch.is_autocast_enabled():
             if self.fused_field and x.dtype == torch.float32 and torch.get_autocast_dtype("cuda") == torch.float16:
                 from . import fused
@@ -303,12 +315,16 @@ class Renderer(nn.Module):
         self.update_mean_count()
 
     @torch.no_grad()
-    def update_extra_state_device(self, decay=0.95, force_full_update=False, force_full_grid=False, seed=None, chunk=1 << 21, noise=None):
+    def update_extra_state_device(self, decay=0.95, force_full_update=False, force_full_grid=False, seed=None, chunk=1 << 21, noise=None, stratified=True):
         """update_extra_state (nerf/renderer.py:566-660) on the library's occupancy kernels (csrc/occupancy.hip): the cell positions come
         out in Morton order (no index tensors, no scatter for a full sweep), the occupied cells are compacted on the device (no
         torch.nonzero), the mean density and the packing threshold never leave it (no .item()): the only host read left is mean_count's.
         seed: the jitter / cell picks are a pure function of (seed, row) -- data-parallel ranks that pass the same seed (default: the call
-        count) keep identical grids without a broadcast.  noise: dict of explicit random numbers (tests)."""
+        count) keep identical grids without a broadcast.  noise: dict of explicit random numbers (tests).
+        stratified (round 5, partial updates without explicit picks): the N uniform draws take one cell out of every run of H^3 / N consecutive Morton
+        indices and the N occupied draws one entry out of every N-th of the occupied list, instead of N iid draws with replacement each
+        (renderer.py:611-621) -- the same probability for every cell, N distinct cells instead of ~0.885 N, and rows in ascending Morton order: the
+        density query's gather gets the full sweep's locality (0.81 -> ~0.6 ms per update).  False = the reference's iid draws."""
         from nerftex_hip import check, lib, ptr, stream
 
         dev, H, cas = self.density_grid.device, self.grid_size, self.cascade
@@ -336,8 +352,9 @@ class Renderer(nn.Module):
             N = H ** 3 // 4
             xyzs = torch.empty(cas * 2 * N, 3, dtype=torch.float32, device=dev)
             indices = torch.empty(cas, 2 * N, dtype=torch.int32, device=dev)
-            check(lib.nerftex_occupancy_sample_partial(ptr(self.density_grid), cas, H, float(self.bound), N, ptr(noise.get("coords")), ptr(noise.get("pick")),
-                                                       ptr(noise.get("jitter")), seed, ptr(indices), ptr(xyzs), None, stream()))
+            check(lib.nerftex_occupancy_sample_partial_ordered(ptr(self.density_grid), cas, H, float(self.bound), N, ptr(noise.get("coords")),
+                                                               ptr(noise.get("pick")), ptr(noise.get("jitter")), seed, ptr(indices), ptr(xyzs), None,
+                                                               int(bool(stratified) and H ** 3 % N == 0), stream()))
             sigmas, rows = density(xyzs), 2 * N
         check(lib.nerftex_occupancy_update(ptr(self.density_grid), ptr(sigmas), ptr(indices), rows, cas, H, float(decay), int(force_full_grid),
                                            float(self.density_thresh), ptr(self._mean_thresh), ptr(self.density_bitfield), stream()))

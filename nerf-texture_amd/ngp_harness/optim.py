@@ -40,14 +40,21 @@ class HalfLeafAdam(torch.optim.Optimizer):
     _needs_device = True  # the update is a HIP kernel; tests of the host-side / wire logic subclass this with a torch stand-in for _launch
 
     def __init__(self, owners, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
-        """owners: [(module, attribute name)] of fp32 parameters, e.g. (encoder, "embeddings"), (sigma_net, "weights"); each module gets
-        a `half_leaf` attribute that GridEncoder._table / FFMLP._weights hand to the kernels under autocast."""
+        """owners: [(module, attribute name)] or [(module, attribute name, 16-bit dtype)] of fp32 parameters, e.g. (encoder, "embeddings"),
+        (sigma_net, "weights", torch.bfloat16); each module gets a `half_leaf` attribute that GridEncoder._table / FFMLP._weights hand to the
+        kernels under autocast.  The 16-bit type is per owner (round 5): a bf16 field keeps its hash table in fp16 -- gridencoder/grid.py:38-41
+        casts it to half under ANY autocast -- and its MLP weights in bf16; one launch updates all of them."""
         assert 1 <= len(owners) <= 8
         self.masters, self.leaves = [], []
-        for mod, name in owners:
+        self.bf16_mask = 0
+        for i, owner in enumerate(owners):
+            mod, name = owner[0], owner[1]
+            dt = owner[2] if len(owner) > 2 else torch.half
+            assert dt in (torch.half, torch.bfloat16)
+            self.bf16_mask |= (1 << i) if dt == torch.bfloat16 else 0
             master = getattr(mod, name)
             assert (master.is_cuda or not self._needs_device) and master.dtype == torch.float32 and master.is_contiguous()
-            leaf = master.detach().to(torch.half).requires_grad_(True)
+            leaf = master.detach().to(dt).requires_grad_(True)
             mod.half_leaf = leaf
             self.masters.append(master)
             self.leaves.append(leaf)
@@ -112,19 +119,20 @@ class HalfLeafAdam(torch.optim.Optimizer):
             return
         grads = [self.leaves[i].grad for i in idx]
         for i, g in zip(idx, grads):
-            assert g.dtype == torch.half and g.is_contiguous() and g.shape == self.masters[i].shape
+            assert g.dtype == self.leaves[i].dtype and g.is_contiguous() and g.shape == self.masters[i].shape
+        mask = sum(1 << k for k, i in enumerate(idx) if (self.bf16_mask >> i) & 1)
         grp = self.param_groups[0]
         n = (ctypes.c_uint64 * max(len(idx), 1))(*[self.masters[i].numel() for i in idx])
         arrays = (_ptr_array([self.masters[i] for i in idx]), _ptr_array([self.exp_avg[i] for i in idx]),
                   _ptr_array([self.exp_avg_sq[i] for i in idx]), _ptr_array(grads), _ptr_array([self.leaves[i] for i in idx]), n)
         hyper = (float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"])
         if amp is None:
-            check(lib.nerftex_adam_half_step(len(idx), *arrays, ptr(self.step_count), float(step_offset), *hyper, ptr(grad_scale), ptr(found_inf),
-                                             stream()))
+            check(lib.nerftex_adam_mixed_step(len(idx), *arrays, mask, ptr(self.step_count), float(step_offset), *hyper, ptr(grad_scale), ptr(found_inf),
+                                              stream()))
         else:
             scale, tracker, found, ticket, growth, backoff, interval = amp
-            check(lib.nerftex_adam_half_step_amp(len(idx), *arrays, ptr(self.step_count), *hyper, ptr(scale), ptr(tracker), ptr(found), ptr(ticket),
-                                                 growth, backoff, interval, stream()))
+            check(lib.nerftex_adam_mixed_step_amp(len(idx), *arrays, mask, ptr(self.step_count), *hyper, ptr(scale), ptr(tracker), ptr(found), ptr(ticket),
+                                                  growth, backoff, interval, stream()))
         for i in idx:
             torch.autograd.graph.increment_version(self.masters[i])
 
@@ -188,7 +196,8 @@ class FusedAmp:
 
     def _check(self, grads):
         n = (ctypes.c_uint64 * len(grads))(*[g.numel() for g in grads])
-        check(lib.nerftex_amp_check_half(len(grads), _ptr_array(grads), n, ptr(self.found_inf), stream()))
+        mask = sum(1 << k for k, g in enumerate(grads) if g.dtype == torch.bfloat16)
+        check(lib.nerftex_amp_check_mixed(len(grads), _ptr_array(grads), n, mask, ptr(self.found_inf), stream()))
 
     @torch.no_grad()
     def step(self):

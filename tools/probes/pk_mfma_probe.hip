@@ -28,13 +28,17 @@ enum Op {
     PK_MUL, PK_MUL_OPSEL, PK_ADD, PK_ADD_NEG, PK_ADD_ONE, PK_FMA, PK_MOV,   // the packed-fp32 family (target feature packed-fp32-ops)
     MUL_F32, FMA_F32, FMA_F64, MUL_F64, ADD_F64,                              // plain fp32 (control) and fp64
     PK_FMA_F16, PK_MUL_F16, PK_ADD_F16, CVT_PK_F16, CVT_PK_BF16, FMA_MIX, FMA_MIXLO, DOT2C,  // 16-bit forms the library contains
-    MUL_LO_U32, MAD_U64, EXP_F32, RCP_F32, DPP_ROW_SHL, CVT_F64_F32, N_OPS
+    MUL_LO_U32, MAD_U64, EXP_F32, RCP_F32, DPP_ROW_SHL, CVT_F64_F32,
+    CHAIN_K3D, CHAIN_K3D_NOPS, CHAIN_K3D_FRESH_REGS, CHAIN_SCALAR, CHAIN_K3D_AFTER_LOAD, CHAIN_PK3_PLAIN, N_OPS   // dependent chains (round 5, second pass)
 };
 static const char* kNames[N_OPS] = {
     "v_pk_mul_f32", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_add_f32", "v_pk_add_f32 neg_lo/neg_hi", "v_pk_add_f32 v, 1.0 op_sel_hi:[1,0] neg", "v_pk_fma_f32",
     "v_pk_mov_b32 op_sel:[1,0]", "v_mul_f32 (control)", "v_fma_f32 (control)", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_pk_fma_f16", "v_pk_mul_f16", "v_pk_add_f16",
-    "v_cvt_pk_f16_f32", "v_cvt_pk_bf16_f32", "v_fma_mix_f32", "v_fma_mixlo_f16", "v_dot2c_f32_f16", "v_mul_lo_u32", "v_mad_u64_u32", "v_exp_f32", "v_rcp_f32",
-    "v_mov_b32_dpp row_shl:1", "v_cvt_f64_f32"};
+    "v_cvt_pk_f16_f32", "v_cvt_pk_bf16_f32", "v_fma_mix_f32", "v_fma_mixlo_f16 (writes 16 of 32 bits: differs alone too, an artefact)", "v_dot2c_f32_f16", "v_mul_lo_u32", "v_mad_u64_u32", "v_exp_f32", "v_rcp_f32",
+    "v_mov_b32_dpp row_shl:1 (inline asm: no hazard nops -- differs alone too, an artefact)", "v_cvt_f64_f32",
+    "CHAIN as compiled into K3d: pk_fma(sgpr,0.5) floor floor pk_add(neg) pk_add(1.0) 3 x pk_mul(op_sel), registers reused", "the same chain, s_nop 1 after every instruction",
+    "the same chain, every result in a fresh register pair", "the same arithmetic with single instructions (control)", "the K3d chain right behind the global load of its input + s_waitcnt",
+    "three dependent plain v_pk_mul_f32"};
 
 template <typename T>
 __device__ __forceinline__ bool bits_differ(const T& x, const T& y) {
@@ -78,15 +82,69 @@ __device__ __forceinline__ bool twice_differs(f2 a, f2 b, f2 c) {
 #undef TWICE2
 }
 
+// ---- dependent chains, as one asm block each, executed twice.  Fixed registers v[40:53] (clobbered); %3 = the per-level scale pair in SGPRs
+#define K3D_BODY(NOP)                                                                                   \
+    "v_pk_fma_f32 v[42:43], v[40:41], %3, 0.5 op_sel_hi:[1,0,0]\n" NOP                                  \
+    "v_floor_f32 v44, v42\n" NOP "v_floor_f32 v45, v43\n" NOP                                           \
+    "v_pk_add_f32 v[46:47], v[42:43], v[44:45] neg_lo:[0,1] neg_hi:[0,1]\n" NOP                         \
+    "v_pk_add_f32 v[42:43], v[46:47], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n" NOP              \
+    "v_pk_mul_f32 v[48:49], v[42:43], v[42:43] op_sel:[0,1] op_sel_hi:[1,0]\n" NOP                      \
+    "v_pk_mul_f32 v[50:51], v[42:43], v[46:47] op_sel:[0,1] op_sel_hi:[1,0]\n" NOP                      \
+    "v_pk_mul_f32 v[46:47], v[46:47], v[46:47] op_sel:[0,1] op_sel_hi:[1,0]\n" NOP
+#define K3D_OUT "s_nop 4\n v_mov_b32 %0, v48\n v_mov_b32 %1, v50\n v_mov_b32 %2, v46\n"
+#define K3D_CLOB "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53"
 template <int OP>
-__global__ __launch_bounds__(1024) void victim(uint32_t iters, uint32_t* __restrict__ stats, uint32_t* __restrict__ first) {
+__device__ __forceinline__ bool chain_differs(f2 a, f2 sc, const float* mem) {
+    float r[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if constexpr (OP == CHAIN_K3D)
+            asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n s_nop 4\n" K3D_BODY("") K3D_OUT
+                         : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(a[0]), "v"(a[1]) : K3D_CLOB);
+        else if constexpr (OP == CHAIN_K3D_NOPS)
+            asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n s_nop 4\n" K3D_BODY("s_nop 1\n") K3D_OUT
+                         : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(a[0]), "v"(a[1]) : K3D_CLOB);
+        else if constexpr (OP == CHAIN_K3D_FRESH_REGS)
+            asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n s_nop 4\n"
+                         "v_pk_fma_f32 v[42:43], v[40:41], %3, 0.5 op_sel_hi:[1,0,0]\n"
+                         "v_floor_f32 v44, v42\n v_floor_f32 v45, v43\n"
+                         "v_pk_add_f32 v[46:47], v[42:43], v[44:45] neg_lo:[0,1] neg_hi:[0,1]\n"
+                         "v_pk_add_f32 v[52:53], v[46:47], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+                         "v_pk_mul_f32 v[48:49], v[52:53], v[52:53] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                         "v_pk_mul_f32 v[50:51], v[52:53], v[46:47] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                         "v_pk_mul_f32 v[40:41], v[46:47], v[46:47] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                         "s_nop 4\n v_mov_b32 %0, v48\n v_mov_b32 %1, v50\n v_mov_b32 %2, v40\n"
+                         : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(a[0]), "v"(a[1]) : K3D_CLOB);
+        else if constexpr (OP == CHAIN_SCALAR)
+            asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n s_nop 4\n"
+                         "v_fma_f32 v42, v40, %3, 0.5\n v_fma_f32 v43, v41, %3, 0.5\n v_floor_f32 v44, v42\n v_floor_f32 v45, v43\n"
+                         "v_sub_f32 v46, v42, v44\n v_sub_f32 v47, v43, v45\n v_sub_f32 v42, 1.0, v46\n v_sub_f32 v43, 1.0, v47\n"
+                         "v_mul_f32 v48, v42, v43\n v_mul_f32 v50, v42, v47\n v_mul_f32 v46, v46, v47\n" K3D_OUT
+                         : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc[0]), "v"(a[0]), "v"(a[1]) : K3D_CLOB);
+        else if constexpr (OP == CHAIN_K3D_AFTER_LOAD)
+            asm volatile("global_load_dwordx2 v[40:41], %4, off\n s_waitcnt vmcnt(0)\n" K3D_BODY("") K3D_OUT
+                         : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(mem), "v"(a[1]) : K3D_CLOB, "memory");
+        else
+            asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n s_nop 4\n"
+                         "v_pk_mul_f32 v[42:43], v[40:41], %3\n v_pk_mul_f32 v[44:45], v[42:43], v[40:41]\n v_pk_mul_f32 v[46:47], v[44:45], v[42:43]\n"
+                         "s_nop 4\n v_mov_b32 %0, v46\n v_mov_b32 %1, v47\n v_mov_b32 %2, v44\n"
+                         : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(a[0]), "v"(a[1]) : K3D_CLOB);
+    }
+    return __float_as_uint(r[0][0]) != __float_as_uint(r[1][0]) || __float_as_uint(r[0][1]) != __float_as_uint(r[1][1]) || __float_as_uint(r[0][2]) != __float_as_uint(r[1][2]);
+}
+
+template <int OP>
+__global__ __launch_bounds__(1024) void victim(uint32_t iters, uint32_t* __restrict__ stats, uint32_t* __restrict__ first, const float* __restrict__ mem, const f2 scale_arg) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     f2 a = {0.37f + (float)(t & 1023) * 1e-3f, 0.81f + (float)(t >> 10) * 1e-4f}, b = {1.25f, 0.61f + (float)(t & 63) * 1e-2f}, c = {1e-3f * (float)(t & 255), -0.5f};
     uint32_t bad = 0, when = 0;
     for (uint32_t i = 0; i < iters; i++) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            if (twice_differs<OP>(a, b, c)) { bad++; when = i * 8 + u; }
+            bool d;
+            if constexpr (OP >= CHAIN_K3D) d = chain_differs<OP>(a, scale_arg, mem + 2 * ((t + i * 8 + u) & 0xfffff));
+            else d = twice_differs<OP>(a, b, c);
+            if (d) { bad++; when = i * 8 + u; }
             a[0] += 0.37f; a[1] = a[1] * 0.999f + 0.013f; b[0] -= 1e-3f; b[1] += 0.61f; c[0] = c[0] * 0.5f + 0.1f; c[1] += 0.01f;
             if (a[0] > 100.0f) { a[0] -= 99.5f; b[1] -= 60.0f; }
         }
@@ -123,6 +181,7 @@ __global__ __launch_bounds__(256) void mfma_busy(float* __restrict__ sink, uint3
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+static float* g_mem = nullptr;  // 2 M floats in [0, 1): the inputs of CHAIN_K3D_AFTER_LOAD
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <int OP>
@@ -137,7 +196,7 @@ static void run_case(double secs, int neighbour, hipStream_t mainst, hipStream_t
                 else if (neighbour == 1) hipLaunchKernelGGL(mfma_busy<1>, dim3(1024), dim3(256), 0, side, sink, 10000u);
                 else hipLaunchKernelGGL(mfma_busy<2>, dim3(1024), dim3(256), 0, side, sink, 20000u);
             }
-            hipLaunchKernelGGL(victim<OP>, dim3(2048), dim3(1024), 0, mainst, 64u, stats, first);
+            hipLaunchKernelGGL(victim<OP>, dim3(2048), dim3(1024), 0, mainst, 64u, stats, first, g_mem, f2{127.0f, 127.0f});
             launches++;
         }
         CK(hipStreamSynchronize(mainst));
@@ -171,11 +230,22 @@ int main(int argc, char** argv) {
     const bool all_nb = argc > 2 && !strcmp(argv[2], "all");
     float* sink; uint32_t *stats, *first;
     CK(hipMalloc(&sink, 64)); CK(hipMalloc(&stats, 8)); CK(hipMalloc(&first, 64));
+    {
+        const size_t n = (size_t)2 << 20;
+        float* h = (float*)malloc(n * 4);
+        srand(3);
+        for (size_t i = 0; i < n; i++) h[i] = (float)rand() / ((float)RAND_MAX + 1.0f);
+        CK(hipMalloc(&g_mem, n * 4));
+        CK(hipMemcpy(g_mem, h, n * 4, hipMemcpyHostToDevice));
+        free(h);
+    }
+    const int first_op = argc > 3 ? atoi(argv[3]) : 0;
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     hipStream_t mainst, side;
     CK(hipStreamCreateWithFlags(&mainst, hipStreamNonBlocking));
     CK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
-    run_all<0>(secs, all_nb, mainst, side, sink, stats, first);
+    if (first_op >= CHAIN_K3D) run_all<CHAIN_K3D>(secs, all_nb, mainst, side, sink, stats, first);  // (the chains only)
+    else run_all<0>(secs, all_nb, mainst, side, sink, stats, first);
     return 0;
 }
