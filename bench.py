@@ -95,8 +95,8 @@ def parse():
                     "rocprofv3 --kernel-trace --stats, ~40 s); roofline.avg_launch_ms then comes from the committed profile or from eager launches")
     ap.add_argument("--no-traffic-profile", action="store_true", help="skip the two PMC child runs (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, ~30 s each) "
                     "that measure roofline.traffic; the committed constant is then used and labelled")
-    ap.add_argument("--pipeline-adam", action="store_true", help="1 GPU, fused path: sum the table gradient level group by level group and run each group's "
-                    "Adam on a second stream while the next group is being summed (A/B; DESIGN.md 4.5)")
+    ap.add_argument("--pipeline-adam", type=int, default=0, help="1 GPU, the fresh-ray headline loop (accelerate): sum the table gradient in this many level groups "
+                    "and run each group's Adam on a second stream while the next group is being summed (A/B, off by default: DESIGN.md 4.5)")
     ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
     ap.add_argument("--allreduce-chunks", type=int, default=1, help="N > 1: exchange the table gradient as this many level-group chunks, each started as soon "
                     "as the backward has produced its rows (default 1 = one all-reduce after the backward)")
@@ -691,7 +691,7 @@ def _replay_child_cmd(args, mlp, rays, dtype, steps):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(args.warmup), "--rays", str(rays), "--mlp", mlp,
            "--dtype", dtype, "--bound", str(args.bound), "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer",
            "--no-kernel-timing", "--baked-pool", "--no-occupancy-timing"]
-    for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb", "pipeline_adam"):
+    for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb"):
         if getattr(args, flag, False):
             cmd.append("--" + flag.replace("_", "-"))
     return cmd
@@ -853,7 +853,8 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     field.train()
     # (march_across_ring_end: the loop makes no occupancy update inside the timed region -- the metric excludes it -- so the next ring's first
     # marches may start behind the ring's read-back, as they do in the baked-pool loop)
-    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1, amp_dtype=amp_dt)
+    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1, amp_dtype=amp_dt,
+                         pipeline_adam=getattr(args, "pipeline_adam", 0))
     if group > 1:
         assert n_pool % group == 0 and steps % group == 0
         po = [torch.stack([pool[c * group + i][0] for i in range(group)]).contiguous() for c in range(n_pool // group)]
@@ -915,8 +916,17 @@ def measure_curved(dev, n_points=262144, reps=10):
     proj = field.projector
     g = torch.Generator().manual_seed(7)
     vt = torch.as_tensor(v, dtype=torch.float32)
+    # round 5: the points in the order a renderer hands them to the field -- 64 consecutive samples along each of n_points / 64 rays that hit the surface
+    # (rounds 3-4 measured points around randomly drawn vertices in RANDOM order: no coherence at all, which no caller of the reference produces --
+    # its MeshFeatureField is fed by march_rays_train; that order is still measured below, as `random_order`: profiles/r05_pmc_curved.txt)
+    n_rays = n_points // 64
+    ro = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1) * 2.5
+    hit = vt[torch.randint(0, vt.shape[0], (n_rays,), generator=g)]
+    rd = torch.nn.functional.normalize(hit - ro, dim=-1)
+    ts = (hit - ro).norm(dim=-1, keepdim=True) + (torch.arange(64).float().reshape(1, 64) - 32) * (0.12 / 64) + torch.rand(n_rays, 1, generator=g) * 1e-3
+    xyz = (ro[:, None] + rd[:, None] * ts[..., None]).reshape(-1, 3).contiguous().to(dev)
     base = vt[torch.randint(0, vt.shape[0], (n_points,), generator=g)]
-    xyz = (base * (1 + (torch.rand(n_points, 1, generator=g) - 0.5) * 0.12) + (torch.rand(n_points, 3, generator=g) - 0.5) * 0.01).to(dev)
+    xyz_random = (base * (1 + (torch.rand(n_points, 1, generator=g) - 0.5) * 0.12) + (torch.rand(n_points, 3, generator=g) - 0.5) * 0.01).to(dev)
     dirs = torch.nn.functional.normalize(torch.randn(n_points, 3, generator=g), dim=-1).to(dev)
 
     def timed(fn):
@@ -953,10 +963,14 @@ def measure_curved(dev, n_points=262144, reps=10):
             torch.autograd.backward([s_, c_], [gs, gc])
         t_field_fb, _ = timed(field_fb)
     total = t_knn + t_proj + t_fb
-    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces): K = 8 neighbour search (uniform vertex grid, "
+    t_knn_r, nb_r = timed(lambda: proj.knn(xyz_random))
+    t_proj_r, _ = timed(lambda: proj.project_fused(xyz_random, neighbours=nb_r))
+    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces), sample points in a renderer's order (64 per ray): K = 8 neighbour search (uniform vertex grid, "
                         "exact) + projector (K-neighbour normal + two BVH traces + select + frame + FreqEncoder, one kernel) + GridEncoder_clustering L=8 hash "
                         "lookup forward and table-gradient backward, 1 GPU" % len(f),
             "points_per_batch": n_points, "inside_height_threshold": float(mask.float().mean()), "value": n_points / (total * 1e-6), "unit": "sample points/s",
+            "random_order": {"neighbour_search_us": t_knn_r, "projector_us": t_proj_r, "value": n_points / ((t_knn_r + t_proj_r + t_fb) * 1e-6),
+                             "note": "the same number of points around randomly drawn vertices in random order (the workload of rounds 3-4): divergence-bound search, profiles/r05_pmc_curved.txt"},
             "neighbour_search_us": t_knn, "projector_us": t_proj, "lookup_forward_us": t_fwd, "lookup_forward_backward_us": t_fb,
             "field_forward_us": t_field_fwd, "field_forward_backward_us": t_field_fb, "field_points_per_s_forward_backward": n_points / (t_field_fb * 1e-6),
             "dtype": "f32 geometry, f16 table and MLPs under autocast"}

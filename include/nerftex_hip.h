@@ -331,6 +331,12 @@ int nerftex_grid_encode_backward_phase(const void* grad, const float* inputs, co
                                        void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                        uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul, int phase,
                                        uint32_t level_lo, uint32_t level_hi, void* stream);
+/* the same with GradScaler's non-finite scan folded into the phase-2 stores (nerftex_grid_encode_backward_amp's contract, level range by level
+ * range: *found_inf is raised when a row of levels [lo, hi) comes out inf / nan).  [extension, round 5]                                  */
+int nerftex_grid_encode_backward_phase_amp(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                           void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                           uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul, int phase,
+                                           uint32_t level_lo, uint32_t level_hi, float* found_inf, void* stream);
 
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).

@@ -1061,6 +1061,21 @@ extern "C" int nerftex_grid_encode_backward_phase(const void* grad, const float*
                                true, in_add, in_mul, stream, nullptr, (uint32_t)phase, level_lo, level_hi);
 }
 
+extern "C" int nerftex_grid_encode_backward_phase_amp(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                                      void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                                      uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul, int phase,
+                                                      uint32_t level_lo, uint32_t level_hi, float* found_inf, void* stream) {
+    (void)embeddings;
+    clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    if (phase < 1 || phase > 3 || level_lo > level_hi || level_hi > L) {
+        set_error("grid_encode_backward_phase: phase must be 1 (bin), 2 (sum levels [lo, hi)) or 3 (both), 0 <= lo <= hi <= L");
+        return NERFTEX_ERR_INVALID;
+    }
+    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype, align_corners, dtype, layout,
+                               true, in_add, in_mul, stream, found_inf, (uint32_t)phase, level_lo, level_hi);
+}
+
 namespace {
 int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,

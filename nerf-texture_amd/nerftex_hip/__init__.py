@@ -31,6 +31,7 @@ _SIGNATURES = {
     "nerftex_grid_encode_backward_amp": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _i, _vp, _vp, _u32, _i, _i, _i, _f32, _f32, _vp, _vp],
     "nerftex_field_density": [_vp, _vp, _u32, _vp, _vp],
     "nerftex_grid_encode_backward_phase": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _i, _u32, _u32, _vp],
+    "nerftex_grid_encode_backward_phase_amp": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _i, _u32, _u32, _vp, _vp],
     "nerftex_release_workspaces": [],
     "nerftex_field_forward_rows": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "nerftex_grid_encode_forward_rows": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _u32, _vp],

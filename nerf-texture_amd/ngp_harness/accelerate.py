@@ -41,7 +41,7 @@ RING = 16
 
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
-                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False):
+                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0):
         from .model import NGPField
 
         field = renderer.field
@@ -67,6 +67,19 @@ class AcceleratedTrainer:
         else:
             self.opt = torch.optim.Adam(field.get_params(lr), betas=betas, eps=eps, fused=True, capturable=self.use_graph)
             self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype in (torch.float16, torch.bfloat16))  # (the table gradient is fp16 either way)
+        # pipeline_adam = k > 1 (fused path; round 5, an A/B -- OFF by default): the table gradient is summed in k level groups and the Adam update of
+        # group g runs on a second stream while group g + 1 is being summed (VALU-bound sums beside an HBM-bound update).  CAVEAT, the reason it is
+        # not the default: GradScaler skips the WHOLE step when any gradient element is non-finite; here group g's update has started before the
+        # groups behind it have been scanned.  Non-finite incoming gradients are caught before (the MLP backward's scan, which every overflow of
+        # dL/dfeatures passes through); what is not is a row of a LATER level group overflowing fp16 as a sum of finite contributions -- then the
+        # earlier groups are already updated and the step is skipped for the rest.
+        self.pipeline_adam = int(pipeline_adam) if (self.fused and int(pipeline_adam) > 1 and self.amp is not None and field.fused_field) else 0
+        if self.pipeline_adam:
+            from .dp import TableGradChunks
+
+            self._chunks = TableGradChunks(field.encoder, self.pipeline_adam)
+            self._chunks.with_amp = True
+            self._adam_stream = torch.cuda.Stream(device=self.dev)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
         self._graphs, self._M = None, 0
         # steps_per_call = k > 1: `step_group` takes the batches of k consecutive steps at once and replays ONE graph for their shade + backward +
@@ -99,7 +112,24 @@ class AcceleratedTrainer:
             self.opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=self.amp_dtype):
             image, depth, loss, scaled = r.shade_train(marched, self.bg_color, target=tgt, scale=self.amp.scale if self.amp else None)
-        if self.amp:
+        if self.amp and self.pipeline_adam:
+            scaled.backward(self._one)  # (the table gradient is only BINNED: TableGradChunks is attached)
+            chunks, main, side = self._chunks, torch.cuda.current_stream(), self._adam_stream
+            state = chunks.take()
+            if state[1] is None:  # a batch the phased backward does not take (small): the gradient is complete, one update
+                self.amp.step()
+            else:
+                for i in range(len(chunks)):
+                    chunks.sum_chunk(i, state)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        a, b = chunks.rows[i]
+                        self.opt.launch_rows(0, a, b, 1.0, self.amp.scale, self.amp.found_inf)
+                main.wait_stream(side)
+                self.amp.step(exclude=(0,))  # the two MLP weight vectors + the scale / step-counter update
+        elif self.amp:
             scaled.backward(self._one)
             self.amp.step()
         else:

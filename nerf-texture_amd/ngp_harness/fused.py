@@ -168,16 +168,23 @@ class _ngp_field(Function):
         dummy = torch.empty(1, **half)
         # (the chunked form hands autograd a gradient that is FINISHED LATER, in place: only valid when `.grad` becomes this very tensor --
         # an fp16 leaf, so that `.to(t_dtype)` below is the identity, and no earlier `.grad` to accumulate into: TableGradChunks.begin checks)
-        chunker = ctx.grad_chunker if (sink is None and t_dtype == torch.float16) else None
+        chunker = ctx.grad_chunker if ((sink is None or getattr(ctx.grad_chunker, "with_amp", False)) and t_dtype == torch.float16) else None
         if chunker is not None:
-            # data parallelism: only BIN the contributions here; the caller sums the level groups one by one (chunker.sum_chunk) and starts each
-            # group's all-reduce while the next one is being summed.  grad_table is complete once every group has been summed.
+            # only BIN the contributions here; the caller sums the level groups one by one (chunker.sum_chunk) -- data parallelism: each group's
+            # all-reduce starts while the next group is being summed; single GPU (round 5, with_amp): each group's Adam runs on a second stream
+            # while the next group is being summed (the non-finite scan rides on each group's stores).  grad_table is complete once every group
+            # has been summed.
             L = offsets.shape[0] - 1
             args = (ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, L, S, H, gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE,
                     affine[0], affine[1])
-            if lib.nerftex_grid_encode_backward_phase(*args, 1, 0, L, stream()) == 0:
-                chunker.begin(grad_table, lambda lo, hi: check(lib.nerftex_grid_encode_backward_phase(*args, 2, lo, hi, stream())),
-                              keep=(grad_x, x, table_h, offsets, dummy))
+            if sink is not None:
+                phase = lambda ph, lo, hi: lib.nerftex_grid_encode_backward_phase_amp(*args, ph, lo, hi, found, stream())  # noqa: E731
+            else:
+                phase = lambda ph, lo, hi: lib.nerftex_grid_encode_backward_phase(*args, ph, lo, hi, stream())  # noqa: E731
+            if phase(1, 0, L) == 0:
+                chunker.begin(grad_table, lambda lo, hi: check(phase(2, lo, hi)), keep=(grad_x, x, table_h, offsets, dummy))
+                if sink is not None:
+                    sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
                 return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None, None
             chunker.begin(grad_table, None, keep=None)  # (small batch / unknown table: the one-call backward below; the groups are complete already)
         if sink is not None:

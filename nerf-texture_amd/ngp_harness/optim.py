@@ -111,10 +111,24 @@ class HalfLeafAdam(torch.optim.Optimizer):
                 self.param_groups[0][k] = v
         self.resync()
 
-    def _launch(self, step_offset, grad_scale, found_inf, amp=None):
-        """One launch over every leaf that has a gradient.  amp = (scale, growth_tracker, found_inf, ticket, growth, backoff, interval):
-        the loss scaler's update rides along (step number *step_count + 1; the launch advances step_count itself)."""
-        idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None]
+    def launch_rows(self, i, a, b, step_offset, grad_scale, found_inf):
+        """Adam over rows [a, b) of leaf i alone (current stream): the table updated level group by level group, each group as soon as its rows
+        of the gradient are final (accelerate(pipeline_adam=True)).  The step number is *step_count + step_offset; step_count is not advanced."""
+        g = self.leaves[i].grad
+        assert g is not None and g.dtype == self.leaves[i].dtype and g.is_contiguous()
+        if b <= a:
+            return
+        parts = [t[a:b] for t in (self.masters[i].data, self.exp_avg[i], self.exp_avg_sq[i], g, self.leaves[i].data)]
+        grp = self.param_groups[0]
+        n = (ctypes.c_uint64 * 1)(parts[0].numel())
+        check(lib.nerftex_adam_mixed_step(1, *[_ptr_array([t]) for t in parts], n, (self.bf16_mask >> i) & 1, ptr(self.step_count), float(step_offset),
+                                          float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], ptr(grad_scale), ptr(found_inf), stream()))
+
+    def _launch(self, step_offset, grad_scale, found_inf, amp=None, exclude=()):
+        """One launch over every leaf that has a gradient (but `exclude`: leaves already updated by launch_rows).  amp = (scale, growth_tracker,
+        found_inf, ticket, growth, backoff, interval): the loss scaler's update rides along (step number *step_count + 1; the launch advances
+        step_count itself)."""
+        idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None and i not in exclude]
         if not idx and amp is None:
             return
         grads = [self.leaves[i].grad for i in idx]
@@ -133,7 +147,7 @@ class HalfLeafAdam(torch.optim.Optimizer):
             scale, tracker, found, ticket, growth, backoff, interval = amp
             check(lib.nerftex_adam_mixed_step_amp(len(idx), *arrays, mask, ptr(self.step_count), *hyper, ptr(scale), ptr(tracker), ptr(found), ptr(ticket),
                                                   growth, backoff, interval, stream()))
-        for i in idx:
+        for i in list(idx) + list(exclude):
             torch.autograd.graph.increment_version(self.masters[i])
 
     @torch.no_grad()
@@ -200,9 +214,11 @@ class FusedAmp:
         check(lib.nerftex_amp_check_mixed(len(grads), _ptr_array(grads), n, mask, ptr(self.found_inf), stream()))
 
     @torch.no_grad()
-    def step(self):
+    def step(self, exclude=()):
+        """exclude: indices of leaves whose Adam update has been launched already (HalfLeafAdam.launch_rows, reading this object's scale and
+        found_inf): they are neither scanned nor updated here; the scale / step-counter update still is."""
         _poll_deferred_error()
-        grads = [leaf.grad for leaf in self.opt.leaves if leaf.grad is not None]
+        grads = [leaf.grad for i, leaf in enumerate(self.opt.leaves) if leaf.grad is not None and i not in exclude]
         covered = getattr(self, "covered", None)
         if covered:  # gradients whose producing kernels already raised found_inf (attach): the very tensors, untouched since
             grads = [g for g in grads if g.data_ptr() not in covered]
@@ -210,4 +226,4 @@ class FusedAmp:
         if grads:
             self._check(grads)
         # Adam (skipped on overflow) and the scale / step-counter update in one launch
-        self.opt._launch(1.0, self.scale, self.found_inf, (self.scale, self.growth_tracker, self.found_inf, self.ticket, *self.consts))
+        self.opt._launch(1.0, self.scale, self.found_inf, (self.scale, self.growth_tracker, self.found_inf, self.ticket, *self.consts), exclude=exclude)

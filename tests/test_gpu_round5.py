@@ -184,6 +184,49 @@ def test_step_group_in_bf16_trains_like_single_steps(dev):
     assert np.isfinite(last) and last < first, (first, last)
 
 
+def test_pipelined_adam_gives_the_parameters_of_the_single_update(dev):
+    """accelerate(renderer, pipeline_adam=4): the table gradient summed in 4 level groups, each group's Adam on a second stream while the next group
+    is being summed -- against the default (one sum, one update): the same kernels on the same rows with the same step number and scale, so the
+    same parameters, bit for bit, through eager steps and replayed graphs (no overflowing step in this run: the caveat in accelerate.py is about
+    those)."""
+    from ngp_harness import scene
+    from ngp_harness.accelerate import accelerate
+    from ngp_harness.model import NGPField, Renderer
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    n, n_pool = 2048, 4
+    pool = []
+    for k in range(n_pool):
+        o, d = scene.train_batch(n, seed=500 + k, n_views=2)
+        pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
+    gt = torch.rand(n_pool, n, 3, generator=torch.Generator().manual_seed(23)).to(dev)
+
+    def run(pipe):
+        torch.manual_seed(0)
+        field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
+        torch.manual_seed(1)
+        field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+        r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+        r.set_occupancy(torch.from_numpy(grid).to(dev))
+        t = accelerate(r, dt_gamma=1 / 128, pipeline_adam=pipe)
+        assert t.pipeline_adam == pipe
+        losses = []
+        for s_ in range(16 + 2 + 22):
+            t.step(*pool[s_ % n_pool], gt[s_ % n_pool])
+            losses.append(t.loss.clone())
+        torch.cuda.synchronize()
+        assert t._graphs is not None
+        return field, torch.stack(losses), float(t.amp.scale), float(t.opt.step_count)
+
+    f0, l0, s0, c0 = run(0)
+    f4, l4, s4, c4 = run(4)
+    assert (s0, c0) == (s4, c4) == (65536.0, 40.0)
+    assert torch.equal(l0, l4)
+    for (n0, p0), (_, p4) in zip(f0.named_parameters(), f4.named_parameters()):
+        assert torch.equal(p0, p4), n0
+
+
 # ------------------------------------------------------------------------------------------------- stratified occupancy picks
 def test_stratified_partial_occupancy_draw_is_ordered_and_covers_every_stratum(dev):
     """nerftex_occupancy_sample_partial_ordered(stratified=1): the uniform half names exactly one cell of every run of H^3 / N consecutive Morton

@@ -29,7 +29,10 @@ enum Op {
     MUL_F32, FMA_F32, FMA_F64, MUL_F64, ADD_F64,                              // plain fp32 (control) and fp64
     PK_FMA_F16, PK_MUL_F16, PK_ADD_F16, CVT_PK_F16, CVT_PK_BF16, FMA_MIX, FMA_MIXLO, DOT2C,  // 16-bit forms the library contains
     MUL_LO_U32, MAD_U64, EXP_F32, RCP_F32, DPP_ROW_SHL, CVT_F64_F32,
-    CHAIN_K3D, CHAIN_K3D_NOPS, CHAIN_K3D_FRESH_REGS, CHAIN_SCALAR, CHAIN_K3D_AFTER_LOAD, CHAIN_PK3_PLAIN, N_OPS   // dependent chains (round 5, second pass)
+    CHAIN_K3D, CHAIN_K3D_NOPS, CHAIN_K3D_FRESH_REGS, CHAIN_SCALAR, CHAIN_K3D_AFTER_LOAD, CHAIN_PK3_PLAIN,   // dependent chains (round 5, second pass)
+    // third pass: producer -> consumer PAIRS, which link of the chain is it?  (all beside the MFMA neighbours; N = s_nop between the two)
+    PAIR_ADD_MULSWAP, PAIR_ADD_MULSWAP_NOP7, PAIR_ADD_MULSWAP_NOP15, PAIR_ADD_MULSWAP_INDEP, PAIR_ADD_MULPLAIN, PAIR_ADD_ADDONE, PAIR_FLOOR_ADD, PAIR_ADD_SCALARMUL,
+    PAIR_FMA_ADD, PAIR_MOVS_MULSWAP, N_OPS
 };
 static const char* kNames[N_OPS] = {
     "v_pk_mul_f32", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_add_f32", "v_pk_add_f32 neg_lo/neg_hi", "v_pk_add_f32 v, 1.0 op_sel_hi:[1,0] neg", "v_pk_fma_f32",
@@ -38,7 +41,11 @@ static const char* kNames[N_OPS] = {
     "v_mov_b32_dpp row_shl:1 (inline asm: no hazard nops -- differs alone too, an artefact)", "v_cvt_f64_f32",
     "CHAIN as compiled into K3d: pk_fma(sgpr,0.5) floor floor pk_add(neg) pk_add(1.0) 3 x pk_mul(op_sel), registers reused", "the same chain, s_nop 1 after every instruction",
     "the same chain, every result in a fresh register pair", "the same arithmetic with single instructions (control)", "the K3d chain right behind the global load of its input + s_waitcnt",
-    "three dependent plain v_pk_mul_f32"};
+    "three dependent plain v_pk_mul_f32",
+    "PAIR pk_add(neg) -> pk_mul op_sel:[0,1] op_sel_hi:[1,0] of its result (halves swapped)", "the same pair, s_nop 7 between", "the same pair, 2 x s_nop 7 between",
+    "pk_add(neg) then pk_mul op_sel of an OLDER register (no dependency)", "PAIR pk_add(neg) -> plain pk_mul of its result", "PAIR pk_add(neg) -> pk_add(1.0 op_sel_hi:[1,0]) of its result",
+    "PAIR 2 x v_floor_f32 -> pk_add(neg) of their results", "PAIR pk_add(neg) -> v_mul_f32 hi, lo of its result", "PAIR pk_fma(sgpr pair, 0.5 op_sel_hi:[1,0,0]) -> pk_add(neg) of its result",
+    "PAIR 2 x v_mov_b32 -> pk_mul op_sel of the moved pair (single-instruction producers)"};
 
 template <typename T>
 __device__ __forceinline__ bool bits_differ(const T& x, const T& y) {
@@ -124,7 +131,25 @@ __device__ __forceinline__ bool chain_differs(f2 a, f2 sc, const float* mem) {
         else if constexpr (OP == CHAIN_K3D_AFTER_LOAD)
             asm volatile("global_load_dwordx2 v[40:41], %4, off\n s_waitcnt vmcnt(0)\n" K3D_BODY("") K3D_OUT
                          : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(mem), "v"(a[1]) : K3D_CLOB, "memory");
-        else
+        else if constexpr (OP >= PAIR_ADD_MULSWAP) {
+#define PAIR(BODY) asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n v_mov_b32 v44, %5\n v_mov_b32 v45, %4\n s_nop 7\n" BODY "s_nop 7\n v_mov_b32 %0, v48\n v_mov_b32 %1, v49\n v_mov_b32 %2, v42\n" \
+                                : "=v"(r[k][0]), "=v"(r[k][1]), "=v"(r[k][2]) : "s"(sc), "v"(a[0]), "v"(a[1]) : K3D_CLOB)
+#define SWAPMUL "v_pk_mul_f32 v[48:49], v[42:43], v[42:43] op_sel:[0,1] op_sel_hi:[1,0]\n"
+#define ADDNEG "v_pk_add_f32 v[42:43], v[40:41], v[44:45] neg_lo:[0,1] neg_hi:[0,1]\n"
+            if constexpr (OP == PAIR_ADD_MULSWAP) PAIR(ADDNEG SWAPMUL);
+            else if constexpr (OP == PAIR_ADD_MULSWAP_NOP7) PAIR(ADDNEG "s_nop 7\n" SWAPMUL);
+            else if constexpr (OP == PAIR_ADD_MULSWAP_NOP15) PAIR(ADDNEG "s_nop 7\n s_nop 7\n" SWAPMUL);
+            else if constexpr (OP == PAIR_ADD_MULSWAP_INDEP) PAIR(ADDNEG "v_pk_mul_f32 v[48:49], v[40:41], v[40:41] op_sel:[0,1] op_sel_hi:[1,0]\n");
+            else if constexpr (OP == PAIR_ADD_MULPLAIN) PAIR(ADDNEG "v_pk_mul_f32 v[48:49], v[42:43], v[42:43]\n");
+            else if constexpr (OP == PAIR_ADD_ADDONE) PAIR(ADDNEG "v_pk_add_f32 v[48:49], v[42:43], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n");
+            else if constexpr (OP == PAIR_FLOOR_ADD) PAIR("v_floor_f32 v42, v40\n v_floor_f32 v43, v41\n v_pk_add_f32 v[48:49], v[40:41], v[42:43] neg_lo:[0,1] neg_hi:[0,1]\n");
+            else if constexpr (OP == PAIR_ADD_SCALARMUL) PAIR(ADDNEG "v_mul_f32 v48, v43, v42\n v_mov_b32 v49, v48\n");
+            else if constexpr (OP == PAIR_FMA_ADD) PAIR("v_pk_fma_f32 v[42:43], v[40:41], %3, 0.5 op_sel_hi:[1,0,0]\n v_pk_add_f32 v[48:49], v[42:43], v[44:45] neg_lo:[0,1] neg_hi:[0,1]\n");
+            else PAIR("v_mov_b32 v42, v41\n v_mov_b32 v43, v40\n" SWAPMUL);
+#undef PAIR
+#undef SWAPMUL
+#undef ADDNEG
+        } else
             asm volatile("v_mov_b32 v40, %4\n v_mov_b32 v41, %5\n s_nop 4\n"
                          "v_pk_mul_f32 v[42:43], v[40:41], %3\n v_pk_mul_f32 v[44:45], v[42:43], v[40:41]\n v_pk_mul_f32 v[46:47], v[44:45], v[42:43]\n"
                          "s_nop 4\n v_mov_b32 %0, v46\n v_mov_b32 %1, v47\n v_mov_b32 %2, v44\n"
@@ -245,7 +270,8 @@ int main(int argc, char** argv) {
     hipStream_t mainst, side;
     CK(hipStreamCreateWithFlags(&mainst, hipStreamNonBlocking));
     CK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
-    if (first_op >= CHAIN_K3D) run_all<CHAIN_K3D>(secs, all_nb, mainst, side, sink, stats, first);  // (the chains only)
+    if (first_op >= PAIR_ADD_MULSWAP) run_all<PAIR_ADD_MULSWAP>(secs, all_nb, mainst, side, sink, stats, first);  // (the pairs only)
+    else if (first_op >= CHAIN_K3D) run_all<CHAIN_K3D>(secs, all_nb, mainst, side, sink, stats, first);  // (the chains and the pairs)
     else run_all<0>(secs, all_nb, mainst, side, sink, stats, first);
     return 0;
 }
