@@ -21,8 +21,10 @@
 //    one stream, no split-K side streams / events (ffmlp.cu:711-740), fp32 instead of fp16 accumulation.
 //
 // Supported: hidden_dim in {16,32,64,128,256}, input_dim % 16 == 0, output_dim == 16 (padded),
-// num_layers >= 2, B % 128 == 0, every activation of ffmlp.py:89-96.  The weights of all layers must
-// fit the 160 KB LDS of a CU (true for every width <= 128 and for 256 with num_layers == 2).
+// num_layers >= 2, B % 128 == 0, every activation of ffmlp.py:89-96.  When the weight fragments of all layers
+// fit the 160 KB LDS of a CU they are staged once per workgroup; otherwise (hidden 256 with >= 3 layers, hidden 128
+// with >= 6) the forward / inference / dgrad kernels stage ONE layer at a time between two barriers (round 5: the
+// STREAM forms), as the reference's threadblock_layer reads each layer from global memory (ffmlp.cu:47-129).
 #include "common.hpp"
 #include "sh_common.hpp"  // the SH basis of the fused field kernel (switches fp contraction off for what follows ...)
 #include "workspace.hpp"
