@@ -227,6 +227,97 @@ class MeshProjector(torch.nn.Module):
         return p_sur, sdf.unsqueeze(-1), mask.bool(), normal, tbn.view(N, 3, 3), face_idx, z
 
 
+class LipLayer(torch.nn.Module):
+    """tools/map.py:211-228: y = act(W_n x + b) with the rows of W scaled down to an l1 norm of at most softplus(c) (a Lipschitz bound that is
+    itself trained)."""
+
+    def __init__(self, in_dim, out_dim, act=True):
+        super().__init__()
+        self.act = act
+        self.W = torch.nn.Parameter(torch.randn(out_dim, in_dim).float() * 1e-1)
+        self.b = torch.nn.Parameter(torch.zeros(out_dim, dtype=torch.float32))
+        self.c = torch.nn.Parameter(torch.ones([], dtype=torch.float32))
+
+    def bound(self):
+        return torch.nn.functional.softplus(self.c)
+
+    def normalization(self):
+        absrowsum = self.W.abs().sum(dim=1)
+        scale = torch.minimum(torch.ones_like(absrowsum), self.bound() / absrowsum)
+        return self.W * scale[..., None]
+
+    def forward(self, x):
+        y = torch.einsum("ab,nb->na", self.normalization(), x) + self.b
+        return torch.relu(y) if self.act else y
+
+
+class LipMLP(torch.nn.Module):
+    """tools/map.py:189-208: num_layers hidden LipLayers of n_neurons + a linear LipLayer; regularization() = the product of the layers' bounds."""
+
+    def __init__(self, in_dim, out_dim, n_neurons=64, num_layers=3):
+        super().__init__()
+        dims = [in_dim] + [n_neurons] * num_layers
+        self.layers = torch.nn.ModuleList([LipLayer(a, b) for a, b in zip(dims[:-1], dims[1:])] + [LipLayer(dims[-1], out_dim, act=False)])
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def regularization(self):
+        loss = 1.0
+        for layer in self.layers:
+            loss = loss * layer.bound()
+        return loss
+
+
+class FactorizedNormalNet(torch.nn.Module):
+    """tools/map.py:231-337 `Factorized_Normal_Net` (lip=True, direct_pred_coor=False: what MeshFeatureField builds by default, :585-588): the fine
+    normal in the local frame as two angles -- phi (anisotropic) from a hash grid of its own over the surface point (L = 4, 512 -> 1024,
+    2^19 rows, align_corners: :235; one more G1 caller, and a G3 caller when p_sur carries a gradient) ++ the first 12 height bands, theta
+    (isotropic) from the first 32 texture features ++ the same height bands, each through a 2 x 16 LipMLP; normal = (sin t cos p, sin t sin p,
+    cos t), optionally rotated by a per-point frame.  The networks are 16 wide: framework ops, as in the reference (its tcnn alternative,
+    lip=False, is the un-vendored dependency)."""
+
+    def __init__(self, x_dim, z_dim, theta_scale=np.pi / 2 * 1.1, phi_scale=np.pi * 2 * 1.1, bound_output=False, low_freq_band_len_f=32, low_freq_band_len_z=12):
+        super().__init__()
+        from gridencoder import GridEncoder
+
+        self.encoder = GridEncoder(input_dim=3, num_levels=4, level_dim=2, base_resolution=512, log2_hashmap_size=19, desired_resolution=1024, gridtype="hash",
+                                   align_corners=True)
+        self.low_freq_band_len_x = min(x_dim, low_freq_band_len_f)
+        self.low_freq_band_len_z = min(z_dim, low_freq_band_len_z)
+        self.phi_net = LipMLP(in_dim=self.encoder.output_dim + self.low_freq_band_len_z, out_dim=1, n_neurons=16, num_layers=2)
+        self.theta_net = LipMLP(in_dim=self.low_freq_band_len_x + self.low_freq_band_len_z, out_dim=1, n_neurons=16, num_layers=2)
+        self.theta_scale, self.phi_scale, self.bound_output = theta_scale, phi_scale, bound_output
+
+    def regularization(self):
+        return self.phi_net.regularization() + self.theta_net.regularization()
+
+    @staticmethod
+    def toCoor(phi, theta):
+        sin_theta = torch.sin(theta)
+        return torch.cat([sin_theta * torch.cos(phi), sin_theta * torch.sin(phi), torch.cos(theta)], dim=-1)
+
+    def phi_embedding(self, p_sur):
+        return self.encoder(p_sur)
+
+    def forward(self, z_embed, x_embed, p_sur=None, phi_embed=None, tbn=None, return_rot_angles=False):
+        assert p_sur is None or phi_embed is None, "Only one of p_sur and phi_embed is None"
+        if p_sur is not None:
+            phi_embed = self.encoder(p_sur)
+        zl = z_embed[..., :self.low_freq_band_len_z].float()
+        phi = self.phi_net(torch.cat([phi_embed.float(), zl], dim=-1))
+        theta = self.theta_net(torch.cat([x_embed[..., :self.low_freq_band_len_x].float(), zl], dim=-1))
+        if self.bound_output:
+            theta = self.theta_scale * torch.sigmoid(theta)
+            phi = self.phi_scale * torch.sigmoid(phi)
+        if return_rot_angles:
+            return theta, phi
+        normal = self.toCoor(phi=phi, theta=theta)
+        return normal if tbn is None else torch.einsum("na,nab->nb", normal, tbn)
+
+
 class CurvedFieldLookup(torch.nn.Module):
     def __init__(self, vertices, faces, bound=1.0, h_threshold=0.05):
         super().__init__()
@@ -276,7 +367,7 @@ class CurvedField(torch.nn.Module):
     unless no_noise."""
 
     def __init__(self, vertices, faces, bound=1.0, h_threshold=0.05, K=8, num_level=8, hidden_dim=32, geo_feat_dim=15, hidden_dim_color=64,
-                 num_layers=2, num_layers_color=3, dir_degree=4, prob_model=False, vertex_normals=None, tbn=None):
+                 num_layers=2, num_layers_color=3, dir_degree=4, prob_model=False, vertex_normals=None, tbn=None, pred_normal=False):
         super().__init__()
         from ffmlp import FFMLP
         from gridencoder import GridEncoder
@@ -290,6 +381,12 @@ class CurvedField(torch.nn.Module):
         self.encoder_var = GridEncoder(**kw) if prob_model else None
         if prob_model:
             torch.nn.init.normal_(self.encoder_var.embeddings, std=1e-5)  # reset_parameters(std=1e-5), tools/map.py:566
+        # pred_normal (the reference's default, tools/map.py:547, :585-588): the factorized fine-normal net; its consumer -- the light models of
+        # network_curvedfield.py:331-380 -- is out of scope, so forward() keeps the coarse normal (render_light_model False, :283) and the fine
+        # normal is what `embed(..., with_fine_normal=True)` / `fine_normal()` return
+        self.normal_net = FactorizedNormalNet(x_dim=self.encoder.output_dim, z_dim=1 + 2 * self.multires) if pred_normal else None
+        if pred_normal:
+            self.normal_net.encoder.embeddings.data.uniform_(0, 1e-3)  # tools/map.py:588
         self.in_dim = self.encoder.output_dim + 1 + 2 * self.multires  # 16 + 25
         self.in_pad = (self.in_dim + 15) // 16 * 16
         self.sigma_net = FFMLP(input_dim=self.in_pad, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
@@ -298,16 +395,25 @@ class CurvedField(torch.nn.Module):
         self.color_pad = (self.color_in + 15) // 16 * 16
         self.color_net = FFMLP(input_dim=self.color_pad, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
 
-    def embed(self, x, no_noise=False, requires_grad_xyz=False):
-        """MeshFeatureField.forward (no import, tools/map.py:620-641): -> embed [N,41], normal_coarse [N,3], h_mask [N].
+    def fine_normal(self, x, no_noise=False, requires_grad_xyz=False):
+        """normal_fine of MeshFeatureField.forward (tools/map.py:637-641, 726-735): the factorized net's local normal rotated into the world by the
+        hit face's frame, normalised.  -> (normal_fine [N,3], normal_coarse [N,3], h_mask [N])."""
+        assert self.normal_net is not None, "CurvedField(pred_normal=True)"
+        embed, normal_coarse, h_mask, normal_fine = self.embed(x, no_noise=no_noise, requires_grad_xyz=requires_grad_xyz, with_fine_normal=True)
+        return normal_fine, normal_coarse, h_mask
+
+    def embed(self, x, no_noise=False, requires_grad_xyz=False, with_fine_normal=False):
+        """MeshFeatureField.forward (no import, tools/map.py:620-641): -> embed [N,41], normal_coarse [N,3], h_mask [N]
+        (+ normal_fine [N,3] with with_fine_normal, the 4-tuple of :737 in the reference's order embed, normal_coarse, normal_fine, h_mask
+        re-ordered to keep the 3-tuple's positions).
         requires_grad_xyz (network_curvedfield.py:236-259, the branch that differentiates sigma with respect to the sample position): the
         projection carries `diff_project_layer`'s gradient, the hash table is looked up with input gradients (dy_dx) and the height ladder
         is evaluated by framework ops on the differentiable height -- dL/dembed reaches x."""
         if requires_grad_xyz:
-            p_sur, sdf, h_mask, normal, _ = self.projector.project(x, K=self.projector.K, h_threshold=self.h_threshold, requires_grad_xyz=True)
+            p_sur, sdf, h_mask, normal, local_tbn = self.projector.project(x, K=self.projector.K, h_threshold=self.h_threshold, requires_grad_xyz=True)
             z_embed = freq_encode(sdf, self.multires)
         else:
-            p_sur, sdf, h_mask, normal, _, _, z_embed = self.projector.project_fused(x, multires=self.multires)
+            p_sur, sdf, h_mask, normal, local_tbn, _, z_embed = self.projector.project_fused(x, multires=self.multires)
         x_embed = self.encoder(p_sur, bound=self.bound)
         if self.encoder_var is not None:
             var = self.encoder_var(p_sur, bound=self.bound)
@@ -315,6 +421,11 @@ class CurvedField(torch.nn.Module):
             x_embed = x_embed + noise * torch.exp(var)
         embed = torch.cat([x_embed, z_embed.to(x_embed.dtype)], dim=-1)
         normal = normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)  # tools/map.py:720
+        if with_fine_normal:
+            local = self.normal_net(p_sur=p_sur, z_embed=z_embed, x_embed=x_embed)  # :639
+            fine = torch.einsum("nba,nb->na", local_tbn, local)  # :727 (the frame's rows are t, b, n: local -> world)
+            fine = fine / (fine.norm(dim=-1, keepdim=True) + 1e-5)  # :732
+            return embed, normal, h_mask, fine
         return embed, normal, h_mask
 
     def _sigma(self, embed):
@@ -368,8 +479,12 @@ class CurvedField(torch.nn.Module):
         color = torch.sigmoid(h)
         return torch.where(h_mask, sigma, torch.zeros_like(sigma)), torch.where(h_mask.unsqueeze(-1), color, torch.zeros_like(color)), {}
 
-    def regular_loss(self):
-        return 1e-8 * self.encoder.clustering_loss()  # tools/map.py:770-774
+    def regular_loss(self, lip_weight=0.0):
+        """tools/map.py:770-774; lip_weight: network_curvedfield.py:225-227 adds 1e-4 * normal_net.regularization() when the light model renders."""
+        loss = 1e-8 * self.encoder.clustering_loss()
+        if lip_weight and self.normal_net is not None:
+            loss = loss + lip_weight * self.normal_net.regularization()
+        return loss
 
     def get_params(self, lr):
         return [{"params": self.parameters(), "lr": lr}]
