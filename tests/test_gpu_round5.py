@@ -227,6 +227,92 @@ def test_pipelined_adam_gives_the_parameters_of_the_single_update(dev):
         assert torch.equal(p0, p4), n0
 
 
+# ------------------------------------------------------------------------------------------------- the factorized normal net (N4)
+def _normal_net_from_fixture(dev):
+    from ngp_harness.curved import FactorizedNormalNet
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_python_normal_net.npz"))
+    net = FactorizedNormalNet(x_dim=16, z_dim=25)
+    gen = torch.Generator().manual_seed(int(g["table_seed"]))
+    with torch.no_grad():
+        net.encoder.embeddings.copy_(torch.rand(net.encoder.embeddings.shape, generator=gen) - 0.5)
+        for name, mlp in (("phi", net.phi_net), ("theta", net.theta_net)):
+            for i, layer in enumerate(mlp.layers):
+                layer.b.copy_(torch.rand(layer.b.shape, generator=gen) * 0.2 - 0.1)  # (the generator's stream, as tools/make_golden.py draws it)
+                layer.c.copy_(torch.rand((), generator=gen) * 1.5 + 0.25)
+                layer.W.copy_(torch.from_numpy(g[f"{name}_W{i}"]))
+                assert np.allclose(layer.b.numpy(), g[f"{name}_b{i}"]) and abs(float(layer.c) - float(g[f"{name}_c{i}"])) < 1e-7
+    return g, net.to(dev)
+
+
+def test_factorized_normal_net_through_the_hash_grid_matches_the_reference_class(dev):
+    """FactorizedNormalNet with its phi hash grid on the HIP kernels (G1 + the input gradient G3, fp32, no autocast) against
+    tools/map.py:231-337 executed over the oracle (ref_python_normal_net.npz): the local normal, the angles, MeshFeatureField's world normal,
+    and the gradients with respect to the surface points (through dy_dx), the phi table and the LipMLP weights."""
+    g, net = _normal_net_from_fixture(dev)
+    t = lambda k, grad=False: torch.from_numpy(g[k]).to(dev).requires_grad_(grad)  # noqa: E731
+    p_sur, z, x, tbn = t("p_sur", True), t("z_embed", True), t("x_embed", True), t("tbn")
+    np.testing.assert_allclose(net.phi_embedding(p_sur).detach().cpu().numpy(), g["phi_embed"], rtol=1e-5, atol=1e-6)
+    local = net(p_sur=p_sur, z_embed=z, x_embed=x)
+    theta, phi = net(p_sur=p_sur, z_embed=z, x_embed=x, return_rot_angles=True)
+    np.testing.assert_allclose(theta.detach().cpu().numpy(), g["theta"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(phi.detach().cpu().numpy(), g["phi"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(local.detach().cpu().numpy(), g["normal_local"], rtol=1e-5, atol=1e-6)
+    fine = torch.einsum("nba,nb->na", tbn, local)
+    fine = fine / (fine.norm(dim=-1, keepdim=True) + 1e-5)
+    np.testing.assert_allclose(fine.detach().cpu().numpy(), g["normal_fine"], rtol=1e-5, atol=1e-6)
+    ((fine * t("grad_w")).sum() + 0.1 * net.regularization()).backward()
+    np.testing.assert_allclose(p_sur.grad.cpu().numpy(), g["g_p_sur"], rtol=1e-3, atol=1e-5 * float(np.abs(g["g_p_sur"]).max()))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["g_x_embed"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), g["g_z_embed"], rtol=1e-4, atol=1e-6)
+    gt = net.encoder.embeddings.grad
+    rows = torch.from_numpy(g["g_table_rows"]).to(dev)
+    np.testing.assert_allclose(gt[rows].cpu().numpy(), g["g_table_vals"], rtol=1e-4, atol=1e-6 * float(np.abs(g["g_table_vals"]).max()))
+    assert abs(float(gt.abs().double().sum()) - float(g["g_table_abs"])) <= 1e-4 * float(g["g_table_abs"])  # (and nothing outside those rows)
+    for name, mlp in (("phi", net.phi_net), ("theta", net.theta_net)):
+        for i, layer in enumerate(mlp.layers):
+            np.testing.assert_allclose(layer.W.grad.cpu().numpy(), g[f"g_{name}_W{i}"], rtol=1e-4, atol=1e-5 * float(np.abs(g[f"g_{name}_W{i}"]).max()))
+
+
+def test_curved_field_with_the_fine_normal(dev):
+    """CurvedField(pred_normal=True) -- the reference's default, tools/map.py:547 --: embed(with_fine_normal=True) returns MeshFeatureField's
+    4-tuple content; the fine normal is a unit vector, equals rotate(normal_net(p_sur, z, x)) recomputed from the projector's outputs, carries a
+    gradient to the phi table and the LipMLPs (and to x with requires_grad_xyz), and leaves sigma / colour untouched (light model off)."""
+    from ngp_harness.curved import CurvedField, star_flower_mesh
+
+    v, f = star_flower_mesh(n_lat=24, n_lon=48)
+    torch.manual_seed(0)
+    field = CurvedField(v, f, bound=1.0, h_threshold=0.05, pred_normal=True).to(dev)
+    torch.manual_seed(0)
+    plain = CurvedField(v, f, bound=1.0, h_threshold=0.05, pred_normal=False).to(dev)
+    plain.load_state_dict({k: w for k, w in field.state_dict().items() if not k.startswith("normal_net.")})
+    gen = torch.Generator().manual_seed(4)
+    vt = torch.as_tensor(v)
+    x = (vt[torch.randint(0, vt.shape[0], (1024,), generator=gen)] * (1 + (torch.rand(1024, 1, generator=gen) - 0.5) * 0.1)).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(1024, 3, generator=gen), dim=-1).to(dev)
+    field.normal_net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        embed, nc, hm, fine = field.embed(x, with_fine_normal=True)
+        e2, nc2, hm2 = field.embed(x)
+        s1, c1, _ = field(x, d)
+        s2, c2, _ = plain(x, d)
+    assert torch.equal(embed, e2) and torch.equal(nc, nc2) and torch.equal(hm, hm2)
+    assert torch.equal(s1, s2) and torch.equal(c1, c2)
+    assert fine.shape == (1024, 3) and float((fine.norm(dim=-1) - 1).abs().max()) < 1e-3
+    p_sur, sdf, _, _, tbn, _, z = field.projector.project_fused(x, multires=field.multires)
+    with torch.autocast("cuda", dtype=torch.float16):
+        local = field.normal_net(p_sur=p_sur, z_embed=z, x_embed=embed[:, :16])
+    want = torch.einsum("nba,nb->na", tbn, local.float())
+    want = want / (want.norm(dim=-1, keepdim=True) + 1e-5)
+    assert float((fine.float() - want).abs().max()) < 2e-3
+    xg = x.clone().requires_grad_(True)
+    fine_g, _, _ = field.fine_normal(xg, requires_grad_xyz=True)
+    (fine_g.float() * torch.randn(1024, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1))).sum().backward()
+    assert float(field.normal_net.encoder.embeddings.grad.abs().sum()) > 0 and float(field.normal_net.phi_net.layers[0].W.grad.abs().sum()) > 0
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all()) and float(xg.grad.abs().sum()) > 0
+    assert float(field.regular_loss(lip_weight=1e-4)) > float(field.regular_loss())
+
+
 # ------------------------------------------------------------------------------------------------- stratified occupancy picks
 def test_stratified_partial_occupancy_draw_is_ordered_and_covers_every_stratum(dev):
     """nerftex_occupancy_sample_partial_ordered(stratified=1): the uniform half names exactly one cell of every run of H^3 / N consecutive Morton

@@ -499,6 +499,9 @@ def reference_python_goldens():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--round5-only" in sys.argv:
+        round5_goldens()
+        return
     if "--round3-only" not in sys.argv and "--round4-only" not in sys.argv:
         sh_golden()
         module_goldens()
@@ -506,6 +509,7 @@ def main():
     if "--round4-only" not in sys.argv:
         round3_goldens()
     round4_goldens()
+    round5_goldens()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -907,6 +911,65 @@ def round4_projector_gradients():
     np.savez_compressed(os.path.join(OUT, "ref_python_projector_grad.npz"), **out)
     print("ref_python_projector_grad.npz: |dL/dxyz| max", float(np.abs(out["grad_xyz"]).max()), "; d sigma_remap / dx max", float(np.abs(out["grad_normal_dsigma_remap_dx"]).max()),
           "nonzero rows", int((np.abs(out["grad_normal_dsigma_remap_dx"]).sum(-1) > 0).sum()), "of", pts.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: the factorized normal net of MeshFeatureField (tools/map.py:189-337, used at :585-588, :637-641, :726-732)
+# ---------------------------------------------------------------------------------------------------------------------------
+def round5_goldens():
+    """`Factorized_Normal_Net(x_dim=16, z_dim=25, lip=True, direct_pred_coor=False)` -- the reference's class, executed in fp32 on the CPU over the
+    oracle's hash-grid kernels (its phi table: get_encoder('hashgrid', L = 4, 512 -> 1024), tools/map.py:235) -- with LipMLP / LipLayer as they are:
+    forward (local normal, the two angles, the bound_output form), MeshFeatureField's rotation into the world (:727, :732), regularization(), and
+    the gradients of a scalar loss with respect to every LipLayer parameter, the phi table, the surface points (the hash grid's input gradient,
+    G3), the texture features and the height bands."""
+    import torch
+
+    _install_map_imports()
+    import tools.map as ref_map
+
+    torch.manual_seed(11)
+    net = ref_map.Factorized_Normal_Net(x_dim=16, z_dim=25, lip=True, direct_pred_coor=False, bound_output=False)
+    gen = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        net.encoder.embeddings.copy_(torch.rand(net.encoder.embeddings.shape, generator=gen) - 0.5)
+        for mlp in (net.phi_net, net.theta_net):
+            for layer in mlp.layers:  # biases and bounds away from their initial 0 / 1, so that both sides of the row clamp occur
+                layer.b.copy_(torch.rand(layer.b.shape, generator=gen) * 0.2 - 0.1)
+                layer.c.copy_(torch.rand((), generator=gen) * 1.5 + 0.25)
+    N = 640
+    p_sur = ((torch.rand(N, 3, generator=gen) * 2 - 1) * 0.9).requires_grad_(True)
+    z_embed = (torch.randn(N, 25, generator=gen) * 0.7).requires_grad_(True)
+    x_embed = (torch.randn(N, 16, generator=gen) * 0.5).requires_grad_(True)
+    q, _ = torch.linalg.qr(torch.randn(N, 3, 3, generator=gen))
+    tbn = q.contiguous()
+    out = dict(p_sur=p_sur.detach().numpy(), z_embed=z_embed.detach().numpy(), x_embed=x_embed.detach().numpy(), tbn=tbn.numpy(), table_seed=12,
+               table_rows=int(net.encoder.embeddings.shape[0]), offsets=net.encoder.offsets.numpy().copy(), per_level_scale=float(net.encoder.per_level_scale))
+    for name, mlp in (("phi", net.phi_net), ("theta", net.theta_net)):
+        for i, layer in enumerate(mlp.layers):
+            out[f"{name}_W{i}"], out[f"{name}_b{i}"], out[f"{name}_c{i}"] = layer.W.detach().numpy().copy(), layer.b.detach().numpy().copy(), float(layer.c)
+            out[f"{name}_Wn{i}"] = layer.normalization().detach().numpy()
+    local = net(p_sur=p_sur, z_embed=z_embed, x_embed=x_embed)                       # tools/map.py:639
+    theta, phi = net(p_sur=p_sur, z_embed=z_embed, x_embed=x_embed, return_rot_angles=True)  # :643
+    fine = torch.einsum("nba,nb->na", tbn, local)                                    # :727
+    fine = fine / (fine.norm(dim=-1, keepdim=True) + 1e-5)                           # :732
+    reg = net.regularization()
+    gw = torch.randn(N, 3, generator=gen)
+    loss = (fine * gw).sum() + 0.1 * reg
+    loss.backward()
+    gt = net.encoder.embeddings.grad
+    nz = torch.nonzero(gt.abs().sum(-1)).squeeze(-1)
+    out.update(normal_local=local.detach().numpy(), theta=theta.detach().numpy(), phi=phi.detach().numpy(), normal_fine=fine.detach().numpy(), regularization=float(reg),
+               phi_embed=net.phi_embedding(p_sur).detach().numpy(), grad_w=gw.numpy(), g_p_sur=p_sur.grad.numpy().copy(), g_z_embed=z_embed.grad.numpy().copy(),
+               g_x_embed=x_embed.grad.numpy().copy(), g_table_rows=nz.numpy(), g_table_vals=gt[nz].numpy(), g_table_abs=float(gt.abs().double().sum()))
+    for name, mlp in (("phi", net.phi_net), ("theta", net.theta_net)):
+        for i, layer in enumerate(mlp.layers):
+            out[f"g_{name}_W{i}"], out[f"g_{name}_b{i}"], out[f"g_{name}_c{i}"] = layer.W.grad.numpy().copy(), layer.b.grad.numpy().copy(), float(layer.c.grad)
+    net.bound_output = True
+    with torch.no_grad():
+        out["normal_local_bounded"] = net(p_sur=p_sur, z_embed=z_embed, x_embed=x_embed, tbn=tbn).numpy()  # (with its own `tbn` argument: :335-337)
+    np.savez_compressed(os.path.join(OUT, "ref_python_normal_net.npz"), **out)
+    print("ref_python_normal_net.npz: theta", float(theta.min()), float(theta.max()), "phi", float(phi.min()), float(phi.max()), "regularization", float(reg),
+          "rows with a gradient", int(nz.shape[0]), "|dL/dp_sur| max", float(p_sur.grad.abs().max()))
 
 
 if __name__ == "__main__":
