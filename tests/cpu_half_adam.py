@@ -11,8 +11,8 @@ from ngp_harness.optim import FusedAmp, HalfLeafAdam
 class CpuHalfLeafAdam(HalfLeafAdam):
     _needs_device = False
 
-    def _launch(self, step_offset, grad_scale, found_inf, amp=None):
-        idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None]
+    def _launch(self, step_offset, grad_scale, found_inf, amp=None, exclude=()):
+        idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None and i not in exclude]
         grp = self.param_groups[0]
         lr, (b1, b2), eps = float(grp["lr"]), grp["betas"], grp["eps"]
         if amp is not None:
