@@ -1068,10 +1068,42 @@ def main():
         t_pipe, img_pipe, n_pipe, it_pipe = frames(renderer.render_infer_pipelined)
         F, P = args.infer_slots, args.infer_parts
         t_big, img_big, n_big, it_big = frames(lambda ro, rd, dt_gamma: renderer.render_infer_pipelined(ro, rd, dt_gamma=dt_gamma, slots_per_ray=F, parts=P))
-        mpix = {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3, "samples_per_frame": n_big, "iterations": it_big,
+        # round 5: the same loop with the host taken out (Renderer.render_infer_graphed: per ray range one graph per block of iterations, n_step derived
+        # on the device); per-frame times over 10 frames, and the host's own share (time spent enqueueing, before the final synchronise)
+        graphed = None
+        if use_amp and res["dtype"] == "fp16" and getattr(field, "fused_field", False):
+            try:
+                with torch.autocast("cuda", dtype=torch.float16):
+                    render_g = lambda: renderer.render_infer_graphed(ro, rd, dt_gamma=dt_gamma, slots_per_ray=F, parts=P)  # noqa: E731
+                    img_g, _, n_g = render_g()  # records the graphs
+                    render_g()
+                    torch.cuda.synchronize()
+                    per_frame, enqueue = [], []
+                    for _ in range(10):
+                        t2 = time.perf_counter()
+                        img_g, _, n_g = render_g()
+                        t3 = time.perf_counter()
+                        torch.cuda.synchronize()
+                        per_frame.append(time.perf_counter() - t2)
+                        enqueue.append(t3 - t2)
+                per_frame.sort()
+                t_g = sum(per_frame) / len(per_frame)
+                graphed = {"mpix_per_s": 0.64 / t_g, "ms_per_frame": t_g * 1e3, "ms_per_frame_min_median_max": [per_frame[0] * 1e3, per_frame[5] * 1e3, per_frame[-1] * 1e3],
+                           "host_enqueue_ms": sum(enqueue) / len(enqueue) * 1e3, "iterations_launched": renderer.last_iters, "sample_slots_launched": int(n_g),
+                           "max_abs_image_difference_vs_reference_loop": float((img_g - img_ref).abs().max()),
+                           "loop": f"the loop below as HIP graphs: per ray range one graph resets it and one runs 6 iterations (replayed until no ray is left; the host "
+                                   f"learns that one block late from a 4-byte copy), every launch sized for the whole range, n_step = clamp({F} N / alive, {F}, {8 * F}) "
+                                   f"derived by the kernels from the alive count on the device (NERFTEX_ROWS_AUTO); {P} ranges side by side; same image bit for bit"}
+            except Exception as e:  # noqa: BLE001 -- a side measurement
+                print(f"[bench] graphed inference failed ({type(e).__name__}: {e})", file=sys.stderr)
+        head_inf = graphed if graphed is not None else {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3}
+        mpix = {"mpix_per_s": head_inf["mpix_per_s"], "ms_per_frame": head_inf["ms_per_frame"], "graphed": graphed,
+                "host_launched": {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3, "samples_per_frame": n_big, "iterations": it_big},
+                "samples_per_frame": n_big, "iterations": it_big,
                 "loop": f"run_cuda's inference loop, no per-iteration host stall (launches sized by an earlier alive count, the true count read on the "
                         f"device: nerftex_*_rays_dev / *_rows), {F} N sample slots per iteration instead of N (n_step = clamp({F} N // n_alive, {F}, {8 * F})), "
-                        f"the rays in {P} ranges on their own streams; same image as the reference loop, bit for bit",
+                        f"the rays in {P} ranges on their own streams; same image as the reference loop, bit for bit"
+                        + ("; `mpix_per_s` is the graph-replayed form of it (`graphed`), `host_launched` the same loop enqueued launch by launch" if graphed else ""),
                 "reference_schedule_no_stall": {"mpix_per_s": 0.64 / t_pipe, "ms_per_frame": t_pipe * 1e3, "samples_per_frame": n_pipe, "iterations": it_pipe,
                                                 "loop": "the reference's schedule (N slots per iteration), only the host stall removed"},
                 "reference_loop": {"mpix_per_s": 0.64 / t_ref, "ms_per_frame": t_ref * 1e3, "samples_per_frame": n_ref, "iterations": it_ref,

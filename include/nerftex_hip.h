@@ -52,6 +52,20 @@ typedef struct nerftex_raytracer nerftex_raytracer;
  * (INTEGRATION.md "Scratch memory and streams"). [extension] */
 unsigned nerftex_workspace_slots_touched(void);
 
+/* Stream captures record against ONE library scratch set by default, so two graphs that use the same slot must not be replayed side by side
+ * (INTEGRATION.md "Scratch memory and streams").  A caller that WANTS to replay such graphs concurrently -- the ray ranges of an inference
+ * frame, each a chain of compaction / march / field / compositing launches on its own stream -- records each of them under its own set:
+ * captures made by the calling thread after nerftex_workspace_capture_set(k) use set k (0 = the default; 0 .. 255), until it is changed
+ * back.  Graphs recorded under different sets share no scratch. [extension, round 5] */
+int nerftex_workspace_capture_set(int set);
+
+/* "Rows per unit" arguments of the device-count entry points (n_step of nerftex_march_rays_dev / nerftex_composite_rays_dev, rows_per_unit of
+ * nerftex_grid_encode_forward_rows / nerftex_field_forward_rows) may be this code instead of a number: every kernel of the iteration then derives
+ * n_step = clamp(F * N / alive, F, 8 F) -- the rule of nerf/renderer.py:470 with F N sample slots per iteration -- from the alive count on the
+ * device, so that a whole iteration can be recorded into a HIP graph without the host knowing the count.  N < 2^24 rays, F <= 127; buffers
+ * sized for F * N (+ 128) rows. [extension, round 5] */
+#define NERFTEX_ROWS_AUTO(N, F) (0x80000000u | ((uint32_t)(F) << 24) | (uint32_t)(N))
+
 /* Debugging aid: where the library's scratch of `slot` for `stream` (NULL = the default stream) currently sits and how large it is (*ptr = NULL,
  * *bytes = 0 if none has been allocated).  Nothing is allocated.  The contents are whatever the last call that used the slot left -- for slot 5
  * (hash-grid backward) the directory, the partial tiles and the record regions, in that order (csrc/gridencoder_binned.hip). [extension] */

@@ -99,4 +99,15 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// "rows per unit" of a launch sized by a device-side count (the inference loop: units = alive rays, rows per unit = n_step): a plain number,
+// or -- bit 31 set, NERFTEX_ROWS_AUTO(N, F) of include/nerftex_hip.h -- "derive it from the count": n_step = clamp(F N / count, F, 8 F), the
+// rule of nerf/renderer.py:470 with F N slots per iteration, evaluated by every kernel of the iteration from the same device word, so that
+// an iteration can be recorded into a HIP graph without the host knowing how many rays are alive
+__host__ __device__ __forceinline__ uint32_t unit_rows(uint32_t code, uint32_t count) {
+    if (!(code >> 31)) return code;
+    const uint32_t F = (code >> 24) & 127u, N = code & 0xffffffu;
+    const uint32_t q = F * N / (count ? count : 1u);
+    return q < F ? F : (q > 8u * F ? 8u * F : q);
+}
+
 }  // namespace nerftex

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void grid_forward_level_kernel(const float* __
     if (level >= L) return;
     const uint32_t b = (q % nchunks) * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    if (lc.units_dev && b >= (uint32_t)lc.units_dev[0] * lc.rows_per_unit) return;
+    if (lc.units_dev && b >= (uint32_t)lc.units_dev[0] * unit_rows(lc.rows_per_unit, (uint32_t)lc.units_dev[0])) return;
 
     float x[D];
     bool oob = false;

@@ -1024,7 +1024,10 @@ __global__ __launch_bounds__(kRayBlock) void march_rays_kernel(uint32_t n_alive,
                                                             float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb,
                                                             const int* __restrict__ n_alive_dev) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);  // the launch was sized by an upper bound; the true count lives on the device
+    if (n_alive_dev) {  // the launch was sized by an upper bound; the true count lives on the device
+        n_step = unit_rows(n_step, (uint32_t)n_alive_dev[0]);  // (NERFTEX_ROWS_AUTO: the iteration's n_step derived from that count)
+        n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
+    }
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     const Dda s(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, bound, dt_gamma, max_steps, C, H, grid, fars[index]);
@@ -1065,7 +1068,10 @@ __global__ __launch_bounds__(kRayBlock) void composite_rays_kernel(uint32_t n_al
                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
                                                                 float* __restrict__ image, const int* __restrict__ n_alive_dev) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_alive_dev) n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
+    if (n_alive_dev) {
+        n_step = unit_rows(n_step, (uint32_t)n_alive_dev[0]);
+        n_alive = min(n_alive, (uint32_t)n_alive_dev[0]);
+    }
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     float t = rays_t[n];

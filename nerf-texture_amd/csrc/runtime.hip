@@ -76,6 +76,7 @@ std::mutex g_ws_mutex;
 }  // namespace
 
 std::atomic<unsigned> g_ws_touched{0};
+thread_local int t_capture_set = 0;  // nerftex_workspace_capture_set: which scratch set the captures of this thread record against
 
 void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
     g_ws_touched.fetch_or(1u << (unsigned)slot, std::memory_order_relaxed);
@@ -88,7 +89,8 @@ void* workspace(WorkspaceSlot slot, size_t bytes, hipStream_t stream) {
     // in now.  All captures share one set (graphs that use it must not be replayed concurrently with each other: INTEGRATION.md) instead
     // of leaving one set per captured graph behind.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) stream = kCaptureSet;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        stream = reinterpret_cast<hipStream_t>(reinterpret_cast<uintptr_t>(kCaptureSet) - (uintptr_t)t_capture_set);
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     Slot& s = g_ws[dev][stream].slot[slot];
     if (s.bytes < bytes) {
@@ -242,6 +244,16 @@ long nerftex_tune_get(const char* name) {
 }
 
 // test aid: bit mask of the scratch slots (csrc/workspace.hpp WorkspaceSlot) library calls have asked for since the last call of this function
+int nerftex_workspace_capture_set(int set) {
+    nerftex::clear_error();
+    if (set < 0 || set > 255) {
+        nerftex::set_error("workspace_capture_set: 0 (the default set) .. 255");
+        return NERFTEX_ERR_INVALID;
+    }
+    nerftex::t_capture_set = set;
+    return NERFTEX_OK;
+}
+
 unsigned nerftex_workspace_slots_touched(void) {
     const unsigned m = nerftex::g_ws_touched.exchange(0u, std::memory_order_relaxed);
     return m;

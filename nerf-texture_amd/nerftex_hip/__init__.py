@@ -17,6 +17,12 @@ LAYOUT_LBC, LAYOUT_BLC = 0, 1
 LAYOUT_GRAD_OVERWRITE = 0x100  # backward: grad_embeddings is uninitialised and gets overwritten
 
 
+def rows_auto(n_rays, slots_per_ray):
+    """NERFTEX_ROWS_AUTO(N, F): the n_step / rows_per_unit code that makes the kernels derive n_step from the alive count on the device."""
+    assert 0 < n_rays < (1 << 24) and 0 < slots_per_ray <= 127
+    return 0x80000000 | (int(slots_per_ray) << 24) | int(n_rays)
+
+
 from ._build import build  # noqa: E402,F401
 
 
@@ -33,6 +39,7 @@ _SIGNATURES = {
     "nerftex_grid_encode_backward_phase": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _i, _u32, _u32, _vp],
     "nerftex_grid_encode_backward_phase_amp": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _i, _u32, _u32, _vp, _vp],
     "nerftex_release_workspaces": [],
+    "nerftex_workspace_capture_set": [_i],
     "nerftex_field_forward_rows": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "nerftex_grid_encode_forward_rows": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _u32, _vp],
     "nerftex_field_mid_forward": [_vp, _vp, _u32, _vp, _vp, _vp],

@@ -530,6 +530,152 @@ class Renderer(nn.Module):
         self.last_iters = max(j.i for j in jobs)
         return image + (1 - weights_sum).unsqueeze(-1) * bg_color, depth, sum(j.n_samples for j in jobs)
 
+    @torch.no_grad()
+    def render_infer_graphed(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, max_steps=1024, slots_per_ray=4, parts=3, block=6):
+        """render_infer_pipelined with the HOST taken out of the loop (round 5): per ray range one HIP graph resets the range and one graph runs
+        `block` iterations; a frame is parts x (1 + ~3) graph replays instead of parts x ~18 x 12 launches, so the frame time no longer depends
+        on how fast the host enqueues (r4: 65 to 84 Mpix/s between a 16-core and a 128-core host for the same device work).  What made the
+        iteration recordable: its launch sizes are the range's full size (N rays, F N sample slots) and n_step = clamp(F N / alive, F, 8 F) is
+        derived by the kernels from the alive count on the device (NERFTEX_ROWS_AUTO) -- the host only learns, one block late, whether any ray is
+        left (a 4-byte copy per block into pinned memory).  Rays, accumulators and the iteration's buffers are persistent (the graphs bake
+        their addresses): the frame's rays are copied in.  The ranges replay side by side on their own streams; their graphs were recorded
+        under scratch sets of their own (nerftex_workspace_capture_set).  Same image as the reference loop, bit for bit: a ray's samples and
+        the order they are composited in do not depend on how they are cut into iterations (tests/test_gpu_round5.py).  No perturbation
+        (inference); the graphs are re-recorded when the field's parameters, the occupancy bitfield's storage or the shapes change."""
+        from .streams import part_streams
+
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        parts = max(1, min(int(parts), N))
+        field = self.field
+        leaves = [getattr(m, "half_leaf", None) for m in (getattr(field, "encoder", None), getattr(field, "sigma_net", None), getattr(field, "color_net", None))]
+        stamp = (N, parts, int(slots_per_ray), int(block), float(dt_gamma), int(max_steps), self.density_bitfield.data_ptr(), torch.get_autocast_dtype("cuda"),
+                 torch.is_autocast_enabled(), tuple((p.data_ptr(), p._version) for p in field.parameters()), tuple((t.data_ptr(), t._version) for t in leaves if t is not None))
+        st = getattr(self, "_infer_graphs", None)
+        main = torch.cuda.current_stream()
+        if st is None or st["stamp"] != stamp:
+            # one eager frame first: lazy initialisation (cached fp16 copies, level-table registration, workspace growth) outside the captures
+            self.render_infer_pipelined(rays_o, rays_d, dt_gamma=dt_gamma, bg_color=bg_color, max_steps=max_steps, slots_per_ray=slots_per_ray, parts=parts)
+            torch.cuda.synchronize()
+            ro, rd = torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, 3, dtype=torch.float32, device=dev)
+            streams = part_streams(dev, parts)
+            per = -(-N // parts)
+            jobs = []
+            for k in range(parts):
+                lo, hi = k * per, min(N, (k + 1) * per)
+                job = _InferGraphPart(self, ro[lo:hi], rd[lo:hi], dt_gamma, max_steps, slots_per_ray, block, k + 1, streams[k])
+                job.capture()
+                jobs.append(job)
+            torch.cuda.synchronize()
+            st = self._infer_graphs = {"stamp": stamp, "ro": ro, "rd": rd, "jobs": jobs, "streams": streams}
+        st["ro"].copy_(rays_o, non_blocking=True), st["rd"].copy_(rays_d, non_blocking=True)
+        jobs, streams = st["jobs"], st["streams"]
+        for k, job in enumerate(jobs):
+            streams[k].wait_stream(main)
+            with torch.cuda.stream(streams[k]):
+                job.g_init.replay()
+            job.pending = []
+        max_blocks = -(-int(max_steps) // (int(slots_per_ray) * int(block)))
+        active, rounds = list(range(len(jobs))), 0
+        while active and rounds < max_blocks:
+            for k in list(active):
+                job = jobs[k]
+                with torch.cuda.stream(streams[k]):
+                    job.g_block.replay()
+                    slot = rounds % job.ring
+                    # the alive count at the START of the block's last iteration (an upper bound of what is left): read by the host one block late
+                    job.host[slot:slot + 1].copy_(job.counters[1:2], non_blocking=True)
+                    job.events[slot].record()
+                job.pending.append(slot)
+                if len(job.pending) > 1:
+                    s_ = job.pending.pop(0)
+                    job.events[s_].synchronize()
+                    if int(job.host[s_]) <= 0:
+                        active.remove(k)
+            rounds += 1
+        for k in range(len(jobs)):
+            main.wait_stream(streams[k])
+        image = torch.cat([j.image for j in jobs])
+        weights_sum = torch.cat([j.weights_sum for j in jobs])
+        depth = torch.cat([j.depth for j in jobs])
+        self.last_iters = rounds * int(block)
+        return image + (1 - weights_sum).unsqueeze(-1) * bg_color, depth, rounds * int(block) * sum(j.M for j in jobs)
+
+
+class _InferGraphPart:
+    """One range of rays of Renderer.render_infer_graphed: persistent buffers + two HIP graphs -- `init` (near / far, cleared accumulators, every
+    ray alive) and `block` (an even number of iterations, so that the ping-pong parity is the same at every replay).  An iteration is the reference
+    loop's body (nerf/renderer.py:455-483) in its device-count form, with n_step DERIVED ON THE DEVICE from the alive count
+    (NERFTEX_ROWS_AUTO): compaction -> march -> hash-grid gather + field -> compositing, every launch sized for all N rays / F N slots and
+    cut short by the kernels."""
+
+    def __init__(self, renderer, rays_o, rays_d, dt_gamma, max_steps, F, block, set_id, stream):
+        from nerftex_hip import rows_auto
+
+        self.r, self.rays_o, self.rays_d = renderer, rays_o, rays_d  # (views of the frame's static ray buffers)
+        self.dt_gamma, self.max_steps, self.F, self.block, self.set_id, self.stream = float(dt_gamma), int(max_steps), int(F), int(block), int(set_id), stream
+        N, dev = rays_o.shape[0], rays_o.device
+        self.N, self.auto = N, rows_auto(N, F)
+        self.weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        self.rays_alive = torch.zeros(2, N, dtype=torch.int32, device=dev)
+        self.rays_t = torch.zeros(2, N, dtype=torch.float32, device=dev)
+        self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.all_rays = torch.arange(N, dtype=torch.int32, device=dev)
+        self.start_counts = torch.tensor([0, N], dtype=torch.int32, device=dev)
+        self.M = (N * F + 127) // 128 * 128
+        self.buf = torch.empty(self.M * 8, dtype=torch.float32, device=dev)
+        self.ring = 4
+        self.host = torch.zeros(self.ring, dtype=torch.int32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.ring)]
+        self.g_init = self.g_block = None
+
+    def _init_ops(self):
+        r = self.r
+        self.nears, self.fars = raymarching.near_far_from_aabb(self.rays_o, self.rays_d, r.aabb_infer, r.min_near)
+        self.weights_sum.zero_(), self.depth.zero_(), self.image.zero_()
+        # every ray alive in the OLD half: the first iteration's compaction carries them over (order-preserving: the same arrays)
+        self.rays_alive[1].copy_(self.all_rays)
+        self.rays_t[1].copy_(self.nears)
+        self.counters.copy_(self.start_counts)
+
+    def _iteration(self, j):
+        from nerftex_hip import check, lib, ptr, stream
+
+        r, N, M = self.r, self.N, self.M
+        cur, old = j % 2, (j + 1) % 2
+        c, ra, rt = self.counters, self.rays_alive, self.rays_t
+        check(lib.nerftex_compact_rays_dev(N, ptr(c[old:]), ptr(ra[cur]), ptr(ra[old]), ptr(rt[cur]), ptr(rt[old]), ptr(c[cur:]), stream()))
+        buf = self.buf
+        xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:8 * M].view(M, 2)
+        check(lib.nerftex_march_rays_dev(N, ptr(c[cur:]), self.auto, ptr(ra[cur]), ptr(rt[cur]), ptr(self.rays_o), ptr(self.rays_d), float(r.bound), self.dt_gamma,
+                                         self.max_steps, r.cascade, r.grid_size, ptr(r.density_bitfield), ptr(self.fars), ptr(xyzs), ptr(dirs), ptr(deltas), 0,
+                                         stream()))
+        sigmas, rgbs = r.field.infer(xyzs, dirs, (c[cur:], self.auto))
+        if r.density_scale != 1:
+            sigmas = r.density_scale * sigmas
+        sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
+        check(lib.nerftex_composite_rays_dev(N, ptr(c[cur:]), self.auto, ptr(ra[cur]), ptr(rt[cur]), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(self.weights_sum),
+                                             ptr(self.depth), ptr(self.image), stream()))
+
+    def capture(self):
+        from nerftex_hip import check, lib
+
+        assert self.block % 2 == 0
+        check(lib.nerftex_workspace_capture_set(self.set_id))  # this range's graphs get scratch of their own: the ranges replay side by side
+        try:
+            self.g_init = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_init, stream=self.stream, capture_error_mode="thread_local"):
+                self._init_ops()
+            self.g_block = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_block, stream=self.stream, pool=self.g_init.pool(), capture_error_mode="thread_local"):
+                for j in range(self.block):
+                    self._iteration(j)
+        finally:
+            check(lib.nerftex_workspace_capture_set(0))
+
 
 class _InferPart:
     """One range of rays going through the sync-free inference loop (Renderer.render_infer_pipelined); step() enqueues one iteration

@@ -227,6 +227,47 @@ def test_pipelined_adam_gives_the_parameters_of_the_single_update(dev):
         assert torch.equal(p0, p4), n0
 
 
+# ------------------------------------------------------------------------------------------------- graph-replayed inference
+def test_graphed_inference_gives_the_image_of_the_reference_loop(dev):
+    """Renderer.render_infer_graphed (per ray range: one graph that resets it, one that runs a block of iterations; n_step derived on the device)
+    against render_infer (nerf/renderer.py:436-487 as written) and render_infer_pipelined: same image and depth, bit for bit; a second frame with
+    other rays replays the recorded graphs; a changed parameter re-records them."""
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev)
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-0.3, 0.3)  # (densities that terminate some rays early and leave others running)
+    field.eval()
+    r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+    r.set_occupancy(torch.from_numpy(grid).to(dev))
+    rng = np.random.default_rng(3)
+    frames = []
+    for _ in range(2):
+        pose = scene.rand_poses(1, 2.0, rng)[0]
+        o, d = scene.get_rays(pose, scene.intrinsics(160, 120), 160, 120)
+        frames.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
+    with torch.autocast("cuda", dtype=torch.float16):
+        for k, (ro, rd) in enumerate(frames):
+            img_ref, dep_ref, _ = r.render_infer(ro, rd, dt_gamma=1 / 128)
+            img_g, dep_g, _ = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=4, parts=3, block=4)
+            assert torch.equal(img_g, img_ref) and torch.equal(dep_g, dep_ref), k
+            assert float(img_ref.std()) > 1e-3
+        graphs = r._infer_graphs["jobs"][0].g_block
+        img_again, _, _ = r.render_infer_graphed(*frames[0], dt_gamma=1 / 128, slots_per_ray=4, parts=3, block=4)
+        assert r._infer_graphs["jobs"][0].g_block is graphs, "the second and third frames replay the recorded graphs"
+        assert torch.equal(img_again, r.render_infer(*frames[0], dt_gamma=1 / 128)[0])
+        with torch.no_grad():
+            field.sigma_net.weights.mul_(1.01)  # a parameter changes (in place, version counter bumped -- as an optimizer step does): new fp16 copies -> the graphs must be re-recorded, not replayed on stale weights
+    with torch.autocast("cuda", dtype=torch.float16):
+        img_new, _, _ = r.render_infer_graphed(*frames[0], dt_gamma=1 / 128, slots_per_ray=4, parts=3, block=4)
+        assert r._infer_graphs["jobs"][0].g_block is not graphs
+        assert torch.equal(img_new, r.render_infer(*frames[0], dt_gamma=1 / 128)[0])
+
+
 # ------------------------------------------------------------------------------------------------- the factorized normal net (N4)
 def _normal_net_from_fixture(dev):
     from ngp_harness.curved import FactorizedNormalNet
