@@ -1089,10 +1089,10 @@ def main():
                 per_frame.sort()
                 t_g = sum(per_frame) / len(per_frame)
                 graphed = {"mpix_per_s": 0.64 / t_g, "ms_per_frame": t_g * 1e3, "ms_per_frame_min_median_max": [per_frame[0] * 1e3, per_frame[5] * 1e3, per_frame[-1] * 1e3],
-                           "host_enqueue_ms": sum(enqueue) / len(enqueue) * 1e3, "iterations_launched": renderer.last_iters, "sample_slots_launched": int(n_g),
+                           "host_ms_inside_the_call": sum(enqueue) / len(enqueue) * 1e3,  # (mostly WAITING for the block-old alive counts, not enqueueing: ~30 graph replays per frame) "iterations_launched": renderer.last_iters, "sample_slots_launched": int(n_g),
                            "max_abs_image_difference_vs_reference_loop": float((img_g - img_ref).abs().max()),
-                           "loop": f"the loop below as HIP graphs: per ray range one graph resets it and one runs 6 iterations (replayed until no ray is left; the host "
-                                   f"learns that one block late from a 4-byte copy), every launch sized for the whole range, n_step = clamp({F} N / alive, {F}, {8 * F}) "
+                           "loop": f"the loop below as HIP graphs: per ray range one graph resets it and one runs 2 iterations (replayed until no ray is left; the host "
+                                   f"learns the alive count one block late from a 4-byte copy and picks the recorded launch size that covers it: all rays, 1/2, 1/4, 1/8, 1/32, ...), n_step = clamp({F} N / alive, {F}, {8 * F}) "
                                    f"derived by the kernels from the alive count on the device (NERFTEX_ROWS_AUTO); {P} ranges side by side; same image bit for bit"}
             except Exception as e:  # noqa: BLE001 -- a side measurement
                 print(f"[bench] graphed inference failed ({type(e).__name__}: {e})", file=sys.stderr)

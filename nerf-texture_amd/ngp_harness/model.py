@@ -531,7 +531,7 @@ class Renderer(nn.Module):
         return image + (1 - weights_sum).unsqueeze(-1) * bg_color, depth, sum(j.n_samples for j in jobs)
 
     @torch.no_grad()
-    def render_infer_graphed(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, max_steps=1024, slots_per_ray=4, parts=3, block=6):
+    def render_infer_graphed(self, rays_o, rays_d, dt_gamma=0.0, bg_color=1, max_steps=1024, slots_per_ray=4, parts=3, block=2):
         """render_infer_pipelined with the HOST taken out of the loop (round 5): per ray range one HIP graph resets the range and one graph runs
         `block` iterations; a frame is parts x (1 + ~3) graph replays instead of parts x ~18 x 12 launches, so the frame time no longer depends
         on how fast the host enqueues (r4: 65 to 84 Mpix/s between a 16-core and a 128-core host for the same device work).  What made the
@@ -575,14 +575,14 @@ class Renderer(nn.Module):
             streams[k].wait_stream(main)
             with torch.cuda.stream(streams[k]):
                 job.g_init.replay()
-            job.pending = []
+            job.pending, job.known = [], job.N  # known: the newest alive count the host has (an upper bound: alive rays never increase)
         max_blocks = -(-int(max_steps) // (int(slots_per_ray) * int(block)))
         active, rounds = list(range(len(jobs))), 0
         while active and rounds < max_blocks:
             for k in list(active):
                 job = jobs[k]
                 with torch.cuda.stream(streams[k]):
-                    job.g_block.replay()
+                    job.graph_for(job.known).replay()
                     slot = rounds % job.ring
                     # the alive count at the START of the block's last iteration (an upper bound of what is left): read by the host one block late
                     job.host[slot:slot + 1].copy_(job.counters[1:2], non_blocking=True)
@@ -591,7 +591,8 @@ class Renderer(nn.Module):
                 if len(job.pending) > 1:
                     s_ = job.pending.pop(0)
                     job.events[s_].synchronize()
-                    if int(job.host[s_]) <= 0:
+                    job.known = min(job.known, int(job.host[s_]))
+                    if job.known <= 0:
                         active.remove(k)
             rounds += 1
         for k in range(len(jobs)):
@@ -600,7 +601,7 @@ class Renderer(nn.Module):
         weights_sum = torch.cat([j.weights_sum for j in jobs])
         depth = torch.cat([j.depth for j in jobs])
         self.last_iters = rounds * int(block)
-        return image + (1 - weights_sum).unsqueeze(-1) * bg_color, depth, rounds * int(block) * sum(j.M for j in jobs)
+        return image + (1 - weights_sum).unsqueeze(-1) * bg_color, depth, rounds * int(block) * sum(j.M for j in jobs)  # (slots of full-size launches: an upper bound)
 
 
 class _InferGraphPart:
@@ -631,6 +632,15 @@ class _InferGraphPart:
         self.host = torch.zeros(self.ring, dtype=torch.int32).pin_memory()
         self.events = [torch.cuda.Event() for _ in range(self.ring)]
         self.g_init = self.g_block = None
+        self.bounds = [N] + [b for b in (N // 2, N // 4, N // 8, N // 32, N // 128, N // 512) if b >= 256]
+
+    def graph_for(self, alive_upper_bound):
+        """The block graph with the smallest launch size that still covers `alive_upper_bound` rays."""
+        best = 0
+        for i, b in enumerate(self.bounds):
+            if b >= alive_upper_bound:
+                best = i
+        return self.g_blocks[best]
 
     def _init_ops(self):
         r = self.r
@@ -641,10 +651,12 @@ class _InferGraphPart:
         self.rays_t[1].copy_(self.nears)
         self.counters.copy_(self.start_counts)
 
-    def _iteration(self, j):
+    def _iteration(self, j, bound):
+        """One iteration recorded for at most `bound` alive rays (the launches' size; the kernels read the true count and derive n_step from it)."""
         from nerftex_hip import check, lib, ptr, stream
 
-        r, N, M = self.r, self.N, self.M
+        r, N = self.r, bound
+        M = (min(self.N * self.F, bound * 8 * self.F) + 127) // 128 * 128  # count * n_step <= min(F N, count * 8 F)
         cur, old = j % 2, (j + 1) % 2
         c, ra, rt = self.counters, self.rays_alive, self.rays_t
         check(lib.nerftex_compact_rays_dev(N, ptr(c[old:]), ptr(ra[cur]), ptr(ra[old]), ptr(rt[cur]), ptr(rt[old]), ptr(c[cur:]), stream()))
@@ -669,10 +681,16 @@ class _InferGraphPart:
             self.g_init = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_init, stream=self.stream, capture_error_mode="thread_local"):
                 self._init_ops()
-            self.g_block = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_block, stream=self.stream, pool=self.g_init.pool(), capture_error_mode="thread_local"):
-                for j in range(self.block):
-                    self._iteration(j)
+            # one block graph per launch size: all rays, then 1/2, 1/4, 1/8, 1/32, ... of them -- the host picks the smallest one that covers the
+            # (one block old) alive count it knows, so the late iterations do not dispatch full-size grids whose workgroups all exit at once
+            self.g_blocks = []
+            for bound in self.bounds:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream, pool=self.g_init.pool(), capture_error_mode="thread_local"):
+                    for j in range(self.block):
+                        self._iteration(j, bound)
+                self.g_blocks.append(g)
+            self.g_block = self.g_blocks[0]
         finally:
             check(lib.nerftex_workspace_capture_set(0))
 
