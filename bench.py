@@ -827,7 +827,7 @@ def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_
     return out
 
 
-def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"):
+def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16", randint_rays=False):
     """A training loop that feeds FRESH rays every step through ngp_harness.accelerate (the one call a trainer adds to the drop-in
     packages: graph replay + fused field + HalfLeafAdam / FusedAmp, or torch's capturable Adam + GradScaler for nn.Linear MLPs).
     group = k > 1: `step_group` -- the loop has the batches of k consecutive steps at a time ([k, N, 3] tensors, copied into the graphs'
@@ -867,6 +867,37 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     else:
         def call(c):
             trainer.step(*pool[c % n_pool], gt[c % n_pool], next_rays=pool[(c + 1) % n_pool])
+    if randint_rays:
+        # NO batch ever repeats (the default loop cycles 8 pre-built batches, so the table's access pattern repeats every 8 steps):
+        # every call draws its pixels with torch.randint on the device -- 4 of 32 orbit views per batch, as scene.train_batch does on the host --
+        # and builds the rays and fresh random target colours there, INSIDE the timed loop (the next call's rays, one call early: next_rays)
+        assert group > 1
+        n_views, per_view, HW = 4, rays // 4, 800
+        rng_np = np.random.default_rng(99)
+        poses = torch.from_numpy(scene.rand_poses(32, 2.0, rng_np)).to(dev)
+        fx, fy, cx, cy = [float(v) for v in scene.intrinsics(HW, HW)]
+        gen = torch.Generator(device=dev).manual_seed(5)
+        state = {}
+
+        def draw():
+            views = torch.randint(0, 32, (group, n_views), device=dev, generator=gen)
+            inds = torch.randint(0, HW * HW, (group, n_views, per_view), device=dev, generator=gen)
+            i = (inds % HW).float() + 0.5
+            j = (inds // HW).float() + 0.5
+            dcam = torch.stack([(i - cx) / fx, (j - cy) / fy, torch.ones_like(i)], -1)
+            dcam = dcam / dcam.norm(dim=-1, keepdim=True)
+            R, t = poses[views][..., :3, :3], poses[views][..., :3, 3]
+            rd = torch.einsum("gvnj,gvij->gvni", dcam, R).reshape(group, rays, 3).contiguous()
+            ro = t[:, :, None, :].expand(group, n_views, per_view, 3).reshape(group, rays, 3).contiguous()
+            return ro, rd, torch.rand(group, rays, 3, device=dev, generator=gen)
+
+        state["cur"] = draw()
+
+        def call(c):  # noqa: F811
+            nxt = draw()
+            ro_, rd_, tg_ = state["cur"]
+            trainer.step_group(ro_, rd_, tg_, next_rays=(nxt[0], nxt[1]))
+            state["cur"] = nxt
     per_call = max(group, 1)
     for c in range((16 + 16 + 48) // per_call):  # priming (full-size buffers, mean count), warm steps, capture, past the first mean_count read-backs
         call(c)
@@ -1139,6 +1170,15 @@ def main():
                               "loss_after_run": r3["loss"]})
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
                 print(f"[bench] accelerate() measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
+        try:  # the headline's loop with rays that never repeat, drawn on the device inside the timed loop
+            r5 = measure_accelerated(args, "ffmlp", 8192, 208, dev, grid, group=4, randint_rays=True)
+            other.append({"workload": "configs[2], the headline's loop with NEVER-REPEATING rays: every call draws its 4 x 8192 pixels with torch.randint on the device (4 of 32 orbit "
+                                      "views per batch) and builds rays and random target colours there, inside the timed loop (the headline cycles 8 pre-built batches)",
+                          "rays_per_batch": 8192, "dtype": "fp16", "value": r5["value"], "unit": "ray-samples/s", "ms_per_step": r5["ms_per_step"], "steps": 208,
+                          "ms_per_step_spread": r5["spread"], "launch": "one replayed HIP graph per 4 steps + their marches ahead on the second stream + ~25 framework launches per call for the ray generation",
+                          "loss_after_run": r5["loss"]})
+        except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
+            print(f"[bench] randint-ray measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
         try:  # the headline's loop (fresh rays, 4 steps per call) with bf16 networks
             r4 = measure_accelerated(args, "ffmlp", 8192, 64, dev, grid, group=4, dtype="bf16")
             other.append({"workload": "configs[2] in bf16 through ngp_harness.accelerate(renderer, steps_per_call=4, amp_dtype=torch.bfloat16).step_group: the headline's loop "
@@ -1289,10 +1329,12 @@ def main():
                 "replicas_identical_after_run": res.get("replicas_identical"), "collective": res.get("collective"), "param_l1_after_run": res.get("param_l1"),
                 "launch": (f"ngp_harness.accelerate(renderer, steps_per_call={args.steps_per_graph}).step_group: FRESH rays every call ([{args.steps_per_graph}, N, 3] tensors "
                            f"copied into the graphs' static buffers), one replayed HIP graph per {args.steps_per_graph} steps (shade + backward + optimizer), the marches of "
-                           f"the next {args.steps_per_graph} batches (handed over one call early) as graphs of their own on a second stream; the baked-pool loop of rounds 1-3 "
-                           "is the first entry of other_config") if fresh is not None else (res["graph"] if res["graph"] else "eager launches"),
+                           f"the next {args.steps_per_graph} batches (handed over one call early) as graphs of their own on a second stream.  The calls cycle 8 PRE-BUILT "
+                           "device batches: the graphs have never seen their contents, but the table's access pattern repeats every 8 steps and ray generation is outside "
+                           "the step (SURVEY 8(d): synthetic, resident inputs); other_config holds the same loop with never-repeating rays drawn by torch.randint inside "
+                           "the timed loop, and the baked-pool loop of rounds 1-3") if fresh is not None else (res["graph"] if res["graph"] else "eager launches"),
                 "headline_loop": "fresh rays through ngp_harness.accelerate" if fresh is not None else "pool of ray batches baked into the graphs",
-                "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16",
+                "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16: the same loop with bf16 networks is in other_config",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
