@@ -7,7 +7,7 @@ The same backward (fixed seeded inputs: samples along rays, fp16 gradients, B = 
 device, with the first three (which must agree).  `--neighbour stream`: a fully fused MLP runs beside it on a second stream of this process.
 `--neighbour process`: a second PROCESS trains on the same GPU meanwhile (tools/determinism_probe.py).  Prints one JSON line.
 
-Round 4: with packed-fp32 instructions in the record builder (the SLP vectorizer's default: `make -C nerf-texture_amd/csrc ab-slp`, then NERFTEX_HIP_LIB=nerf-texture_amd/lib/ab/libnerftex_hip_slp.so) the
+Round 4: with packed-fp32 instructions in the record builder (the SLP vectorizer's default: `make -C nerf-texture_amd/csrc ab-packed`, then NERFTEX_HIP_LIB=nerf-texture_amd/lib/ab/libnerftex_hip_packed.so) the
 `process` case returns a wrong gradient in a few percent of the launches; the shipped build (csrc/Makefile: -fno-slp-vectorize for that file) never."""
 import argparse
 import json
