@@ -37,12 +37,12 @@ import torch  # noqa: E402
 L2_PEAK_BS = 34.5e12  # aggregate L2 bandwidth of the 8 XCDs (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
 # Memory-side bytes per launch of the default workload's hash-grid ops (fp16 table, ~459 k samples), from separate rocprofv3 PMC
-# passes (FETCH_SIZE, WRITE_SIZE; profiles/r04_pmc_grid.txt).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
+# passes (FETCH_SIZE, WRITE_SIZE; profiles/r05_pmc_grid.txt: the bench's own children over the replayed step).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
 # MI355X_MICROARCH.md for wide coalesced streams: here the 8-B record stream) + WRITE_SIZE.  Forward: FETCH_SIZE as reported
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
-TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 127.5e6, "grid_encode_backward": 578.0e6}
-TRAFFIC_PROFILE = "profiles/r04_pmc_grid.txt"
-COMMITTED_STATS = "profiles/r04_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
+TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 85.3e6, "grid_encode_backward": 496.3e6}  # (the FALLBACK only: the run measures them itself, rocprof_traffic)
+TRAFFIC_PROFILE = "profiles/r05_pmc_grid.txt"
+COMMITTED_STATS = "profiles/r05_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
@@ -1127,14 +1127,16 @@ def main():
                                    f"derived by the kernels from the alive count on the device (NERFTEX_ROWS_AUTO); {P} ranges side by side; same image bit for bit"}
             except Exception as e:  # noqa: BLE001 -- a side measurement
                 print(f"[bench] graphed inference failed ({type(e).__name__}: {e})", file=sys.stderr)
-        head_inf = graphed if graphed is not None else {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3}
-        mpix = {"mpix_per_s": head_inf["mpix_per_s"], "ms_per_frame": head_inf["ms_per_frame"], "graphed": graphed,
+        host_form = {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3}
+        use_graphed = graphed is not None and graphed["mpix_per_s"] >= host_form["mpix_per_s"]
+        head_inf = graphed if use_graphed else host_form  # (the faster of the two forms of the same loop in THIS run; both are reported)
+        mpix = {"mpix_per_s": head_inf["mpix_per_s"], "ms_per_frame": head_inf["ms_per_frame"], "mpix_per_s_is": "graphed" if use_graphed else "host_launched", "graphed": graphed,
                 "host_launched": {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3, "samples_per_frame": n_big, "iterations": it_big},
                 "samples_per_frame": n_big, "iterations": it_big,
                 "loop": f"run_cuda's inference loop, no per-iteration host stall (launches sized by an earlier alive count, the true count read on the "
                         f"device: nerftex_*_rays_dev / *_rows), {F} N sample slots per iteration instead of N (n_step = clamp({F} N // n_alive, {F}, {8 * F})), "
                         f"the rays in {P} ranges on their own streams; same image as the reference loop, bit for bit"
-                        + ("; `mpix_per_s` is the graph-replayed form of it (`graphed`), `host_launched` the same loop enqueued launch by launch" if graphed else ""),
+                        + ("; `graphed` is the same loop replayed as HIP graphs (round 5), `host_launched` enqueued launch by launch; `mpix_per_s` = the faster of the two in this run (`mpix_per_s_is`)" if graphed else ""),
                 "reference_schedule_no_stall": {"mpix_per_s": 0.64 / t_pipe, "ms_per_frame": t_pipe * 1e3, "samples_per_frame": n_pipe, "iterations": it_pipe,
                                                 "loop": "the reference's schedule (N slots per iteration), only the host stall removed"},
                 "reference_loop": {"mpix_per_s": 0.64 / t_ref, "ms_per_frame": t_ref * 1e3, "samples_per_frame": n_ref, "iterations": it_ref,
@@ -1236,10 +1238,10 @@ def main():
     kern = per_op(res["replay_us"] if in_replay else res["kernel_us"])
     kern_eager = per_op(res["kernel_us"]) if in_replay else {}
     # what bounds each op, by the counters: the gather is served by the L2s (94 % hits, 128-B lines for 8-B rows): it sits on the
-    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r04_pmc_sq_grid.txt) -- its algorithmic bytes are
+    # L2 -> L1 line rate, not on HBM; the backward's two kernels sit on VALU issue (profiles/r05_pmc_sq_grid.txt) -- its algorithmic bytes are
     # still priced against HBM, the nearest roof the contract names
     BOUND = {"grid_encode_forward": ("l2_line", "the gather is bound by the L2 -> L1 line bandwidth (9.4x line amplification: 128 B moved per 8 B used, 94 % L2 hits; "
-                                                "profiles/r04_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
+                                                "profiles/r05_pmc_l2.txt), not by HBM; `frac` is algorithmic bytes over the HBM peak all the same"),
              "grid_encode_backward": ("hbm", "priced against HBM as the contract asks; by the SQ counters both kernels sit on VALU issue (DESIGN.md 4.1)")}
     dominant = max(kern, key=lambda n: kern[n]["ms"]) if kern else None
     roofline = None
