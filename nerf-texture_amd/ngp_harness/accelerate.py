@@ -64,6 +64,15 @@ class AcceleratedTrainer:
             self.amp, self.scaler = FusedAmp(self.opt), None
             if field.fused_field or bf16:
                 self.amp.attach(field.encoder)  # found_inf raised by the kernels that write the gradients: no separate scan launch
+        elif field.mlp == "torch" and amp_dtype == torch.float16 and self._split_k_layers(field):
+            # configs[1] (nn.Linear MLPs on PyTorch-ROCm; round 5): the same optimizer path as the FFMLP field -- fp16 leaves for the table and the
+            # five weight matrices (SplitKLinear hands its leaf to F.linear under autocast), one Adam launch, the loss scaler's device side in two
+            # launches -- instead of torch's capturable fused Adam + GradScaler: no per-step cast of the 48 MB table, no widening of its gradient
+            from .optim import FusedAmp, HalfLeafAdam
+
+            self.fused = True
+            self.opt = HalfLeafAdam([(field.encoder, "embeddings")] + [(layer, "weight") for layer in self._split_k_layers(field)], lr=lr, betas=betas, eps=eps)
+            self.amp, self.scaler = FusedAmp(self.opt), None
         else:
             self.opt = torch.optim.Adam(field.get_params(lr), betas=betas, eps=eps, fused=True, capturable=self.use_graph)
             self.amp, self.scaler = None, torch.amp.GradScaler("cuda", enabled=amp_dtype in (torch.float16, torch.bfloat16))  # (the table gradient is fp16 either way)
@@ -97,6 +106,14 @@ class AcceleratedTrainer:
         self._ahead = None  # (slot, data_ptr of rays_o, data_ptr of rays_d) of a march started by `next_rays`
         self._side = None
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
+
+    @staticmethod
+    def _split_k_layers(field):
+        """The nn.Linear field's layers when every one of them is a SplitKLinear (at most 7: HalfLeafAdam takes 8 tensors), else []."""
+        from .model import SplitKLinear
+
+        layers = list(field.sigma_net) + list(field.color_net)
+        return layers if layers and len(layers) <= 7 and all(isinstance(m, SplitKLinear) for m in layers) else []
 
     # ---- the two halves of one eager step; mean_count None = the ring's (full-size buffers while it is unknown)
     def _march(self, ro, rd, mean_count=None):

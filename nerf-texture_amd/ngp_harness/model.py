@@ -79,7 +79,11 @@ class SplitKLinear(nn.Linear):
         super().__init__(in_features, out_features, bias=False)
 
     def forward(self, x):
-        return _SplitKLinear.apply(x, self.weight)
+        # under autocast: the fp16 copy an optimizer that keeps 16-bit leaves itself has installed (ngp_harness/optim.py HalfLeafAdam) -- no cast of the
+        # weight per step, fp16 gradient straight into its `.grad` -- as GridEncoder._table / FFMLP._weights do
+        leaf = getattr(self, "half_leaf", None)
+        w = leaf if leaf is not None and torch.is_autocast_enabled() and leaf.dtype == torch.get_autocast_dtype("cuda") else self.weight
+        return _SplitKLinear.apply(x, w)
 
 
 class NGPField(nn.Module):
