@@ -41,7 +41,7 @@ RING = 16
 
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
-                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0):
+                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0, skip_zero_gradient_steps=None):
         from .model import NGPField
 
         field = renderer.field
@@ -89,6 +89,15 @@ class AcceleratedTrainer:
             self._chunks = TableGradChunks(field.encoder, self.pipeline_adam)
             self._chunks.with_amp = True
             self._adam_stream = torch.cuda.Stream(device=self.dev)
+        # skip_zero_gradient_steps (fused field; round 5): the MLP backward kernels skip the 32-row steps whose incoming gradients are all zero -- exact,
+        # and in a trained scene most steps (the samples behind the point where a ray's transmittance has underflowed get exactly zero from the
+        # compositing backward), but a 9 % tax on those kernels while the field is young and every sample carries a gradient
+        # (profiles/r05_ffmlp_skip_zero.json).  A library knob (ffmlp_bwd_skip_zero), process-wide; the kernels are chosen at launch, so it must be
+        # set BEFORE the graphs are recorded: None leaves it as it is, True / False set it here.
+        if skip_zero_gradient_steps is not None:
+            import nerftex_hip
+
+            nerftex_hip.check(nerftex_hip.lib.nerftex_tune_set(b"ffmlp_bwd_skip_zero", int(bool(skip_zero_gradient_steps))))
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
         self._graphs, self._M = None, 0
         # steps_per_call = k > 1: `step_group` takes the batches of k consecutive steps at once and replays ONE graph for their shade + backward +

@@ -228,8 +228,8 @@ def test_pipelined_adam_gives_the_parameters_of_the_single_update(dev):
 
 
 # ------------------------------------------------------------------------------------------------- zero-gradient steps of the field backward
-def test_field_backward_skips_all_zero_steps_without_changing_anything(dev):
-    """nerftex_field_backward: 32-row steps whose incoming gradients (grad_sigma, grad_rgbs) are all zero are skipped by both MLP backward kernels.
+def test_field_backward_skips_all_zero_steps_without_changing_anything(dev, knobs):
+    """nerftex_field_backward with the knob ffmlp_bwd_skip_zero: 32-row steps whose incoming gradients (grad_sigma, grad_rgbs) are all zero are skipped by both MLP backward kernels.
     Per row the result must be what it is without the skip: rows with a gradient bit-identical to a run in which every row has one, rows
     without exactly zero in grad_x, and the weight gradients those of the rows that have a gradient (the zero rows add nothing)."""
     from nerftex_hip import check, lib, ptr, stream
@@ -240,16 +240,16 @@ def test_field_backward_skips_all_zero_steps_without_changing_anything(dev):
     field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
     torch.manual_seed(1)
     field.encoder.embeddings.data.uniform_(-1, 1)
-    B = 128 * 64
+    B = 128 * 160  # (>= 16384: the hash-grid backward's deterministic large-batch path; smaller batches use fp16 atomics, whose order is not fixed)
     g = torch.Generator(device=dev).manual_seed(2)
     x = (torch.rand(B, 3, device=dev, generator=g) * 2 - 1) * 1.9
     d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g), dim=-1)
     gs_full = torch.randn(B, device=dev, generator=g) * 1e-2
     gc_full = torch.randn(B, 3, device=dev, generator=g) * 1e-2
-    # gradient only on rows [0, 1000) and [5000, 5100): whole 32-row steps (and whole 128-row workgroup steps) in between carry none
+    # gradient only on rows [0, 1000) and [12000, 12100): whole 32-row steps (and whole 128-row workgroup steps) in between carry none
     keep = torch.zeros(B, dtype=torch.bool, device=dev)
     keep[:1000] = True
-    keep[5000:5100] = True
+    keep[12000:12100] = True
 
     def run(gs, gc):
         for p in field.parameters():
@@ -260,9 +260,15 @@ def test_field_backward_skips_all_zero_steps_without_changing_anything(dev):
             torch.autograd.backward([sigma, rgbs], [gs, gc])
         return field.encoder.embeddings.grad.clone(), field.sigma_net.weights.grad.clone(), field.color_net.weights.grad.clone()
 
-    gt_full, _, _ = run(gs_full, gc_full)
+    knobs(ffmlp_bwd_skip_zero=1)
+    gt_full, gws_full, gwc_full = run(gs_full, gc_full)
     gs, gc = gs_full * keep, gc_full * keep.unsqueeze(-1)
     gt, gws, gwc = run(gs, gc)
+    knobs(ffmlp_bwd_skip_zero=0)
+    gt_full0, gws_full0, gwc_full0 = run(gs_full, gc_full)  # nothing to skip: the two kernel forms agree bit for bit
+    assert torch.equal(gt_full, gt_full0) and torch.equal(gws_full, gws_full0) and torch.equal(gwc_full, gwc_full0)
+    gt0, gws0, gwc0 = run(gs, gc)  # ... and on the masked gradients
+    assert torch.equal(gt, gt0) and torch.equal(gws, gws0) and torch.equal(gwc, gwc0)
     # reference for the masked gradients: the six-launch form of the same backward (glue kernels + the generic MLP backward kernels, which have no
     # skip; ngp_harness/fused.py FIELD_BACKWARD_FUSED = False -- bit-identical to the fused form by construction, tests/test_gpu_field_glue.py)
     from ngp_harness import fused
