@@ -91,8 +91,8 @@ class AcceleratedTrainer:
             self._adam_stream = torch.cuda.Stream(device=self.dev)
         # skip_zero_gradient_steps (fused field; round 5): the MLP backward kernels skip the 32-row steps whose incoming gradients are all zero -- exact,
         # and in a trained scene most steps (the samples behind the point where a ray's transmittance has underflowed get exactly zero from the
-        # compositing backward), but a 9 % tax on those kernels while the field is young and every sample carries a gradient
-        # (profiles/r05_ffmlp_skip_zero.json).  A library knob (ffmlp_bwd_skip_zero), process-wide; the kernels are chosen at launch, so it must be
+        # compositing backward), but a 9 % tax on those kernels while the field is young and every sample carries a gradient, and a gain of only
+        # 11 % when 99 % of the steps are skipped (they have paid for their loads already): profiles/r05_ffmlp_skip_zero.json.  An A/B, not advice.  A library knob (ffmlp_bwd_skip_zero), process-wide; the kernels are chosen at launch, so it must be
         # set BEFORE the graphs are recorded: None leaves it as it is, True / False set it here.
         if skip_zero_gradient_steps is not None:
             import nerftex_hip
