@@ -31,9 +31,9 @@
 
 #pragma clang fp contract(fast)  // ... restored: the MLP kernels were written and measured with the default
 
-// The kernels are written against a storage type `elem_t` and compiled twice: fp16 (the reference's only mode, ffmlp/src/utils.h:23) and
-// bf16 (BASELINE.json configs[2] names bf16; same exponent range as fp32, so no loss scaling, 8 significand bits instead of 11).
-// Accumulation is fp32 on the matrix cores either way.
+// The kernels are written against a storage type `elem_t` (ffmlp_body.inc) and compiled twice: here for fp16 (the reference's only mode,
+// ffmlp/src/utils.h:23) and in ffmlp_bf16.hip for bf16 (BASELINE.json configs[2] names bf16; 8 significand bits instead of 11) -- two
+// translation units since round 5, so that the two three-minute compiles run side by side.  Accumulation is fp32 on the matrix cores either way.
 namespace nerftex {
 namespace ffmlp_f16 {
 namespace {
@@ -48,18 +48,6 @@ __device__ __forceinline__ float4_t mfma16(const elem8_t& a, const elem8_t& b, c
 }  // namespace
 }  // namespace ffmlp_f16
 
-namespace ffmlp_bf16 {
-namespace {
-using elem_t = __bf16;
-constexpr bool kElemIsHalf = false;
-typedef __bf16 elem4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 elem8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ float4_t mfma16(const elem8_t& a, const elem8_t& b, const float4_t& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-#include "ffmlp_body.inc"
-}  // namespace
-}  // namespace ffmlp_bf16
 }  // namespace nerftex
 
 using namespace nerftex;
@@ -103,23 +91,12 @@ extern "C" int nerftex_field_backward_amp(const float* grad_sigma, const float* 
     return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                            grad_sigma_weights, grad_color_weights, found_inf, stream);
 }
-extern "C" int nerftex_field_forward_bf16(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
-                                          float* sigma, float* rgbs, void* x_rows, void* h, void* cin, void* hc, void* stream) {
-    return ffmlp_bf16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, x_rows, h, cin, hc, nullptr, 0, stream);
-}
-extern "C" int nerftex_field_backward_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
-                                           const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
-                                           void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream) {
-    return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
-                                            grad_sigma_weights, grad_color_weights, found_inf, stream);
-}
 extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
                                           float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {
     return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, nullptr, nullptr, nullptr, nullptr, units_dev,
                                           rows_per_unit, stream);
 }
 NERFTEX_FFMLP_ENTRIES(, ffmlp_f16)        // the reference's exports (ffmlp/src/bindings.cpp:5-10)
-NERFTEX_FFMLP_ENTRIES(_bf16, ffmlp_bf16)  // extension: the same three on bf16 tensors
 #undef NERFTEX_FFMLP_ENTRIES
 
 // ffmlp.cu:711-740 creates num_layers+1 side streams + events for the split-K GEMMs.  Nothing to create here:

@@ -15,8 +15,9 @@ SOURCES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.
 KERNEL_OF = {
     "gridencoder_binned": "bin_fill_dir_kernel", "gridencoder": "grid_forward_level_kernel", "raymarching": "march_count_parallel_kernel",
     "raytracer": "raytrace_kernel", "shencoder": "sh_forward_kernel", "occupancy": "kernel", "trainstep": "adam_half_kernel",
-    "fieldglue": "kernel", "knn": "knn_query_kernel", "ffmlp": "ffmlp_backward_fused_kernel", "runtime": None,
+    "fieldglue": "kernel", "knn": "knn_query_kernel", "ffmlp": "ffmlp_backward_fused_kernel", "ffmlp_bf16": "ffmlp_backward_fused_kernel", "runtime": None,
 }
+MFMA_SOURCES = ("ffmlp", "ffmlp_bf16")  # the two instantiations of ffmlp_body.inc: minutes to compile; covered by the command-line check and the binary's disassembly
 # every packed-fp32 opcode gfx950 has (the `packed-fp32-ops` target feature): v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32, v_pk_mov_b32
 PACKED_FP32 = re.compile(r"\bv_pk_(?:[a-z]+_f32|mov_b32)\b")
 
@@ -48,7 +49,8 @@ def test_every_translation_unit_is_compiled_with_the_packed_fp32_feature_off(sou
     disassembly of the built library below)"""
     cmd = _compile_line(source)
     assert "-target-feature -Xclang -packed-fp32-ops" in " ".join(cmd), cmd
-    assert ("-fno-slp-vectorize" in cmd and "-disable-vector-combine" in cmd) == (source != "ffmlp"), cmd
+    assert ("-fno-slp-vectorize" in cmd and "-disable-vector-combine" in cmd) == (source not in MFMA_SOURCES), cmd
+    assert ("-amdgpu-mfma-vgpr-form" in cmd) == (source in MFMA_SOURCES), cmd
 
 
 def test_the_built_library_contains_no_packed_fp32_instruction():
@@ -71,7 +73,7 @@ def test_the_built_library_contains_no_packed_fp32_instruction():
         assert n_inst > 1_000_000  # (the disassembly really is the library's: ~1.5 M instructions)
 
 
-@pytest.mark.parametrize("source", [s for s in SOURCES if s != "ffmlp"])
+@pytest.mark.parametrize("source", [s for s in SOURCES if s not in MFMA_SOURCES])
 def test_no_translation_unit_contains_packed_fp32(source):
     """csrc/Makefile: NO v_pk_*_f32 / v_pk_mov_b32 anywhere in the library.  Round 4: with them the hash-grid backward's record builder and the
     gather's input-gradient branch were not reproducible when other kernels shared the GPU (tests/test_gpu_dp_shared_gpu.py has the GPU side);
