@@ -332,3 +332,53 @@ def raytrace(vertices, triangles, rays_o, rays_d):
     second = np.zeros(N, np.float32)
     lib().orc_raytrace(_p(v), _p(f), u32(f.shape[0]), _p(o), _p(d), u32(N), _p(pos), _p(nrm), _p(depth), _p(face), _p(second))
     return pos, nrm, depth, face, second
+
+
+# ------------------------------------------------------------------ the occupancy draw of the LIBRARY (not of the reference)
+# The reference draws its partial-update cells with torch.randint / torch.rand (renderer.py:604-628): a generator stream no other implementation
+# can reproduce, so parity for the update is pinned through explicit picks (rand_coords / rand_pick / noise, tests/test_gpu_occupancy.py).  What is
+# restated here is the library's OWN draw for the graph-capturable path (include/nerftex_hip.h: nerftex_occupancy_sample_partial[_ordered] with
+# NULL picks) -- a counter hash and two pick rules -- so that the device's picks have a known answer on the host: checker only, like the rest.
+def counter_uniform01(seed, counter):
+    """24-bit uniform in [0, 1) of (seed, counter): xorshift-multiply finaliser over seed ^ golden + counter * odd."""
+    with np.errstate(over="ignore"):
+        s = (np.uint64(seed) ^ np.uint64(0x9E3779B97F4A7C15)) + np.asarray(counter, np.uint64) * np.uint64(0xD1342543DE82EF95)
+        for _ in range(2):
+            s = s ^ (s >> np.uint64(32))
+            s = s * np.uint64(0xD6E8FEB86659FD93)
+        s = s ^ (s >> np.uint64(32))
+    return (s >> np.uint64(40)).astype(np.uint32).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def occupancy_partial_draw(seed, cascade, H, N, occupied, stratified):
+    """(indices [cascade, 2N] int32, jitter [cascade * 2N, 3] float32 in [0,1)) of the library's partial draw.
+
+    occupied[c]: ascending Morton indices of cascade c's cells with density > 0 (renderer.py:613).  Row r = c * 2N + j; j < N is the uniform half
+    (renderer.py:604-606), j >= N the occupied half (renderer.py:609-619), -1 when the cascade has no occupied cell yet."""
+    H3 = H ** 3
+    f32 = np.float32
+    rows = np.arange(cascade * 2 * N, dtype=np.uint64).reshape(cascade, 2 * N)
+    out = np.empty((cascade, 2 * N), np.int32)
+    uni_rows = rows[:, :N]
+    seed_u, seed_o = int(seed) ^ 0xA5A5, int(seed) ^ 0x5A5A
+    if stratified:
+        per = H3 // N
+        k = np.minimum(per - 1, (counter_uniform01(seed_u, uni_rows * np.uint64(3)) * f32(per)).astype(np.uint32))
+        out[:, :N] = (np.arange(N, dtype=np.uint32)[None] * np.uint32(per) + k).astype(np.int32)
+    else:
+        c3 = [np.minimum(H - 1, (counter_uniform01(seed_u, uni_rows * np.uint64(3) + np.uint64(d)) * f32(H)).astype(np.uint32)) for d in range(3)]
+        out[:, :N] = morton3D(np.stack(c3, -1).reshape(-1, 3).astype(np.int32)).reshape(cascade, N)
+    for c in range(cascade):
+        occ = np.asarray(occupied[c], np.int64)
+        n = occ.shape[0]
+        if n == 0:
+            out[c, N:] = -1
+            continue
+        u = (counter_uniform01(seed_o, rows[c, N:]) * f32(n)).astype(np.uint32).astype(np.uint64)
+        if stratified:
+            k = np.minimum(n - 1, (np.arange(N, dtype=np.uint64) * np.uint64(n) + u) // np.uint64(N))
+        else:
+            k = np.minimum(n - 1, u)
+        out[c, N:] = occ[k.astype(np.int64)]
+    jitter = counter_uniform01(seed, (rows.reshape(-1, 1) * np.uint64(3) + np.arange(3, dtype=np.uint64)[None]))
+    return out, jitter.astype(np.float32)

@@ -117,12 +117,13 @@ class _Owner(torch.nn.Module):
         self.weights = torch.nn.Parameter(torch.randn(shape, generator=gen) * 0.3)
 
 
-def _half_leaf_setup(seed_shift):
+def _half_leaf_setup(seed_shift, second_leaf=torch.float16):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_half_adam import CpuFusedAmp, CpuHalfLeafAdam
 
     a, b = _Owner((16, 8), 1 + seed_shift), _Owner((3, 16), 2 + seed_shift)
-    opt = CpuHalfLeafAdam([(a, "weights"), (b, "weights")], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    # (second_leaf bf16: the mixed set of the bf16 fused field -- fp16 table leaf, bf16 MLP leaves -- accelerate.py)
+    opt = CpuHalfLeafAdam([(a, "weights"), (b, "weights", second_leaf)], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
     amp = CpuFusedAmp(opt, init_scale=2.0 ** 14, growth_interval=2)
     return a, b, opt, amp
 
@@ -134,20 +135,20 @@ def _half_leaf_steps(a, b, opt, amp, x, y, n_steps, loss_mul, exchange, poison_s
         h = torch.relu(x @ a.half_leaf.float().t()) @ b.half_leaf.float().t()
         loss = torch.nn.functional.mse_loss(h, y) * loss_mul
         amp.scale_loss(loss).backward()
-        assert all(leaf.grad.dtype == torch.float16 for leaf in opt.leaves)
+        assert all(leaf.grad.dtype == leaf.dtype and leaf.dtype in (torch.float16, torch.bfloat16) for leaf in opt.leaves)
         if poison and k == poison_step:
             opt.leaves[0].grad[0, 0] = float("inf")  # ONE rank overflows: after the exchange every rank must see it and skip
         exchange()
         amp.step()
 
 
-def _half_leaf_worker(rank, world, port, q, wire):
+def _half_leaf_worker(rank, world, port, q, wire, second_leaf=torch.float16):
     sys.path.insert(0, os.path.join(ROOT, "nerf-texture_amd"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from ngp_harness import dp
 
     dp.init_from_env(backend="gloo")
-    a, b, opt, amp = _half_leaf_setup(seed_shift=10 * rank)  # different init per rank: the broadcast must fix it
+    a, b, opt, amp = _half_leaf_setup(10 * rank, second_leaf)  # different init per rank: the broadcast must fix it
     dp.broadcast([a.weights.data, b.weights.data])
     opt.resync()
     red = dp.FlatGradAllReduce(opt.trainable(), average=False, big_numel=0, big_comm_dtype=wire)  # bench.py's construction for the fused optimizer
@@ -195,6 +196,38 @@ def test_n_rank_half_leaf_adam_matches_single_process(wire, world):
     # (world 8: eight shard gradients, each rounded to fp16, and on the fp16 wire a chain of seven more roundings)
     bar = 4 * 1e-2 * (2e-3 if wire is not None else 4e-3) * (1 if world == 2 else 2)
     assert np.abs(m0 - ref).max() <= bar, (float(np.abs(m0 - ref).max()), bar)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wire", [torch.float32, None], ids=["fp32-wire", "leaf-dtype-wire"])
+def test_two_rank_mixed_fp16_bf16_leaves_match_single_process(wire):
+    """The leaf set of the bf16 fused field (one fp16 leaf, one bf16 leaf in ONE HalfLeafAdam; optim.py bf16_mask) under gloo: replicas stay
+    bit-identical, the overflow seen by one rank skips the step on both, and the result is the single-process one to bf16 rounding."""
+    import numpy as np
+
+    world = 2
+    port = 29950 + os.getpid() % 300 + 411 + (17 if wire is None else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_half_leaf_worker, args=(r, world, port, q, wire, torch.bfloat16)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, m0, l0, s0, c0), (_, m1, l1, s1, c1) = results
+    assert (m0 == m1).all() and (l0 == l1).all() and s0 == s1 and c0 == c1 == 4.0
+    a, b, opt, amp = _half_leaf_setup(0, torch.bfloat16)
+    assert opt.leaves[0].dtype == torch.float16 and opt.leaves[1].dtype == torch.bfloat16 and opt.bf16_mask == 0b10
+    torch.manual_seed(123)
+    x, y = torch.randn(64, 8), torch.randn(64, 3)
+    _half_leaf_steps(a, b, opt, amp, x, y, 5, 1.0, lambda: None, poison_step=2, poison=True)
+    ref = torch.cat([a.weights.detach().reshape(-1), b.weights.detach().reshape(-1)]).numpy()
+    assert amp.get_scale() == s0 and float(opt.step_count) == 4.0
+    # the bf16 leaf's shard gradients are rounded to 8 bits before the sum: 2^-8 relative on Adam's normalised step, 4 steps x lr, and the
+    # forward of later steps reads a bf16 weight -- 4 x 1e-2 x 1.6e-2
+    assert np.abs(m0 - ref).max() <= 4 * 1e-2 * 1.6e-2, float(np.abs(m0 - ref).max())
 
 
 def test_shard_covers_batch():

@@ -451,6 +451,40 @@ def test_stratified_partial_occupancy_draw_is_ordered_and_covers_every_stratum(d
     assert len(torch.unique(idx[0, :N])) == N  # N distinct cells (iid draws with replacement name ~0.885 N)
 
 
+@pytest.mark.parametrize("stratified", [1, 0])
+def test_library_occupancy_draw_has_a_known_answer_on_the_host(dev, oracle, stratified):
+    """The draw the library makes itself (NULL picks: the graph-capturable update) against oracle.occupancy_partial_draw, the numpy restatement of
+    its counter hash and pick rules: cell indices bit-exact; and the positions equal to those of the SAME picks handed in explicitly -- the path
+    tests/test_gpu_occupancy.py pins against renderer.py:592-628."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    H, cas, bound, seed = 64, 3, 4.0, 1234567
+    H3, N = H ** 3, H ** 3 // 4
+    g = torch.Generator(device=dev).manual_seed(11)
+    grid = torch.where(torch.rand(cas, H3, device=dev, generator=g) < 0.05, torch.rand(cas, H3, device=dev, generator=g) * 20, torch.zeros(cas, H3, device=dev))
+    grid[1, H3 // 3:] = 0
+    grid[2] = -1.0  # a cascade without an occupied cell: renderer.py:617
+    idx = torch.empty(cas, 2 * N, dtype=torch.int32, device=dev)
+    xyz = torch.empty(cas * 2 * N, 3, dtype=torch.float32, device=dev)
+    n_occ = torch.zeros(cas, dtype=torch.int32, device=dev)
+    check(lib.nerftex_occupancy_sample_partial_ordered(ptr(grid), cas, H, bound, N, None, None, None, seed, ptr(idx), ptr(xyz), ptr(n_occ), stratified, stream()))
+    occupied = [np.nonzero(grid[c].cpu().numpy() > 0)[0] for c in range(cas)]
+    want, jitter = oracle.occupancy_partial_draw(seed, cas, H, N, occupied, bool(stratified))
+    assert n_occ.tolist() == [len(o) for o in occupied]
+    assert np.array_equal(idx.cpu().numpy(), want)
+    # the same picks, explicit
+    coords = torch.from_numpy(oracle.morton3D_invert(want[:, :N].reshape(-1))).to(dev).view(cas, N, 3).contiguous()
+    pick = np.zeros((cas, N), np.int32)
+    for c in range(cas):
+        if len(occupied[c]):
+            pick[c] = np.searchsorted(occupied[c], want[c, N:])
+    pick = torch.from_numpy(pick).to(dev)
+    noise = torch.from_numpy(jitter).to(dev)
+    idx2, xyz2 = torch.empty_like(idx), torch.empty_like(xyz)
+    check(lib.nerftex_occupancy_sample_partial_ordered(ptr(grid), cas, H, bound, N, ptr(coords), ptr(pick), ptr(noise), 0, ptr(idx2), ptr(xyz2), None, stratified, stream()))
+    assert torch.equal(idx, idx2) and torch.equal(xyz, xyz2)
+
+
 # ------------------------------------------------------------------------------------------------- the hazard gate
 def _probe(name):
     p = os.path.join(ROOT, "tools", "probes", "_bin", name)

@@ -152,3 +152,34 @@ def test_grid_offsets_match_reference(oracle, golden_dir):
     assert fox["rows"] == 6328848  # align_corners=False: (res+1)^3 dense levels
     fox_a = [c for c in cases if c["name"] == "fox_bound2_align"][0]
     assert fox_a["rows"] == 6299960  # what get_encoder() (align_corners=True) builds for the fox config
+
+
+def test_counter_hash_of_the_library_draw_is_uniform_and_pinned(oracle):
+    """oracle.counter_uniform01 / occupancy_partial_draw (the restatement of the LIBRARY's own occupancy draw; the GPU test compares the device
+    against it): pinned first values, 24-bit range, flat histogram, and the stratified rule's invariants."""
+    def by_hand(seed, counter):  # the same hash in Python integers, masked to 64 bits
+        m = (1 << 64) - 1
+        s = ((seed ^ 0x9E3779B97F4A7C15) + counter * 0xD1342543DE82EF95) & m
+        for _ in range(2):
+            s ^= s >> 32
+            s = (s * 0xD6E8FEB86659FD93) & m
+        s ^= s >> 32
+        return s >> 40
+
+    u = oracle.counter_uniform01(5, np.arange(4))
+    assert (u * 16777216).astype(np.uint32).tolist() == [13095836, 11211981, 1805957, 12649101] == [by_hand(5, c) for c in range(4)]
+    far = [(1 << 63) + 12345, (1 << 40) * 3 + 7]
+    assert (oracle.counter_uniform01(2 ** 64 - 3, np.array(far, np.uint64)) * 16777216).astype(np.uint32).tolist() == [by_hand(2 ** 64 - 3, c) for c in far]
+    big = oracle.counter_uniform01(99, np.arange(1 << 20))
+    assert big.min() >= 0 and big.max() < 1 and big.dtype == np.float32
+    hist = np.histogram(big, 64, (0, 1))[0]
+    assert abs(hist - (1 << 14)).max() < 6 * np.sqrt(1 << 14)
+    H, cas = 16, 2
+    N = H ** 3 // 4
+    occupied = [np.arange(0, H ** 3, 7), np.zeros(0, np.int64)]
+    idx, jit = oracle.occupancy_partial_draw(5, cas, H, N, occupied, True)
+    assert np.array_equal(idx[:, :N] // 4, np.tile(np.arange(N), (cas, 1)))
+    assert np.all(np.diff(idx[0, N:]) >= 0) and np.all(idx[0, N:] % 7 == 0) and np.all(idx[1, N:] == -1)
+    assert jit.shape == (cas * 2 * N, 3)
+    idx_iid, _ = oracle.occupancy_partial_draw(5, cas, H, N, occupied, False)
+    assert idx_iid.min() >= -1 and idx_iid.max() < H ** 3 and np.all(idx_iid[0, N:] % 7 == 0)
