@@ -1102,9 +1102,9 @@ def main():
         # round 5: the same loop with the host taken out (Renderer.render_infer_graphed: per ray range one graph per block of iterations, n_step derived
         # on the device); per-frame times over 10 frames, and the host's own share (time spent enqueueing, before the final synchronise)
         graphed = None
-        if use_amp and res["dtype"] == "fp16" and getattr(field, "fused_field", False):
+        if use_amp and ((res["dtype"] == "fp16" and getattr(field, "fused_field", False)) or (res["dtype"] == "bf16" and getattr(field, "fused_field_bf16", False))):
             try:
-                with torch.autocast("cuda", dtype=torch.float16):
+                with torch.autocast("cuda", dtype=torch.bfloat16 if res["dtype"] == "bf16" else torch.float16):
                     render_g = lambda: renderer.render_infer_graphed(ro, rd, dt_gamma=dt_gamma, slots_per_ray=F, parts=P)  # noqa: E731
                     img_g, _, n_g = render_g()  # records the graphs
                     render_g()

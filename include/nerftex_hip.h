@@ -331,6 +331,13 @@ int nerftex_field_forward_bf16(const void* feats_lbc, const float* dirs, const v
 int nerftex_field_backward_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
                                 const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                                 void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream);
+/* ... and the two no-grad forms of the bf16 field: the density query of the occupancy-grid update (nerftex_field_density) and the inference
+ * iteration sized by a device count (nerftex_field_forward_rows, declared below), weights bf16, feats_lbc fp16, outputs fp32.  Same values as
+ * nerftex_field_forward_bf16's sigma / (sigma, rgbs) on the rows they compute. */
+int nerftex_field_density_bf16(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream);
+int nerftex_field_forward_rows_bf16(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                                    uint32_t B, float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit,
+                                    void* stream);
 
 /* Extension (round 4): the table gradient in PARTS, for a data-parallel caller that exchanges it level group by level group: the
  * all-reduce of the rows of levels [lo, hi) can start as soon as those levels are summed, while the later levels are still being summed
@@ -355,7 +362,7 @@ int nerftex_grid_encode_backward_phase_amp(const void* grad, const float* inputs
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).
  *   feats_lbc [16, B, 2] half (nerftex_grid_encode_forward*, NERFTEX_LAYOUT_LBC), sigma_weights as nerftex_field_forward's,
- *   sigma [B] float out.  Same values as nerftex_field_forward's sigma.  B % 128 == 0; fp16 only. */
+ *   sigma [B] float out.  Same values as nerftex_field_forward's sigma.  B % 128 == 0; fp16 weights (bf16: nerftex_field_density_bf16). */
 int nerftex_field_density(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream);
 
 

@@ -54,5 +54,13 @@ extern "C" int nerftex_field_backward_bf16(const float* grad_sigma, const float*
     return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                             grad_sigma_weights, grad_color_weights, found_inf, stream);
 }
+extern "C" int nerftex_field_density_bf16(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream) {
+    return ffmlp_bf16::field_density_entry(feats_lbc, sigma_weights, B, sigma, stream);
+}
+extern "C" int nerftex_field_forward_rows_bf16(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
+                                               float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {
+    return ffmlp_bf16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, nullptr, nullptr, nullptr, nullptr, units_dev,
+                                           rows_per_unit, stream);
+}
 NERFTEX_FFMLP_ENTRIES(_bf16, ffmlp_bf16)  // extension: the reference's three exports on bf16 tensors
 #undef NERFTEX_FFMLP_ENTRIES

@@ -66,14 +66,8 @@ template <typename T> constexpr uint32_t row_bits() { return sizeof(T) == 2 ? 12
 static_assert(kMaxTilesPerLevel == 2 * kWave, "K3d scans one level's tiles with one wave, two tiles per lane");
 static_assert(rows_per_tile<half_t>() == (1u << row_bits<half_t>()) && rows_per_tile<float>() <= (1u << row_bits<float>()), "local row field");
 
-// ---- fp16 <-> 2^-24 fixed point ------------------------------------------------------------------------------------
+// ---- 2^-24 fixed point -> fp16 ------------------------------------------------------------------------------------
 // every finite half is m * 2^-24 with |m| < 2^40; inf / nan map to >= 2^40 and come back as inf
-__device__ __forceinline__ long long half_to_fixed(half_t h) {
-    const uint32_t b = __builtin_bit_cast(uint16_t, h);
-    const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
-    const unsigned long long mag = e ? (unsigned long long)(f | 1024u) << (e - 1u) : (unsigned long long)f;
-    return (b & 0x8000u) ? -(long long)mag : (long long)mag;
-}
 // round-to-nearest-even of s * 2^-24 to half, overflow -> inf.  The magnitude is first cut to 24 significant bits with the lost bits
 // OR-ed into the last one (round to odd): that float is exact, and the ONE rounding v_cvt_f16_f32 then applies (11 bits or fewer,
 // subnormals and overflow included) is the correct rounding of the integer -- checked against the shift-and-compare form on 5e7 values

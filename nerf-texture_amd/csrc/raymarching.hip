@@ -362,11 +362,6 @@ __device__ __forceinline__ float ray_t0(const Dda& s, float near, uint32_t pertu
     return t0;
 }
 
-__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t* __restrict__ p, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
-}
-
 // ------------------------------------------------------------------------------------------------
 // R6 count pass, data-parallel form
 // ------------------------------------------------------------------------------------------------

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "nerftex_adam_mixed_step_amp": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i, _vp],
     "nerftex_amp_check_mixed": [_i, _vp, _vp, _u32, _vp, _vp],
     "nerftex_field_forward_bf16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_density_bf16": [_vp, _vp, _u32, _vp, _vp],
+    "nerftex_field_forward_rows_bf16": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "nerftex_field_backward_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_table_adam_step": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "nerftex_tune_set": [C.c_char_p, C.c_long],

@@ -93,10 +93,11 @@ class _ngp_field(Function):
         # mlp_dtype bf16 (round 5): the two networks, their saved rows and their weight gradients are bf16 (nerftex_field_*_bf16); the table, the
         # gathered features and dL/dfeatures stay fp16 (the table is fp16 under any autocast, gridencoder/grid.py:38-41)
         bf16 = mlp_dtype == torch.bfloat16
-        assert mlp_dtype in (torch.float16, torch.bfloat16) and not (bf16 and live is not None)
+        assert mlp_dtype in (torch.float16, torch.bfloat16)
         ws_h = ws if ws.dtype == mlp_dtype else ws.to(mlp_dtype)
         wc_h = wc if wc.dtype == mlp_dtype else wc.to(mlp_dtype)
         field_forward = lib.nerftex_field_forward_bf16 if bf16 else lib.nerftex_field_forward
+        field_forward_rows = lib.nerftex_field_forward_rows_bf16 if bf16 else lib.nerftex_field_forward_rows
         S, H, gridtype, align, bound = float(np.log2(enc.per_level_scale)), int(enc.base_resolution), int(enc.gridtype_id), int(bool(enc.align_corners)), enc_bound(enc)
         dev = x.device
         feats = torch.empty(L, B, C, dtype=torch.float16, device=dev)
@@ -109,8 +110,7 @@ class _ngp_field(Function):
             assert units.dtype == torch.int32 and units.device == dev
             check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, gridtype, align, F16, LAYOUT_LBC,
                                                        affine[0], affine[1], ptr(units), int(rows_per_unit), stream()))
-            check(lib.nerftex_field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(units), int(rows_per_unit),
-                                                 stream()))
+            check(field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), ptr(units), int(rows_per_unit), stream()))
             ctx.set_materialize_grads(False)
             return sigma, rgbs
         check(lib.nerftex_grid_encode_forward_affine(ptr(x), ptr(table_h), ptr(offsets), ptr(feats), B, D, C, L, S, H, 0, ptr(dummy), gridtype, align, F16,
@@ -204,10 +204,10 @@ class _ngp_field(Function):
 _INFER_CACHE = {}
 
 
-def ngp_field_infer(x, dirs, encoder, sigma_net, color_net, bound, live=None):
+def ngp_field_infer(x, dirs, encoder, sigma_net, color_net, bound, live=None, mlp_dtype=torch.float16):
     """The no-grad form of `ngp_field` for a loop that calls it a few dozen times per frame: two launches and nothing else -- the level
-    constants and the fp16 copies of the MLP weights are kept between calls (re-made when a parameter changes), no autograd node.
-    x [B,3] fp32 contiguous, dirs [B,3] fp32 contiguous, B % 128 == 0; call under autocast(float16)."""
+    constants and the fp16 (mlp_dtype bf16: bf16) copies of the MLP weights are kept between calls (re-made when a parameter changes), no
+    autograd node.  x [B,3] fp32 contiguous, dirs [B,3] fp32 contiguous, B % 128 == 0; call under autocast(mlp_dtype)."""
     import numpy as np
 
     from nerftex_hip import F16, LAYOUT_LBC
@@ -217,14 +217,14 @@ def ngp_field_infer(x, dirs, encoder, sigma_net, color_net, bound, live=None):
     B, dev = x.shape[0], x.device
     table_h = encoder._table()
     ws, wc = sigma_net._weights(), color_net._weights()
-    key = id(encoder)
+    key = (id(encoder), mlp_dtype)
     c = _INFER_CACHE.get(key)
     stamp = (ws._version, ws.data_ptr(), wc._version, wc.data_ptr(), float(bound), encoder.offsets.data_ptr())
     if c is None or c[0] != stamp:
         L = encoder.offsets.shape[0] - 1
         register_offsets(encoder.offsets, L)
         c = (stamp, L, float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), int(encoder.gridtype_id), int(bool(encoder.align_corners)),
-             float(bound), float(np.float32(1.0) / np.float32(2 * bound)), ws.detach().to(torch.float16), wc.detach().to(torch.float16))
+             float(bound), float(np.float32(1.0) / np.float32(2 * bound)), ws.detach().to(mlp_dtype), wc.detach().to(mlp_dtype))
         _INFER_CACHE[key] = c
     _, L, S, H, gridtype, align, add, mul, ws_h, wc_h = c
     assert table_h.dtype == torch.float16 and (L, table_h.shape[1], x.shape[1]) == (16, 2, 3) and B % 128 == 0
@@ -235,14 +235,16 @@ def ngp_field_infer(x, dirs, encoder, sigma_net, color_net, bound, live=None):
     st = stream()
     check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table_h), ptr(encoder.offsets), ptr(feats), B, 3, 2, L, S, H, gridtype, align, F16, LAYOUT_LBC, add,
                                                mul, units, rows_per_unit, st))
-    check(lib.nerftex_field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), units, rows_per_unit, st))
+    field_forward_rows = lib.nerftex_field_forward_rows_bf16 if mlp_dtype == torch.bfloat16 else lib.nerftex_field_forward_rows
+    check(field_forward_rows(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), units, rows_per_unit, st))
     return sigma, rgbs
 
 
-def ngp_density(x, encoder, sigma_net, bound):
+def ngp_density(x, encoder, sigma_net, bound, mlp_dtype=torch.float16):
     """sigma [B] fp32 of the --ff field's `density` (nerf/network_ff.py:103-117) for B % 128 == 0 points: the hash-grid gather (level-major
     output) and the sigma net + trunc_exp as ONE kernel behind it (nerftex_field_density) -- the occupancy-grid update's query
-    (nerf/renderer.py:566-660: 2-4 M cell positions every 16 steps).  No autograd; call under autocast(float16)."""
+    (nerf/renderer.py:566-660: 2-4 M cell positions every 16 steps).  No autograd; call under autocast(mlp_dtype) -- float16, or bfloat16 for
+    the bf16 field (nerftex_field_density_bf16)."""
     import numpy as np
 
     from nerftex_hip import F16, LAYOUT_LBC
@@ -255,14 +257,14 @@ def ngp_density(x, encoder, sigma_net, bound):
     L = encoder.offsets.shape[0] - 1
     assert table_h.dtype == torch.float16 and (L, table_h.shape[1], x.shape[1]) == (16, 2, 3) and B % 128 == 0 and x.dtype == torch.float32
     register_offsets(encoder.offsets, L)
-    ws_h = ws.detach() if ws.dtype == torch.float16 else ws.detach().to(torch.float16)
+    ws_h = ws.detach() if ws.dtype == mlp_dtype else ws.detach().to(mlp_dtype)
     feats = torch.empty(L, B, 2, dtype=torch.float16, device=dev)
     sigma = torch.empty(B, dtype=torch.float32, device=dev)
     st = stream()
     check(lib.nerftex_grid_encode_forward_rows(ptr(x), ptr(table_h), ptr(encoder.offsets), ptr(feats), B, 3, 2, L, float(np.log2(encoder.per_level_scale)),
                                                int(encoder.base_resolution), int(encoder.gridtype_id), int(bool(encoder.align_corners)), F16, LAYOUT_LBC,
                                                float(bound), float(np.float32(1.0) / np.float32(2 * bound)), None, 0, st))
-    check(lib.nerftex_field_density(ptr(feats), ptr(ws_h), B, ptr(sigma), st))
+    check((lib.nerftex_field_density_bf16 if mlp_dtype == torch.bfloat16 else lib.nerftex_field_density)(ptr(feats), ptr(ws_h), B, ptr(sigma), st))
     return sigma
 
 

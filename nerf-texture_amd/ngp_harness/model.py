@@ -151,11 +151,11 @@ class NGPField(nn.Module):
 
     def forward(self, x, d, **kwargs):
         if (self.fused_field_bf16 and x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and kwargs.get("live") is None):
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             from . import fused
 
             sigma, rgbs = fused.ngp_field(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, self.training and torch.is_grad_enabled(),
-                                          mlp_dtype=torch.bfloat16)
+                                          live=kwargs.get("live"), mlp_dtype=torch.bfloat16)
             return sigma, rgbs, {}
         if self.fused_glue and x.shape[0] % 128 == 0 and x.shape[0] > 0 and torch.is_autocast_enabled():
             if self.fused_field and x.dtype == torch.float32 and torch.get_autocast_dtype("cuda") == torch.float16:
@@ -176,14 +176,27 @@ class NGPField(nn.Module):
             h = self._chain(self.color_net, torch.cat([d.to(geo_feat.dtype), geo_feat], dim=-1))
         return sigma, torch.sigmoid(h), {}
 
+    def _fused_infer_dtype(self, x):
+        """The dtype of the fused no-grad kernels that apply to x under the current autocast (float16: the ngp field as fp16 networks; bfloat16:
+        as bf16 networks), or None."""
+        if not (x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()
+                and self.encoder._table().dtype == torch.float16):
+            return None
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.float16 and self.fused_glue and self.fused_field:
+            return dt
+        if dt == torch.bfloat16 and self.fused_field_bf16:
+            return dt
+        return None
+
     @torch.no_grad()
     def infer(self, x, d, live=None):
         """(sigma, rgbs) without autograd bookkeeping: the fused field's two launches when it applies, else forward()."""
-        if (self.fused_glue and self.fused_field and x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()
-                and torch.get_autocast_dtype("cuda") == torch.float16 and self.encoder._table().dtype == torch.float16):
+        dt = self._fused_infer_dtype(x)
+        if dt is not None:
             from . import fused
 
-            return fused.ngp_field_infer(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, live)
+            return fused.ngp_field_infer(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, live, mlp_dtype=dt)
         sigma, rgbs, _ = self.forward(x, d, live=live)
         return sigma, rgbs
 
@@ -195,11 +208,11 @@ class NGPField(nn.Module):
     def density_sigma(self, x):
         """density(x)["sigma"] without autograd bookkeeping -- what the occupancy-grid update asks for, millions of points at a time: the
         fused field's gather + sigma-net kernel when it applies (same values as the field kernel's sigma), else density()."""
-        if (self.fused_field and x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and x.is_contiguous() and torch.is_autocast_enabled()
-                and torch.get_autocast_dtype("cuda") == torch.float16 and self.encoder._table().dtype == torch.float16 and self.sigma_net.hidden_dim == 64):
+        dt = self._fused_infer_dtype(x)
+        if dt is not None and x.is_contiguous() and self.sigma_net.hidden_dim == 64:
             from . import fused
 
-            return fused.ngp_density(x, self.encoder, self.sigma_net, self.bound)
+            return fused.ngp_density(x, self.encoder, self.sigma_net, self.bound, mlp_dtype=dt)
         return self.density(x)["sigma"].reshape(-1).float()
 
     def get_params(self, lr):

@@ -85,6 +85,75 @@ def test_fused_bf16_field_inference_matches_training_forward(dev):
     assert torch.equal(s_t.detach(), s_e) and torch.equal(c_t.detach(), c_e)
 
 
+def test_bf16_field_no_grad_forms_match_the_bf16_field_forward(dev):
+    """nerftex_field_density_bf16 and nerftex_field_forward_rows_bf16 (the occupancy update's query and the inference iteration of the bf16 field)
+    against nerftex_field_forward_bf16: same sigma / (sigma, rgbs) bit for bit on the rows they compute, rows past the device count untouched;
+    and NGPField.infer / density_sigma take them under autocast(bfloat16)."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    fused, _ = _bf16_fields(dev)
+    fused.eval()
+    B = 128 * 40
+    g = torch.Generator(device=dev).manual_seed(8)
+    feats = (torch.rand(16, B, 2, device=dev, generator=g) * 2 - 1).half()
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g), dim=-1).contiguous()
+    ws, wc = fused.sigma_net.weights.detach().to(torch.bfloat16), fused.color_net.weights.detach().to(torch.bfloat16)
+    sigma, rgbs = torch.empty(B, device=dev), torch.empty(B, 3, device=dev)
+    check(lib.nerftex_field_forward_bf16(ptr(feats), ptr(dirs), ptr(ws), ptr(wc), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
+    dens = torch.empty(B, device=dev)
+    check(lib.nerftex_field_density_bf16(ptr(feats), ptr(ws), B, ptr(dens), stream()))
+    assert torch.equal(dens, sigma) and float(sigma.std()) > 0
+    units = torch.tensor([13], dtype=torch.int32, device=dev)
+    live = 13 * 256
+    s2, c2 = torch.full((B,), -7.0, device=dev), torch.full((B, 3), -7.0, device=dev)
+    check(lib.nerftex_field_forward_rows_bf16(ptr(feats), ptr(dirs), ptr(ws), ptr(wc), B, ptr(s2), ptr(c2), ptr(units), 256, stream()))
+    assert torch.equal(s2[:live], sigma[:live]) and torch.equal(c2[:live], rgbs[:live])
+    assert bool((s2[live:] == -7.0).all()) and bool((c2[live:] == -7.0).all())
+    check(lib.nerftex_field_forward_rows_bf16(ptr(feats), ptr(dirs), ptr(ws), ptr(wc), B, ptr(s2), ptr(c2), None, 0, stream()))
+    assert torch.equal(s2, sigma) and torch.equal(c2, rgbs)
+    # the fp16 entry on the same bits would be another function: bf16 weights read as fp16 are other numbers
+    x = (torch.rand(B, 3, device=dev, generator=g) * 2 - 1) * 1.9
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        s_f, c_f, _ = fused(x, dirs)
+        s_i, c_i = fused.infer(x, dirs)
+        s_l, c_l = fused.infer(x, dirs, (units, 256))
+        s_d = fused.density_sigma(x)
+        assert fused._fused_infer_dtype(x) == torch.bfloat16
+    assert torch.equal(s_i, s_f) and torch.equal(c_i, c_f) and torch.equal(s_d, s_f)
+    assert torch.equal(s_l[:live], s_f[:live]) and torch.equal(c_l[:live], c_f[:live])
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        assert fused._fused_infer_dtype(x) is None  # bf16 networks under an fp16 autocast: the framework-op chain, as before
+
+
+def test_graphed_inference_in_bf16_gives_the_image_of_the_reference_loop_in_bf16(dev):
+    """The bf16 field behind Renderer.render_infer_graphed (device-count iterations: nerftex_field_forward_rows_bf16) against the reference-shaped
+    loop on the same field under autocast(bfloat16): same image, bit for bit; and close to -- not equal to -- the fp16 image of the same weights."""
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    imgs = {}
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(0)
+        field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True, mlp_dtype=dt).to(dev)
+        torch.manual_seed(1)
+        field.encoder.embeddings.data.uniform_(-0.3, 0.3)
+        field.eval()
+        r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+        r.set_occupancy(torch.from_numpy(grid).to(dev))
+        pose = scene.rand_poses(1, 2.0, np.random.default_rng(3))[0]
+        o, d = scene.get_rays(pose, scene.intrinsics(160, 120), 160, 120)
+        ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        with torch.autocast("cuda", dtype=dt):
+            img_ref, dep_ref, _ = r.render_infer(ro, rd, dt_gamma=1 / 128)
+            img_g, dep_g, _ = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=4, parts=3, block=2)
+        assert torch.equal(img_g, img_ref) and torch.equal(dep_g, dep_ref), dt
+        imgs[dt] = img_ref
+    diff = float((imgs[torch.bfloat16] - imgs[torch.float16]).abs().max())
+    assert 0 < diff < 0.1, diff
+
+
 def test_mixed_adam_updates_bf16_and_fp16_leaves_like_torch_fused_adam(dev):
     """nerftex_adam_mixed_step(_amp): one launch over an fp16 leaf and two bf16 leaves == torch.optim.Adam(fused=True) on the fp32 masters with
     the widened gradients; the narrowed copies == master.to(dtype).  Also the non-finite scan in both exponent layouts."""
