@@ -365,6 +365,12 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         optimizer_step()
 
     def capture():
+        from ngp_harness.streams import capture_section
+
+        with capture_section():  # (no collector run in the middle of a recording: streams.py)
+            capture_body()
+
+    def capture_body():
         gstate["M"] = (renderer.mean_count + 4095) // 4096 * 4096 + 4096
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

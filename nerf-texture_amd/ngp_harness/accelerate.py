@@ -167,34 +167,37 @@ class AcceleratedTrainer:
     def _capture(self):
         """Record the graphs.  Nothing is executed here: the two eager steps at this buffer size that `step` ran just before (real
         training steps) have sized the library's workspaces and done every lazy initialisation outside the capture."""
+        from .streams import capture_section
+
         r = self.renderer
-        keep_step = r.local_step
-        graphs, pool, pool_m = [], None, None
-        for g in range(RING):  # per ring slot: the step's counter is slot g, as in the eager loop
-            r.local_step = g
-            gm = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"):  # (own memory pool: it may run beside the other graph)
-                marched, _ = self._march(*self._rays[g], mean_count=self._M)
-            pool_m = gm.pool()
-            ga = None
-            if self.group == 1:
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
-                    self._shade(marched, self._targets[g])
-                pool = ga.pool()
-            graphs.append((gm, ga, marched))  # (the sample tensors stay alive: the second graph reads them)
-        self._groups = None
-        if self.group > 1:  # shade + backward + optimizer of `group` consecutive steps per graph
-            self._groups = []
-            for g0 in range(0, RING, self.group):
-                gg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gg, pool=pool, capture_error_mode="thread_local"):
-                    for g in range(g0, g0 + self.group):
-                        self._shade(graphs[g][2], self._targets[g])
-                pool = gg.pool()
-                self._groups.append(gg)
-        self._graphs = graphs
-        r.local_step = keep_step % RING
+        with capture_section():
+            keep_step = r.local_step
+            graphs, pool, pool_m = [], None, None
+            for g in range(RING):  # per ring slot: the step's counter is slot g, as in the eager loop
+                r.local_step = g
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"):  # (own memory pool: it may run beside the other graph)
+                    marched, _ = self._march(*self._rays[g], mean_count=self._M)
+                pool_m = gm.pool()
+                ga = None
+                if self.group == 1:
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                        self._shade(marched, self._targets[g])
+                    pool = ga.pool()
+                graphs.append((gm, ga, marched))  # (the sample tensors stay alive: the second graph reads them)
+            self._groups = None
+            if self.group > 1:  # shade + backward + optimizer of `group` consecutive steps per graph
+                self._groups = []
+                for g0 in range(0, RING, self.group):
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg, pool=pool, capture_error_mode="thread_local"):
+                        for g in range(g0, g0 + self.group):
+                            self._shade(graphs[g][2], self._targets[g])
+                    pool = gg.pool()
+                    self._groups.append(gg)
+            self._graphs = graphs
+            r.local_step = keep_step % RING
 
     def _ensure_buffers(self, n_rays):
         if self._rays is None:

@@ -8,6 +8,7 @@ nerf/renderer.py:338-500 (`run_cuda` train and inference branches) and :566-660 
 bookkeeping: step counter ring, mean_count) against the drop-in packages -- it is the "caller" the hot path
 serves, kept minimal: no GUI, no dataset, no light models.
 """
+import contextlib
 import math
 
 import torch
@@ -692,9 +693,13 @@ class _InferGraphPart:
     def capture(self):
         from nerftex_hip import check, lib
 
+        from .streams import capture_section
+
         assert self.block % 2 == 0
         check(lib.nerftex_workspace_capture_set(self.set_id))  # this range's graphs get scratch of their own: the ranges replay side by side
-        try:
+        with contextlib.ExitStack() as stack:
+            stack.callback(lambda: check(lib.nerftex_workspace_capture_set(0)))
+            stack.enter_context(capture_section())
             self.g_init = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_init, stream=self.stream, capture_error_mode="thread_local"):
                 self._init_ops()
@@ -708,8 +713,6 @@ class _InferGraphPart:
                         self._iteration(j, bound)
                 self.g_blocks.append(g)
             self.g_block = self.g_blocks[0]
-        finally:
-            check(lib.nerftex_workspace_capture_set(0))
 
 
 class _InferPart:

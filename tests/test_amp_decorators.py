@@ -79,3 +79,39 @@ def test_lean_custom_fwd_keeps_the_signature():
     assert str(inspect.signature(wrapped)) == str(inspect.signature(forward))
     with pytest.raises(ValueError):
         lean.custom_fwd(device_type=0)
+
+
+def test_capture_section_collects_first_and_keeps_the_collector_off():
+    """ngp_harness.streams.capture_section (around every graph recording of the package): dead cycles are collected on entry, the collector is
+    off inside and back to what it was afterwards -- also when the body raises, and when it was off to begin with."""
+    import gc
+    import weakref
+
+    from ngp_harness.streams import capture_section
+
+    class Node:
+        pass
+
+    a = Node()
+    a.me = a
+    alive = weakref.ref(a)
+    was = gc.isenabled()
+    gc.disable()
+    del a
+    gc.enable()
+    try:
+        with capture_section():
+            assert alive() is None and not gc.isenabled()
+        assert gc.isenabled()
+        try:
+            with capture_section():
+                raise KeyError("x")
+        except KeyError:
+            pass
+        assert gc.isenabled()
+        gc.disable()
+        with capture_section():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable() if was else gc.disable()

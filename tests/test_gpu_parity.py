@@ -762,8 +762,10 @@ def test_march_replays_from_a_captured_graph(dev, scene_data):
     with torch.cuda.stream(side):
         body(M)
     torch.cuda.current_stream().wait_stream(side)
+    from ngp_harness.streams import capture_section
+
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with capture_section(), torch.cuda.graph(g):
         got = body(M)
     for _ in range(3):
         g.replay()

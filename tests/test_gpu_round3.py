@@ -262,7 +262,9 @@ def test_unregistered_table_under_stream_capture_is_invalid(dev, oracle):
     x, grad, out, launch = _grid_call(dev, 40000, off, rows)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
+    from ngp_harness.streams import capture_section
+
+    with capture_section(), torch.cuda.stream(s):
         graph = torch.cuda.CUDAGraph()
         graph.capture_begin()
         rc = launch()

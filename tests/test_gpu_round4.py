@@ -190,8 +190,10 @@ def test_kernel_timing_leaves_captured_launches_alone(dev):
     nerftex_hip.kernel_profile(1, reset=True)
     try:
         raymarching.near_far_from_aabb(o, d, aabb, 0.2)  # one eager launch: one span
+        from ngp_harness.streams import capture_section
+
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with capture_section(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(3):
                 nears, fars = raymarching.near_far_from_aabb(o, d, aabb, 0.2)
     finally:

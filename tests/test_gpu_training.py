@@ -91,8 +91,10 @@ def test_graph_replay_trains_like_eager(dev):
                     body()
                     losses.append(float(loss_buf))
             torch.cuda.current_stream().wait_stream(side)
+            from ngp_harness.streams import capture_section
+
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_section(), torch.cuda.graph(g):
                 body()
             for _ in range(37):
                 g.replay()
