@@ -15,8 +15,10 @@
  * (lossy); the MI355X kernels accumulate in fp32 on MFMA.  The oracle
  * accumulates exactly (double) and rounds ONCE to fp16 where the reference
  * stores fp16 -- it is the value both approximate, so parity is a tolerance
- * check (stated in the tests), not bitwise.  parity unpinned (no reference
- * test exists for this path).
+ * check (stated in the tests), not bitwise.  The reference holds no test for this
+ * path; the oracle is pinned by float64 autograd of the same chain of layers
+ * (tests/test_independent_anchors.py) and by the reference's own FFMLP module and
+ * networks executed over it (tests/golden/ref_python_*.npz, tools/make_golden.py).
  */
 #include "orc_common.h"
 

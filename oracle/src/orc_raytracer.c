@@ -7,7 +7,9 @@
  * The BVH only decides WHICH triangles get tested, so an exhaustive scan is the reference result up to
  * (a) exact ties between two triangles and (b) a box-entry distance that rounds above a triangle's t.
  * FMA policy as in the other oracle files (cross / dot products fused the way nvcc would).
- * parity unpinned: the reference fixture (test_data/object.obj + intersected_faces.obj) records no rays.
+ * Pinned (tests/test_independent_anchors.py, CPU): the reference's only data for this path (test_data/object.obj + intersected_faces.obj -- faces,
+ * no rays: a ray from the centre through each recorded face returns that face) and a float64 closest hit computed another way (3x3 linear
+ * solve per ray and triangle) on that mesh and on a random triangle soup: faces, depths, positions, normals, misses.
  */
 #include "orc_common.h"
 

@@ -7,6 +7,8 @@ kernels (GPU tests):
   R8 / R9        compositing is alpha_i * prod_{j<i}(1 - alpha_j) (nerf/renderer.py:269-271); its autograd gives dL/dsigma, dL/drgb;
   F1 / F2 / F4   the fully fused MLP is a chain of bias-free linear layers with ReLU whose activations are stored as half.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -184,3 +186,92 @@ def test_hip_ffmlp_matches_float64_autograd(dev, NL):
     out.backward(torch.from_numpy(g).to(dev))
     np.testing.assert_allclose(wt.grad.float().cpu().numpy(), want_gw, rtol=0, atol=4e-3 * np.abs(want_gw).max())
     np.testing.assert_allclose(xt.grad.float().cpu().numpy(), want_gx, rtol=0, atol=4e-3 * np.abs(want_gx).max())
+
+
+# ------------------------------------------------------------------ B2: the brute-force ray/triangle oracle, pinned on the CPU
+def _load_obj(path):
+    v, f = [], []
+    for line in open(path):
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            v.append([float(t) for t in p[1:4]])
+        elif p[0] == "f":
+            f.append([int(t.split("/")[0]) - 1 for t in p[1:4]])
+    return np.asarray(v, np.float32), np.asarray(f, np.uint32)
+
+
+def test_oracle_raytrace_returns_the_faces_of_the_reference_fixture(oracle):
+    """external/RayTracer/test_data (object.obj + intersected_faces.obj, the only data the reference holds for this path; copied as DATA under
+    tests/golden/raytracer): a ray from the centre through each recorded face must come back with exactly that face from the oracle."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raytracer")
+    v, f = _load_obj(os.path.join(root, "object.obj"))
+    hv, hf = _load_obj(os.path.join(root, "intersected_faces.obj"))
+    assert v.shape == (20, 3) and f.shape == (36, 3) and hf.shape == (3, 3)
+    cent = hv[hf].mean(1)
+    d = (cent / np.linalg.norm(cent, axis=1, keepdims=True)).astype(np.float32)
+    pos, nrm, depth, face, _ = oracle.raytrace(v, f, np.zeros_like(d), d)
+    assert (face >= 0).all()
+    for k in range(3):
+        assert {tuple(np.round(p, 6)) for p in v[f[face[k]]]} == {tuple(np.round(p, 6)) for p in hv[hf[k]]}, f"recorded face {k}"
+    np.testing.assert_allclose(np.linalg.norm(pos, axis=1), depth, rtol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-6)
+
+
+def _closest_hit_float64(v, f, o, d, max_dist=10.0):
+    """Closest ray/triangle hit from first principles in float64: solve o + t d = a + u (b - a) + w (c - a) per (ray, triangle) with a 3x3 linear
+    solve -- no formula shared with triangle.cuh's cross-product form; hit iff u, w >= 0, u + w <= 1, 0 <= t < max_dist (bvh.cu:259)."""
+    v, o, d = v.astype(np.float64), o.astype(np.float64), d.astype(np.float64)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    T = np.full((o.shape[0], f.shape[0]), np.inf)
+    for k in range(f.shape[0]):
+        A = np.stack([np.broadcast_to(b[k] - a[k], d.shape), np.broadcast_to(c[k] - a[k], d.shape), -d], axis=-1)  # [N, 3, 3]: columns e1, e2, -d
+        rhs = o - a[k]
+        ok = np.abs(np.linalg.det(A)) > 1e-14
+        sol = np.zeros_like(rhs)
+        sol[ok] = np.linalg.solve(A[ok], rhs[ok][..., None])[..., 0]
+        u, w, t = sol[:, 0], sol[:, 1], sol[:, 2]
+        hit = ok & (u >= 0) & (w >= 0) & (u + w <= 1) & (t >= 0) & (t < max_dist)
+        T[hit, k] = t[hit]
+    order = np.argsort(T, axis=1)
+    best = order[:, 0]
+    t0 = T[np.arange(o.shape[0]), best]
+    t1 = T[np.arange(o.shape[0]), order[:, 1]]
+    n = np.cross(b[best] - a[best], c[best] - a[best])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    return best, t0, t1, o + t0[:, None] * d, n
+
+
+def test_oracle_raytrace_matches_a_float64_linear_solve(oracle):
+    """oracle.raytrace (the restatement of triangle.cuh:27-39 + bvh.cu:259-302, 695-721) against a float64 closest hit computed another way, on a
+    random triangle soup and on the reference's fixture mesh: same face wherever the two nearest hits are not a tie, depth / position to 1e-5,
+    unit normal to 1e-6, misses as misses."""
+    rng = np.random.default_rng(4)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raytracer")
+    fixture = _load_obj(os.path.join(root, "object.obj"))
+    soup_v = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    soup = (soup_v, rng.integers(0, 300, (200, 3)).astype(np.uint32))
+    soup = (soup[0], soup[1][(soup[1][:, 0] != soup[1][:, 1]) & (soup[1][:, 1] != soup[1][:, 2]) & (soup[1][:, 0] != soup[1][:, 2])])
+    for v, f in (fixture, soup):
+        N = 4000
+        o = rng.uniform(-0.2, 0.2, (N, 3)).astype(np.float32)
+        d = rng.normal(size=(N, 3))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        pos, nrm, depth, face, second = oracle.raytrace(v, f, o, d)
+        best, t0, t1, p64, n64 = _closest_hit_float64(v, f, o, d)
+        hit64 = np.isfinite(t0)
+        clear = hit64 & (t1 - t0 > 1e-4 * np.maximum(t0, 1e-3))  # the two nearest hits are not a tie (shared edges, coplanar overlaps)
+        # a ray that grazes an edge of its ONLY candidate can hit in one precision and miss in the other: a handful, never a clear interior hit
+        assert ((face >= 0) != hit64).mean() < 2e-3
+        both = clear & (face >= 0)
+        assert both.sum() > 0.5 * hit64.sum() > 0
+        assert (face[both] == best[both]).mean() > 0.999
+        same = both & (face == best)
+        np.testing.assert_allclose(depth[same], t0[same], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(pos[same], p64[same], rtol=0, atol=2e-5)
+        sign = np.sign((nrm[same] * n64[same]).sum(1, keepdims=True))
+        np.testing.assert_allclose(nrm[same] * sign, n64[same], atol=2e-6)
+        assert (sign > 0).all(), "the normal is cross(b - a, c - a) normalised, not flipped towards the ray"
+        miss = (face < 0)
+        assert (depth[miss] == 10.0).all() and (nrm[miss] == 0).all()
