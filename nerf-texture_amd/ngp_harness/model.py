@@ -180,15 +180,12 @@ class NGPField(nn.Module):
     def _fused_infer_dtype(self, x):
         """The dtype of the fused no-grad kernels that apply to x under the current autocast (float16: the ngp field as fp16 networks; bfloat16:
         as bf16 networks), or None."""
-        if not (x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()
-                and self.encoder._table().dtype == torch.float16):
+        if not (x.shape[0] % 128 == 0 and x.shape[0] > 0 and x.dtype == torch.float32 and torch.is_autocast_enabled()):
             return None
         dt = torch.get_autocast_dtype("cuda")
-        if dt == torch.float16 and self.fused_glue and self.fused_field:
-            return dt
-        if dt == torch.bfloat16 and self.fused_field_bf16:
-            return dt
-        return None
+        if not ((dt == torch.float16 and self.fused_glue and self.fused_field) or (dt == torch.bfloat16 and self.fused_field_bf16)):
+            return None
+        return dt if self.encoder._table().dtype == torch.float16 else None  # (the table is fp16 under either autocast: gridencoder/grid.py)
 
     @torch.no_grad()
     def infer(self, x, d, live=None):
