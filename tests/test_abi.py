@@ -86,3 +86,34 @@ def test_grid_level_table_matches_reference_golden():
         off, total = level_table(kw.get("input_dim", 3), kw.get("num_levels", 16), c["per_level_scale"], kw.get("base_resolution", 16),
                                  kw.get("log2_hashmap_size", 19), kw.get("align_corners", False))
         assert off.tolist() == c["offsets"] and total == c["rows"], c["name"]
+
+
+def test_header_compiles_as_c_and_its_constants_match_the_python_binding(tmp_path):
+    """include/nerftex_hip.h is a C header (the boundary is a C ABI): gcc -std=c99 -Wall -Werror -pedantic takes it, and the constants a binding
+    has to restate -- NERFTEX_ROWS_AUTO, the dtype / layout / error codes -- have the values nerftex_hip (the ctypes binding) uses."""
+    import re
+    import subprocess
+
+    import nerftex_hip
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "nerftex_hip.h")).read()
+    names = sorted(set(re.findall(r"#define\s+(NERFTEX_[A-Z0-9_]+)\s+[-0-9(]", header)))
+    assert "NERFTEX_OK" in names and len(names) >= 6, names
+    src = tmp_path / "consts.c"
+    lines = ['#include <stdio.h>', '#include "nerftex_hip.h"', "int main(void) {"]
+    lines += [f'    printf("{n} %ld\\n", (long)({n}));' for n in names]
+    lines += ['    printf("ROWS_AUTO_A %lu\\n", (unsigned long)NERFTEX_ROWS_AUTO(640000, 4));',
+              '    printf("ROWS_AUTO_B %lu\\n", (unsigned long)NERFTEX_ROWS_AUTO(16777215, 127));', "    return 0;", "}"]
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "consts"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out["ROWS_AUTO_A"]) == nerftex_hip.rows_auto(640000, 4) and int(out["ROWS_AUTO_B"]) == nerftex_hip.rows_auto(16777215, 127)
+    checked = 0
+    for n in names:
+        py = getattr(nerftex_hip, n[len("NERFTEX_"):], None)
+        if isinstance(py, int):
+            assert int(out[n]) == py, (n, out[n], py)
+            checked += 1
+    assert checked >= 4, (checked, names)  # F16 / F32 / LAYOUT_* / ... restated by the binding
