@@ -97,6 +97,8 @@ def parse():
                     "that measure roofline.traffic; the committed constant is then used and labelled")
     ap.add_argument("--pipeline-adam", type=int, default=0, help="1 GPU, the fresh-ray headline loop (accelerate): sum the table gradient in this many level groups "
                     "and run each group's Adam on a second stream while the next group is being summed (A/B, off by default: DESIGN.md 4.5)")
+    ap.add_argument("--no-fused-table-update", action="store_true", help="1 GPU, the fresh-ray headline loop (accelerate): write the whole table gradient and update "
+                    "the table with the streaming Adam launch (rounds 1-5) instead of applying Adam from the summing kernel's tiles (round 6)")
     ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
     ap.add_argument("--allreduce-chunks", type=int, default=1, help="N > 1: exchange the table gradient as this many level-group chunks, each started as soon "
                     "as the backward has produced its rows (default 1 = one all-reduce after the backward)")
@@ -833,7 +835,7 @@ def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_
     return out
 
 
-def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16", randint_rays=False):
+def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16", randint_rays=False, fused_table_update=None):
     """A training loop that feeds FRESH rays every step through ngp_harness.accelerate (the one call a trainer adds to the drop-in
     packages: graph replay + fused field + HalfLeafAdam / FusedAmp, or torch's capturable Adam + GradScaler for nn.Linear MLPs).
     group = k > 1: `step_group` -- the loop has the batches of k consecutive steps at a time ([k, N, 3] tensors, copied into the graphs'
@@ -860,7 +862,8 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     # (march_across_ring_end: the loop makes no occupancy update inside the timed region -- the metric excludes it -- so the next ring's first
     # marches may start behind the ring's read-back, as they do in the baked-pool loop)
     trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1, amp_dtype=amp_dt,
-                         pipeline_adam=getattr(args, "pipeline_adam", 0))
+                         pipeline_adam=getattr(args, "pipeline_adam", 0),
+                         fused_table_update=False if getattr(args, "no_fused_table_update", False) else fused_table_update)
     if group > 1:
         assert n_pool % group == 0 and steps % group == 0
         po = [torch.stack([pool[c * group + i][0] for i in range(group)]).contiguous() for c in range(n_pool // group)]

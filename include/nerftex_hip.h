@@ -359,6 +359,35 @@ int nerftex_grid_encode_backward_phase_amp(const void* grad, const float* inputs
                                            uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul, int phase,
                                            uint32_t level_lo, uint32_t level_hi, float* found_inf, void* stream);
 
+/* Extension (round 6): the hash-grid table backward that ALSO applies the optimizer's update.  (The reference leaves the optimizer to torch:
+ * main_nerf.py:128 `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` under the GradScaler of nerf/utils.py:1003-1009; this is
+ * nerftex_grid_encode_backward_amp + nerftex_adam_mixed_step_amp on the table, fused where the gradient is still on chip.)
+ * The tiles of the hashed levels have one owner each in the summing kernel; that owner rounds the tile's exact row sums to fp16 -- the values
+ * grad_embeddings would have held -- and applies Adam to the rows itself: grad_embeddings receives ONLY rows [0, *first_updated_row) (the coarse
+ * levels whose tiles several work items share; host word, written before the call returns, a function of the level table and B), every row
+ * from there on is updated and gets NO gradient written.
+ * GradScaler skips a WHOLE step when any gradient element of any tensor is non-finite, which no tile can know about the tiles behind it, so the
+ * optimizer state is DOUBLE-BUFFERED: the call reads set [*live & 1] of param / exp_avg / exp_avg_sq and writes the other set; *found_inf is
+ * raised when a row's gradient comes out inf / nan (it is not read here).  The caller ends the step with nerftex_adam_mixed_step_amp_db, which
+ * updates what is left (rows [0, first_updated_row) and its other tensors) the same way, flips *live iff the step is applied and, on a skipped
+ * step, re-derives the fp16 copy this call rewrote in place (param_half) from the live fp32 set.
+ * fp16 tables, C = 2, NERFTEX_LAYOUT_GRAD_OVERWRITE, a registered level table whose levels are multiples of 4 rows; everything else is refused. */
+typedef struct nerftex_table_adam {
+    float* param[2];       /* fp32 table, state sets 0 and 1, [rows, 2] each */
+    float* exp_avg[2];
+    float* exp_avg_sq[2];
+    void* param_half;      /* the fp16 table the forward reads: rewritten in place for the updated rows */
+    const uint32_t* live;  /* device word: which set holds the current state */
+    const float* step;     /* device: completed optimizer steps (this update is number *step + 1) */
+    const float* grad_scale; /* device, may be NULL: gradients are divided by it */
+    float* found_inf;      /* device: raised on inf / nan */
+    double lr, beta1, beta2, eps;
+} nerftex_table_adam;
+int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                      int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
+                                      void* stream);
+
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).
  *   feats_lbc [16, B, 2] half (nerftex_grid_encode_forward*, NERFTEX_LAYOUT_LBC), sigma_weights as nerftex_field_forward's,
@@ -641,6 +670,17 @@ int nerftex_adam_mixed_step_amp(int count, float* const* params, float* const* e
                                 const void* const* grads16, void* const* params16, const uint64_t* n, uint32_t bf16_mask, float* step,
                                 double lr, double beta1, double beta2, double eps, float* scale, int32_t* growth_tracker, float* found_inf,
                                 uint32_t* ticket, double growth_factor, double backoff_factor, int growth_interval, void* stream);
+/* Extension (round 6): nerftex_adam_mixed_step_amp over DOUBLE-BUFFERED state -- the end of a step whose hashed table rows
+ * nerftex_grid_encode_backward_adam has already updated.  Reads set [*live & 1] (params / exp_avgs / exp_avg_sqs = set 0, the *1 arrays = set 1),
+ * writes the other one; the loss scaler's update (last block, as in the _amp forms) flips *live iff the step is applied.  On a skipped step the
+ * repair range -- repair_n 16-bit elements at repair_half, the fp32 elements they narrow at repair_param0 / repair_param1 -- is re-derived from
+ * the live set (repair_n 0: none).                                                                                                        */
+int nerftex_adam_mixed_step_amp_db(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, float* const* params1,
+                                   float* const* exp_avgs1, float* const* exp_avg_sqs1, const void* const* grads16, void* const* params16,
+                                   const uint64_t* n, uint32_t bf16_mask, float* step, double lr, double beta1, double beta2, double eps,
+                                   float* scale, int32_t* growth_tracker, float* found_inf, uint32_t* ticket, double growth_factor,
+                                   double backoff_factor, int growth_interval, uint32_t* live, void* repair_half, const float* repair_param0,
+                                   const float* repair_param1, uint64_t repair_n, void* stream);
 int nerftex_amp_check_mixed(int count, const void* const* grads16, const uint64_t* n, uint32_t bf16_mask, float* found_inf, void* stream);
 int nerftex_amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, double growth_factor,
                        double backoff_factor, int growth_interval, void* stream);

@@ -32,6 +32,22 @@ struct LevelConsts {
     // level group starts each group's all-reduce while the next group is still being summed (nerftex_grid_encode_backward_phase).
     // phase 0 = everything (the default).
     uint32_t bwd_phase, level_lo, level_hi;
+    // optional (backward, large-batch fp16 path; HOST pointers, read by grid_backward_binned only): the optimizer's update applied by the tile
+    // owners themselves (nerftex_grid_encode_backward_adam, gridencoder_binned.hip TileAdam)
+    const struct TableAdamArgs* tile_adam;
+    uint32_t* tile_adam_first_row;
+};
+
+// nerftex_table_adam of include/nerftex_hip.h (the header is C and knows no namespaces) without found_inf, which travels as LevelConsts::found_inf
+struct TableAdamArgs {
+    float* param[2];
+    float* exp_avg[2];
+    float* exp_avg_sq[2];
+    void* param_half;
+    const uint32_t* live;
+    const float* step;
+    const float* grad_scale;
+    double lr, beta1, beta2, eps;
 };
 
 // coordinate d of point b as the kernels see it (identity unless the caller folded its normalisation in)

@@ -839,6 +839,17 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
     const long force = knob(kKnobGridBwd);  // 1 atomic | 2 owner: A/B switch for profiling
     bool owner = C == 2 && (force ? force == 2 : (B >= kOwnerMinBatch));
     int rc = NERFTEX_OK;
+    if (lc.tile_adam != nullptr) {  // the optimizer's update applied by the tile owners (nerftex_grid_encode_backward_adam): the binned path or nothing
+        if constexpr (C == 2) {
+            if (!calc_grad) {
+                rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, overwrite, st);
+                if (rc >= 0) return rc;
+            }
+        }
+        set_error("grid_encode_backward_adam: exists on the binned table-gradient path only (C = 2, fp16, no input gradient, at most %u rows per level, "
+                  "a level table the library knows: nerftex_grid_register_offsets)", 128u * 4096u);
+        return NERFTEX_ERR_INVALID;
+    }
     if (lc.bwd_phase != 0) {  // a part of the table gradient (nerftex_grid_encode_backward_phase): the binned path or nothing
         if constexpr (C == 2) {
             if (owner && !knob(kKnobGridBwdSweep) && !calc_grad) {
@@ -991,7 +1002,8 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                         int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf = nullptr,
-                        uint32_t phase = 0, uint32_t level_lo = 0, uint32_t level_hi = 0);
+                        uint32_t phase = 0, uint32_t level_lo = 0, uint32_t level_hi = 0, const gridenc::TableAdamArgs* tile_adam = nullptr,
+                        uint32_t* tile_adam_first_row = nullptr);
 }  // namespace
 
 extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
@@ -1076,6 +1088,49 @@ extern "C" int nerftex_grid_encode_backward_phase_amp(const void* grad, const fl
                                true, in_add, in_mul, stream, found_inf, (uint32_t)phase, level_lo, level_hi);
 }
 
+// The hash-grid backward that ALSO applies the optimizer's update (round 6; an extension: the reference leaves the optimizer to torch,
+// main_nerf.py:128).  The tiles of the hashed levels -- one owner each -- never leave LDS as a gradient: their owner rounds the row sums to fp16 and
+// runs Adam on the rows (gridencoder_binned.hip TileAdam).  grad_embeddings receives ONLY rows [0, *first_updated_row) -- the coarse levels whose
+// tiles several work items share -- and the caller finishes the step with nerftex_adam_mixed_step_amp_db over those rows and its other tensors.
+extern "C" int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                                 int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
+                                                 void* stream) {
+    clear_error();
+    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
+    if (!adam || !first_updated_row || !adam->param[0] || !adam->param[1] || !adam->exp_avg[0] || !adam->exp_avg[1] || !adam->exp_avg_sq[0] ||
+        !adam->exp_avg_sq[1] || !adam->param_half || !adam->live || !adam->step || !adam->found_inf) {
+        set_error("grid_encode_backward_adam: both state sets, the fp16 table, live, step, found_inf and first_updated_row must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (dtype != NERFTEX_F16 || !(layout & NERFTEX_LAYOUT_GRAD_OVERWRITE)) {
+        set_error("grid_encode_backward_adam: fp16 tables with NERFTEX_LAYOUT_GRAD_OVERWRITE only");
+        return NERFTEX_ERR_INVALID;
+    }
+    for (const void* p : {(const void*)adam->param[0], (const void*)adam->param[1], (const void*)adam->exp_avg[0], (const void*)adam->exp_avg[1],
+                          (const void*)adam->exp_avg_sq[0], (const void*)adam->exp_avg_sq[1], (const void*)adam->param_half})
+        if (reinterpret_cast<uintptr_t>(p) & 15) {
+            set_error("grid_encode_backward_adam: buffers must be 16-byte aligned");
+            return NERFTEX_ERR_INVALID;
+        }
+    gridenc::TableAdamArgs ta{};
+    for (int i = 0; i < 2; i++) {
+        ta.param[i] = adam->param[i];
+        ta.exp_avg[i] = adam->exp_avg[i];
+        ta.exp_avg_sq[i] = adam->exp_avg_sq[i];
+    }
+    ta.param_half = adam->param_half;
+    ta.live = adam->live;
+    ta.step = adam->step;
+    ta.grad_scale = adam->grad_scale;
+    ta.lr = adam->lr;
+    ta.beta1 = adam->beta1;
+    ta.beta2 = adam->beta2;
+    ta.eps = adam->eps;
+    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype, align_corners, dtype, layout, true,
+                               in_add, in_mul, stream, adam->found_inf, 0, 0, 0, &ta, first_updated_row);
+}
+
 namespace {
 int grid_forward_entry(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                        uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
@@ -1096,7 +1151,7 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                         int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf, uint32_t phase,
-                        uint32_t level_lo, uint32_t level_hi) {
+                        uint32_t level_lo, uint32_t level_hi, const gridenc::TableAdamArgs* tile_adam, uint32_t* tile_adam_first_row) {
     if (!affine) clear_error();
     const bool overwrite = (layout & NERFTEX_LAYOUT_GRAD_OVERWRITE) != 0;
     layout &= ~NERFTEX_LAYOUT_GRAD_OVERWRITE;
@@ -1107,6 +1162,8 @@ int grid_backward_entry(const void* grad, const float* inputs, const int32_t* of
     lc.bwd_phase = phase;
     lc.level_lo = level_lo;
     lc.level_hi = level_hi;
+    lc.tile_adam = tile_adam;
+    lc.tile_adam_first_row = tile_adam_first_row;
     if (dtype == NERFTEX_F32)
         return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
                                         grad_inputs, gridtype, align_corners != 0, layout, overwrite, as_stream(stream));

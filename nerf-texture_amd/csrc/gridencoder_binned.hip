@@ -23,6 +23,7 @@
 // asynchronous copy into pinned memory completes.  Every workgroup re-validates the host copy against the device table; on a
 // mismatch (a stale registration) the launch does nothing and raises a deferred error that the next grid call -- or
 // nerftex_deferred_error() -- returns as NERFTEX_ERR_INVALID.  Nothing here synchronises or traps.
+#include "adam_math.hpp"  // the optimizer's update of one parameter: applied from the LDS tile by sum_tiles_dir_kernel<T, true>
 #include "common.hpp"
 #include "grid_common.hpp"
 #include "grid_record.hpp"  // Sample / make_sample: the records of one (sample, level); kTileBytes, rows_per_tile
@@ -30,6 +31,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -118,6 +120,28 @@ struct DirTable {
     uint32_t part_base[kMaxLevels];      //                         index of the level's first partial tile in the partial-sum buffer
     uint32_t* stale_flag;                // deferred error word (pinned host memory): set when the device table differs from `offsets`
     float* found_inf;                    // optional: set to 1 when a written gradient element is inf / nan (GradScaler's scan, folded in)
+};
+
+// Round 6: the optimizer's update applied by K4d itself.  A workgroup that is the SOLE owner of a tile (every hashed level: slices == 1) ends with
+// the tile's exact gradient in LDS; instead of writing 16 KiB of fp16 gradient for a streaming Adam kernel to read back one launch later, it
+// rounds each row's sums to fp16 in registers -- the very value the gradient tensor would have held -- and applies torch's fused-Adam arithmetic
+// (adam_math.hpp: the same function the streaming kernel calls) to its 8192 parameters: fp32 master + two moments in, the same three + the fp16
+// copy the next forward reads out.  The VALU / LDS-bound record walk of one workgroup then runs beside the HBM-bound parameter stream of its
+// CU's other workgroup, with no queue hand-off in between (round 5 measured 15-25 us per edge for the same overlap built from graph
+// branches), and the gradient write + read-back (39 + 25 MB) and most of one launch disappear from the step.
+// GradScaler skips the WHOLE step when any gradient element anywhere is non-finite, and a tile cannot know that about the tiles behind it: so the
+// optimizer state is DOUBLE-BUFFERED.  Set [*live & 1] is read, the other one written; the step's last launch (nerftex_adam_mixed_step_amp_db)
+// flips *live only when the step is applied, and on a skipped step re-derives the fp16 copy -- the one thing rewritten in place -- from the
+// untouched live set.  Shared tiles (levels 0-3 at the benchmark's size) keep partial sums + combine_tiles + that launch.
+struct TileAdam {
+    float* p[2];
+    float* m[2];
+    float* v[2];
+    half_t* leaf;          // fp16 copy of the table (what G1 gathers from), rewritten in place
+    const uint32_t* live;  // device word
+    const float* step;     // completed optimizer steps; this update is number *step + 1
+    const float* grad_scale;
+    AdamConsts k;
 };
 
 // inf / nan in either half of a pair of fp16 gradient elements
@@ -402,6 +426,51 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
     }
 }
 
+// tile -> optimizer.  Thread = 4 consecutive rows = 8 parameters: 2 x 3 16-byte loads of the live state set issued first, then the eight sums read
+// from LDS and rounded to fp16 (the gradient tensor's value), eight updates, 2 x 3 + 1 16-byte stores.  nrows % 4 == 0 and a 4-row-aligned
+// first row are the host's to check (grid levels are sized in multiples of 8 rows: gridencoder/grid.py:108).
+__device__ __forceinline__ void adam_tile(const char* smem, const TileAdam& ad, const AdamStep& as, const size_t dst_row, const uint32_t nrows, float* found_inf) {
+    const unsigned long long* acc64 = reinterpret_cast<const unsigned long long*>(smem);
+    const uint32_t from = *ad.live & 1u, to = from ^ 1u;
+    const float* __restrict__ ps = ad.p[from];
+    const float* __restrict__ ms = ad.m[from];
+    const float* __restrict__ vs = ad.v[from];
+    float* __restrict__ pd = ad.p[to];
+    float* __restrict__ md = ad.m[to];
+    float* __restrict__ vd = ad.v[to];
+    bool bad = false;
+    for (uint32_t r = threadIdx.x * 4u; r < nrows; r += kSumThreads * 4u) {
+        const size_t e = (dst_row + r) * 2;  // first of the 8 parameters
+        float4_t p[2], m[2], v[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            p[q] = *reinterpret_cast<const float4_t*>(ps + e + 4 * q);
+            m[q] = *reinterpret_cast<const float4_t*>(ms + e + 4 * q);
+            v[q] = *reinterpret_cast<const float4_t*>(vs + e + 4 * q);
+        }
+        half8_t h;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const half_t g = fixed_to_half((long long)acc64[(size_t)r * 2 + j]);
+            bad |= (__builtin_bit_cast(uint16_t, g) & 0x7c00u) == 0x7c00u;
+            float pj = p[j / 4][j % 4], mj = m[j / 4][j % 4], vj = v[j / 4][j % 4];
+            adam_one(pj, mj, vj, (float)g, ad.k, as);
+            p[j / 4][j % 4] = pj;
+            m[j / 4][j % 4] = mj;
+            v[j / 4][j % 4] = vj;
+            h[j] = (half_t)pj;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            *reinterpret_cast<float4_t*>(pd + e + 4 * q) = p[q];
+            *reinterpret_cast<float4_t*>(md + e + 4 * q) = m[q];
+            *reinterpret_cast<float4_t*>(vd + e + 4 * q) = v[q];
+        }
+        *reinterpret_cast<half8_t*>(ad.leaf + e) = h;
+    }
+    if (found_inf && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) *found_inf = 1.0f;
+}
+
 // K4d: a wave takes 64 runs at a time (chunks c_lo + wave + 16 k): their lengths are prefix-summed into a per-wave LDS table and
 // the wave walks the concatenation as ONE flat list of QUADS (four consecutive records; K3d pads every run to whole quads) -- every
 // lane busy, loads independent -- finding the run of a quad with a 6-step search in that table: the search, ~25 of the ~108
@@ -409,18 +478,24 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
 // once per four records.  (Measured alternatives: a wave per run leaves half the lanes idle, 159 us against 95; a lane per
 // run makes every load divergent, 410; one run table for the whole workgroup with 4-16 loads in flight per lane puts two
 // barriers in front of every pass: 137-161.)
-template <typename T>
+struct NoAdam {};
+template <typename T, bool ADAM>
 __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
                                                                    const bool overwrite, unsigned long long* __restrict__ partials,
-                                                                   const int* __restrict__ offsets, const uint32_t probe, const uint32_t item_offset) {
+                                                                   const int* __restrict__ offsets, const uint32_t probe, const uint32_t item_offset,
+                                                                   const std::conditional_t<ADAM, TileAdam, NoAdam> adam) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ AdamStep s_step;
     SumItem it;
     if (!sum_item(tab, L, nchunks, rows_per_tile<T>(), it, item_offset)) return;
     if (!table_matches(tab, offsets, it.level)) return;  // K3d wrote no directory for this level either
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     constexpr uint32_t kWaves = kSumThreads / kWave;
     zero_tile<T>(smem, it.nrows);
+    if constexpr (ADAM) {  // the step's constants (two double pows): one lane, once, while the others clear the tile
+        if (threadIdx.x == 0 && it.slices == 1) s_step = adam_step_consts(adam.k, (double)(*adam.step + 1.0f), adam.grad_scale);
+    }
     __syncthreads();
 
     const uint32_t* drow = dir + ((size_t)it.level * kMaxTilesPerLevel + it.t) * nchunks;
@@ -481,6 +556,10 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
             for (uint32_t i = threadIdx.x; i < it.nrows; i += kSumThreads) mine[i] = acc[i];
             return;
         }
+    }
+    if constexpr (ADAM) {
+        adam_tile(smem, adam, s_step, it.dst_row, it.nrows, tab.found_inf);  // (sole owner: shared tiles have returned above)
+        return;
     }
     write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite, tab.found_inf);
 }
@@ -626,6 +705,14 @@ int take_deferred_error() {
 template <typename T, int D>
 int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int* offsets_dev, T* grad_grid, uint32_t B, uint32_t L,
                          const LevelConsts& lc, uint32_t gridtype, bool align_corners, bool overwrite, hipStream_t st) {
+    // lc.tile_adam (nerftex_grid_encode_backward_adam; fp16 tables, the whole gradient in one call, an uninitialised gradient buffer): K4d applies
+    // the optimizer's update to the tiles it owns alone and writes NO gradient for them; *lc.tile_adam_first_row <- the first table row updated
+    // that way (the rows below it -- the shared coarse levels -- get their gradient in grad_grid as always and are the caller's to update)
+    const TableAdamArgs* ta = lc.tile_adam;
+    if (ta && (sizeof(T) != 2 || lc.bwd_phase != 0 || !overwrite)) {
+        set_error("grid_encode_backward_adam: fp16 tables, the one-call backward and NERFTEX_LAYOUT_GRAD_OVERWRITE only");
+        return NERFTEX_ERR_INVALID;
+    }
     std::vector<int32_t> off;
     int rc = take_deferred_error();
     if (rc != NERFTEX_OK) return rc;
@@ -659,6 +746,19 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     dt.offsets[L] = off[L];
     dt.tile_base[L] = tiles;
     dt.item_base[L] = items;
+    if (ta) {
+        // shared tiles must be a PREFIX of the table (they are: a level's tile count grows with the level until the hash-table cap) and the
+        // rows K4d updates four at a time must be 4-row aligned (levels are sized in multiples of 8 rows, gridencoder/grid.py:108)
+        uint32_t first = 0;
+        while (first < L && dt.slices[first] > 1) first++;
+        for (uint32_t l = first; l < L; l++)
+            if (dt.slices[l] > 1 || (off[l] & 3) || ((off[l + 1] - off[l]) & 3)) {
+                set_error("grid_encode_backward_adam: level %u (rows %d..%d, %u work items per tile) does not fit the tile-owner update: the levels "
+                          "whose tiles are shared must come first, and level sizes must be multiples of 4 rows", l, off[l], off[l + 1], dt.slices[l]);
+                return NERFTEX_ERR_INVALID;
+            }
+        if (lc.tile_adam_first_row) *lc.tile_adam_first_row = (uint32_t)off[first];
+    }
     dt.stale_flag = stale_flag();
     dt.found_inf = sizeof(T) == 2 ? lc.found_inf : nullptr;  // (fp32 tables: the caller scans, launch_backward)
     if (!dt.stale_flag) { set_error("grid_encode_backward: no pinned memory for the deferred error word"); return NERFTEX_ERR_HIP; }
@@ -695,11 +795,33 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     if (!do_sum || lv_lo >= lv_hi) return NERFTEX_OK;
     const uint32_t item_lo = dt.item_base[lv_lo], item_hi = dt.item_base[lv_hi];
     if (item_hi > item_lo) {
-        auto kernel = sum_tiles_dir_kernel<T>;
-        NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
-        KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials,
-                           offsets_dev, probe, item_lo);
+        if constexpr (sizeof(T) == 2) {
+            if (ta) {
+                auto kernel = sum_tiles_dir_kernel<T, true>;
+                NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
+                TileAdam ad{};
+                for (int i = 0; i < 2; i++) {
+                    ad.p[i] = ta->param[i];
+                    ad.m[i] = ta->exp_avg[i];
+                    ad.v[i] = ta->exp_avg_sq[i];
+                }
+                ad.leaf = static_cast<half_t*>(ta->param_half);
+                ad.live = ta->live;
+                ad.step = ta->step;
+                ad.grad_scale = ta->grad_scale;
+                ad.k = AdamConsts{ta->lr, ta->beta1, ta->beta2, ta->eps};
+                KernelTimer kt("sum_tiles_adam_kernel", st, kTimeGrid);
+                hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite,
+                                   partials, offsets_dev, probe, item_lo, ad);
+            }
+        }
+        if (!ta) {
+            auto kernel = sum_tiles_dir_kernel<T, false>;
+            NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
+            KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
+            hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials,
+                               offsets_dev, probe, item_lo, NoAdam{});
+        }
     }
     if ((rc = check_launch("grid_encode_backward(sum)")) != NERFTEX_OK) return rc;
     if constexpr (sizeof(T) == 2) {

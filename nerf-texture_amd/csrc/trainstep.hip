@@ -13,6 +13,7 @@
 //                double pow rounded to float -- tests/test_gpu_trainstep.py compares with torch.optim.Adam(fused=True).
 #include <algorithm>
 
+#include "adam_math.hpp"  // AdamConsts, AdamStep, adam_one: shared with the hash-grid backward that applies the update from its tiles
 #include "common.hpp"
 
 namespace nerftex {
@@ -103,36 +104,34 @@ __global__ __launch_bounds__(kTailThreads) void render_tail_backward_kernel(cons
 constexpr uint32_t kAdamThreads = 256;
 constexpr uint32_t kAdamVec = 8;
 
-struct AdamConsts {
-    double lr, beta1, beta2, eps;
-};
-
-// the moment updates are fused multiply-adds in double, fma(beta, state, (1 - beta) * g ...): how the framework's kernel comes out of
-// the compiler.  It matters more often than double rounding suggests -- fp16 gradients and few-bit constants put the exact sum on a
-// float rounding tie about once in 500 updates, and the two forms fall on different sides of it.
-__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float grad, const AdamConsts& k, const bool unscale, const double scale,
-                                         const float step_size, const float bc2_sqrt) {
-#pragma clang fp contract(off)
-    if (unscale) grad = (float)((double)grad / scale);
-    const double g = (double)grad;
-    m = (float)fma(k.beta1, (double)m, (1 - k.beta1) * g);
-    v = (float)fma(k.beta2, (double)v, (1 - k.beta2) * g * g);
-    const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + k.eps);
-    p -= step_size * m / denom;
-}
-
 constexpr int kMaxTensors = 8;
 
 struct AdamTensors {
-    float* param[kMaxTensors];
+    float* param[kMaxTensors];  // state set 0 -- the only one unless `live` is set
     float* exp_avg[kMaxTensors];
     float* exp_avg_sq[kMaxTensors];
+    // double-buffered form (round 6, nerftex_adam_mixed_step_amp_db): state set 1 and the device word that says which set is LIVE.  The launch
+    // reads set [*live & 1] and writes the other one; the loss scaler's tail flips the word when -- and only when -- the step is applied.  That is
+    // what lets the hash-grid backward update the hashed levels' rows straight from its LDS tiles (nerftex_grid_encode_backward_adam) BEFORE the
+    // last gradient element of the step has been scanned for inf / nan: a step GradScaler has to skip simply never flips.
+    float* param1[kMaxTensors];
+    float* exp_avg1[kMaxTensors];
+    float* exp_avg_sq1[kMaxTensors];
+    const uint32_t* live;
     const half_t* grad[kMaxTensors];
     half_t* param_half[kMaxTensors];
     uint64_t n[kMaxTensors];
     uint32_t block_end[kMaxTensors];  // blocks [block_end[t-1], block_end[t]) work on tensor t
     int count;
     uint32_t bf16_mask;  // bit t: tensor t's 16-bit gradient and 16-bit copy are bf16 (the MLP weights of a bf16 field), else fp16
+};
+
+// double-buffered form, skipped step: the 16-bit copy of the rows an EARLIER kernel of the step has already rewritten (the hash-grid backward's
+// tiles) is re-derived from the live -- unchanged -- fp32 set; n fp16 elements, a multiple of 8, 16-byte aligned
+struct AdamRepair {
+    half_t* leaf;
+    const float* param[2];
+    uint64_t n;
 };
 
 // the 16-bit side of one Adam tensor: gradient in, narrowed parameter out
@@ -154,7 +153,7 @@ template <> struct Half16<true> {
 
 // amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count
 __device__ __forceinline__ void amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
-                                           const double backoff_factor, const int growth_interval) {
+                                           const double backoff_factor, const int growth_interval, uint32_t* live = nullptr) {
     if (*found_inf != 0.0f) {
         *scale = (float)((double)*scale * backoff_factor);
         *growth_tracker = 0;
@@ -168,6 +167,7 @@ __device__ __forceinline__ void amp_update(float* scale, int32_t* growth_tracker
             *growth_tracker = successful;
         }
         if (step) *step += 1.0f;
+        if (live) *live ^= 1u;  // double-buffered state: the set this step wrote becomes the live one
     }
     *found_inf = 0.0f;
 }
@@ -182,23 +182,31 @@ struct AmpTail {
     uint32_t* ticket;  // zero on entry, left zero
     double growth_factor, backoff_factor;
     int growth_interval;
+    uint32_t* live;  // double-buffered form: flipped when the step is applied
+};
+
+// src / dst: the state set read and the one written (the same set unless the launch is double-buffered)
+struct AdamState {
+    const float* p; const float* m; const float* v;
+};
+struct AdamStateOut {
+    float* p; float* m; float* v;
 };
 
 template <bool BF16>
-__device__ __forceinline__ void adam_tensor(float* __restrict__ param, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, const half_t* __restrict__ grad,
-                                            half_t* __restrict__ param_half, const uint64_t n, const uint32_t block, const uint32_t nblocks, const AdamConsts& k,
-                                            const bool unscale, const double scale, const float step_size, const float bc2_sqrt) {
+__device__ __forceinline__ void adam_tensor(const AdamState src, const AdamStateOut dst, const half_t* __restrict__ grad, half_t* __restrict__ param_half,
+                                            const uint64_t n, const uint32_t block, const uint32_t nblocks, const AdamConsts& k, const AdamStep& s) {
     using H = Half16<BF16>;
     using V8 = typename H::vec8;
     const uint64_t groups = n / kAdamVec;
     for (uint64_t i = (uint64_t)block * kAdamThreads + threadIdx.x; i < groups; i += (uint64_t)nblocks * kAdamThreads) {
         float4 p[2], m[2], v[2];
-        p[0] = reinterpret_cast<const float4*>(param)[2 * i];
-        p[1] = reinterpret_cast<const float4*>(param)[2 * i + 1];
-        m[0] = reinterpret_cast<const float4*>(exp_avg)[2 * i];
-        m[1] = reinterpret_cast<const float4*>(exp_avg)[2 * i + 1];
-        v[0] = reinterpret_cast<const float4*>(exp_avg_sq)[2 * i];
-        v[1] = reinterpret_cast<const float4*>(exp_avg_sq)[2 * i + 1];
+        p[0] = reinterpret_cast<const float4*>(src.p)[2 * i];
+        p[1] = reinterpret_cast<const float4*>(src.p)[2 * i + 1];
+        m[0] = reinterpret_cast<const float4*>(src.m)[2 * i];
+        m[1] = reinterpret_cast<const float4*>(src.m)[2 * i + 1];
+        v[0] = reinterpret_cast<const float4*>(src.v)[2 * i];
+        v[1] = reinterpret_cast<const float4*>(src.v)[2 * i + 1];
         const V8 g = __builtin_nontemporal_load(reinterpret_cast<const V8*>(grad) + i);
         float* pf = reinterpret_cast<float*>(p);
         float* mf = reinterpret_cast<float*>(m);
@@ -206,25 +214,25 @@ __device__ __forceinline__ void adam_tensor(float* __restrict__ param, float* __
         V8 h;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            adam_one(pf[j], mf[j], vf[j], H::widen(g, j), k, unscale, scale, step_size, bc2_sqrt);
+            adam_one(pf[j], mf[j], vf[j], H::widen(g, j), k, s);
             H::narrow(h, j, pf[j]);
         }
-        reinterpret_cast<float4*>(param)[2 * i] = p[0];
-        reinterpret_cast<float4*>(param)[2 * i + 1] = p[1];
-        reinterpret_cast<float4*>(exp_avg)[2 * i] = m[0];
-        reinterpret_cast<float4*>(exp_avg)[2 * i + 1] = m[1];
-        reinterpret_cast<float4*>(exp_avg_sq)[2 * i] = v[0];
-        reinterpret_cast<float4*>(exp_avg_sq)[2 * i + 1] = v[1];
+        reinterpret_cast<float4*>(dst.p)[2 * i] = p[0];
+        reinterpret_cast<float4*>(dst.p)[2 * i + 1] = p[1];
+        reinterpret_cast<float4*>(dst.m)[2 * i] = m[0];
+        reinterpret_cast<float4*>(dst.m)[2 * i + 1] = m[1];
+        reinterpret_cast<float4*>(dst.v)[2 * i] = v[0];
+        reinterpret_cast<float4*>(dst.v)[2 * i + 1] = v[1];
         reinterpret_cast<V8*>(param_half)[i] = h;
     }
     // ragged end (n not a multiple of 8): the tensor's first block, first lanes
     const uint64_t rest = groups * kAdamVec + threadIdx.x;
     if (block == 0 && rest < n) {
-        float p = param[rest], m = exp_avg[rest], v = exp_avg_sq[rest];
-        adam_one(p, m, v, H::widen1(grad, rest), k, unscale, scale, step_size, bc2_sqrt);
-        param[rest] = p;
-        exp_avg[rest] = m;
-        exp_avg_sq[rest] = v;
+        float p = src.p[rest], m = src.m[rest], v = src.v[rest];
+        adam_one(p, m, v, H::widen1(grad, rest), k, s);
+        dst.p[rest] = p;
+        dst.m[rest] = m;
+        dst.v[rest] = v;
         H::narrow1(param_half, rest, p);
     }
 }
@@ -232,38 +240,40 @@ __device__ __forceinline__ void adam_tensor(float* __restrict__ param, float* __
 // up to 8 tensors per launch (the table and the MLP weight vectors): a block finds its tensor, then grid-strides inside it
 __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTensors tens, const float* step, const float step_offset,
                                                                  const AdamConsts k, const float* grad_scale, const float* found_inf,
-                                                                 const AmpTail tail) {
+                                                                 const AmpTail tail, const AdamRepair repair) {
     const bool skip = found_inf && *found_inf == 1.0f;  // GradScaler: skip the step, every buffer stays as it is
-    if (!skip) {
+    const uint32_t from = tens.live ? (*tens.live & 1u) : 0u, to = tens.live ? from ^ 1u : 0u;
+    if (!skip && tens.count > 0 && blockIdx.x < tens.block_end[tens.count - 1]) {  // (a launch with a repair may carry more blocks than the tensors need)
     int t = 0;
     while (t + 1 < tens.count && blockIdx.x >= tens.block_end[t]) t++;
     const uint32_t first = t ? tens.block_end[t - 1] : 0u;
     const uint32_t nblocks = tens.block_end[t] - first, block = blockIdx.x - first;
-    float* __restrict__ param = tens.param[t];
-    float* __restrict__ exp_avg = tens.exp_avg[t];
-    float* __restrict__ exp_avg_sq = tens.exp_avg_sq[t];
+    const AdamState src{from ? tens.param1[t] : tens.param[t], from ? tens.exp_avg1[t] : tens.exp_avg[t], from ? tens.exp_avg_sq1[t] : tens.exp_avg_sq[t]};
+    const AdamStateOut dst{to ? tens.param1[t] : tens.param[t], to ? tens.exp_avg1[t] : tens.exp_avg[t], to ? tens.exp_avg_sq1[t] : tens.exp_avg_sq[t]};
     const half_t* __restrict__ grad = tens.grad[t];
     half_t* __restrict__ param_half = tens.param_half[t];
     const uint64_t n = tens.n[t];
 
-    const double steps = (double)(*step + step_offset);
-    const float bc1 = (float)(1 - pow(k.beta1, steps));
-    const float bc2_sqrt = (float)sqrt(1 - pow(k.beta2, steps));
-    const float step_size = (float)(k.lr / (double)bc1);
-    const bool unscale = grad_scale != nullptr;
-    const double scale = unscale ? (double)*grad_scale : 1.0;
+    const AdamStep s = adam_step_consts(k, (double)(*step + step_offset), grad_scale);
 
-    if ((tens.bf16_mask >> t) & 1u) adam_tensor<true>(param, exp_avg, exp_avg_sq, grad, param_half, n, block, nblocks, k, unscale, scale, step_size, bc2_sqrt);
-    else adam_tensor<false>(param, exp_avg, exp_avg_sq, grad, param_half, n, block, nblocks, k, unscale, scale, step_size, bc2_sqrt);
+    if ((tens.bf16_mask >> t) & 1u) adam_tensor<true>(src, dst, grad, param_half, n, block, nblocks, k, s);
+    else adam_tensor<false>(src, dst, grad, param_half, n, block, nblocks, k, s);
+    }
+    if (skip && repair.n) {  // rows whose 16-bit copy an earlier kernel of this -- skipped -- step rewrote: back to half(live fp32 set)
+        const float4* p = reinterpret_cast<const float4*>(repair.param[from]);
+        for (uint64_t i = (uint64_t)blockIdx.x * kAdamThreads + threadIdx.x; i < repair.n / 8; i += (uint64_t)gridDim.x * kAdamThreads) {
+            const float4 a = p[2 * i], b = p[2 * i + 1];
+            reinterpret_cast<half8_t*>(repair.leaf)[i] = half8_t{(half_t)a.x, (half_t)a.y, (half_t)a.z, (half_t)a.w, (half_t)b.x, (half_t)b.y, (half_t)b.z, (half_t)b.w};
+        }
     }
     if (tail.scale != nullptr) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            // no fence: the last block consumes nothing the others wrote -- it only needs them to be past their reads of the three words,
-            // which the ticket (a device-scope atomic, performed memory-side) says.  A device-scope release here would have every one
-            // of the 2048 blocks write its XCD's L2 back: measured +125 us on a 60 us kernel
+            // no fence: the last block consumes nothing the others wrote -- it only needs them to be past their reads of the three words (and
+            // of `live`), which the ticket (a device-scope atomic, performed memory-side) says.  A device-scope release here would have every
+            // one of the 2048 blocks write its XCD's L2 back: measured +125 us on a 60 us kernel
             if (atomicAdd(tail.ticket, 1u) == gridDim.x - 1) {
-                amp_update(tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor, tail.backoff_factor, tail.growth_interval);
+                amp_update(tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor, tail.backoff_factor, tail.growth_interval, tail.live);
                 *tail.ticket = 0u;
             }
         }
@@ -303,8 +313,8 @@ __global__ __launch_bounds__(256) void amp_check_half_kernel(const CheckTensors 
 }
 
 __global__ void amp_update_kernel(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
-                                  const double backoff_factor, const int growth_interval) {
-    amp_update(scale, growth_tracker, found_inf, step, growth_factor, backoff_factor, growth_interval);
+                                  const double backoff_factor, const int growth_interval, uint32_t* live) {
+    amp_update(scale, growth_tracker, found_inf, step, growth_factor, backoff_factor, growth_interval, live);
 }
 
 }  // namespace
@@ -352,9 +362,18 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) !=
 }  // namespace
 
 namespace {
+// double-buffered form: the second state set, the live word, and the repair of a skipped step
+struct AdamSecondSet {
+    float* const* params1;
+    float* const* exp_avgs1;
+    float* const* exp_avg_sqs1;
+    const uint32_t* live;
+    AdamRepair repair;
+};
 int adam_half_launch(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, const void* const* grads_half,
                      void* const* params_half, const uint64_t* n, const float* step, float step_offset, double lr, double beta1, double beta2,
-                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream, uint32_t bf16_mask = 0);
+                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream, uint32_t bf16_mask = 0,
+                     const struct AdamSecondSet* second = nullptr);
 }  // namespace
 
 extern "C" int nerftex_adam_half_step(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
@@ -375,7 +394,7 @@ extern "C" int nerftex_adam_half_step_amp(int count, float* const* params, float
         set_error("adam_half_step_amp: scale, growth_tracker, found_inf, step and ticket must not be NULL");
         return NERFTEX_ERR_INVALID;
     }
-    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval};
+    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval, nullptr};
     return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads_half, params_half, n, step, 1.0f, lr, beta1, beta2, eps, scale, found_inf,
                             tail, stream);
 }
@@ -398,15 +417,46 @@ extern "C" int nerftex_adam_mixed_step_amp(int count, float* const* params, floa
         set_error("adam_mixed_step_amp: scale, growth_tracker, found_inf, step and ticket must not be NULL");
         return NERFTEX_ERR_INVALID;
     }
-    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval};
+    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval, nullptr};
     return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads16, params16, n, step, 1.0f, lr, beta1, beta2, eps, scale, found_inf, tail,
                             stream, bf16_mask);
+}
+
+// nerftex_adam_mixed_step_amp over DOUBLE-BUFFERED optimizer state (round 6): the launch reads state set [*live & 1] and writes the other one; the
+// loss scaler's tail flips *live when the step is applied and leaves it when GradScaler skips the step.  The companion of
+// nerftex_grid_encode_backward_adam, which has updated the hashed levels' rows from its LDS tiles earlier in the step, before the whole gradient had
+// been scanned: on a skipped step nothing that launch wrote is ever read (the set it wrote does not become live), except the 16-bit copy of those
+// rows, which it rewrote in place -- `repair_*` name them (repair_n 16-bit elements from repair_half, the fp32 rows they narrow in either set) and
+// this launch re-derives them from the live set.  Tensors passed here are what is LEFT of the step: the table rows of the shared (coarse) levels
+// and the MLP weights.
+extern "C" int nerftex_adam_mixed_step_amp_db(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, float* const* params1,
+                                              float* const* exp_avgs1, float* const* exp_avg_sqs1, const void* const* grads16, void* const* params16,
+                                              const uint64_t* n, uint32_t bf16_mask, float* step, double lr, double beta1, double beta2, double eps,
+                                              float* scale, int32_t* growth_tracker, float* found_inf, uint32_t* ticket, double growth_factor,
+                                              double backoff_factor, int growth_interval, uint32_t* live, void* repair_half, const float* repair_param0,
+                                              const float* repair_param1, uint64_t repair_n, void* stream) {
+    if (!scale || !growth_tracker || !found_inf || !step || !ticket || !live || !params1 || !exp_avgs1 || !exp_avg_sqs1) {
+        clear_error();
+        set_error("adam_mixed_step_amp_db: scale, growth_tracker, found_inf, step, ticket, live and the second state set must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (repair_n && (!repair_half || !repair_param0 || !repair_param1 || repair_n % 8 || misaligned(repair_half) || misaligned(repair_param0) ||
+                     misaligned(repair_param1))) {
+        clear_error();
+        set_error("adam_mixed_step_amp_db: the repair range needs its three buffers, 16-byte aligned, and a multiple of 8 elements");
+        return NERFTEX_ERR_INVALID;
+    }
+    const AmpTail tail{scale, growth_tracker, found_inf, step, ticket, growth_factor, backoff_factor, growth_interval, live};
+    const AdamSecondSet second{params1, exp_avgs1, exp_avg_sqs1, live, AdamRepair{static_cast<half_t*>(repair_half), {repair_param0, repair_param1}, repair_n}};
+    return adam_half_launch(count, params, exp_avgs, exp_avg_sqs, grads16, params16, n, step, 1.0f, lr, beta1, beta2, eps, scale, found_inf, tail, stream,
+                            bf16_mask, &second);
 }
 
 namespace {
 int adam_half_launch(int count, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, const void* const* grads_half,
                      void* const* params_half, const uint64_t* n, const float* step, float step_offset, double lr, double beta1, double beta2,
-                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream, uint32_t bf16_mask) {
+                     double eps, const float* grad_scale, const float* found_inf, const AmpTail& tail, void* stream, uint32_t bf16_mask,
+                     const AdamSecondSet* second) {
     clear_error();
     if (count < 0 || count > kMaxTensors) {
         set_error("adam_half_step: at most 8 tensors per call");
@@ -416,11 +466,17 @@ int adam_half_launch(int count, float* const* params, float* const* exp_avgs, fl
     uint32_t blocks = 0;
     for (int t = 0; t < count; t++) {
         if (n[t] == 0) continue;
-        if (misaligned(params[t]) || misaligned(exp_avgs[t]) || misaligned(exp_avg_sqs[t]) || misaligned(grads_half[t]) || misaligned(params_half[t])) {
+        if (misaligned(params[t]) || misaligned(exp_avgs[t]) || misaligned(exp_avg_sqs[t]) || misaligned(grads_half[t]) || misaligned(params_half[t]) ||
+            (second && (misaligned(second->params1[t]) || misaligned(second->exp_avgs1[t]) || misaligned(second->exp_avg_sqs1[t])))) {
             set_error("adam_half_step: buffers must be 16-byte aligned");
             return NERFTEX_ERR_INVALID;
         }
         const int k = tens.count++;
+        if (second) {
+            tens.param1[k] = second->params1[t];
+            tens.exp_avg1[k] = second->exp_avgs1[t];
+            tens.exp_avg_sq1[k] = second->exp_avg_sqs1[t];
+        }
         tens.param[k] = params[t];
         tens.exp_avg[k] = exp_avgs[t];
         tens.exp_avg_sq[k] = exp_avg_sqs[t];
@@ -432,10 +488,16 @@ int adam_half_launch(int count, float* const* params, float* const* exp_avgs, fl
         tens.block_end[k] = blocks;
     }
     hipStream_t st = as_stream(stream);
-    if (tens.count == 0) {  // nothing to update: the scaler's bookkeeping still happens
+    AdamRepair repair{};
+    if (second) {
+        tens.live = second->live;
+        repair = second->repair;
+        if (repair.n) blocks = std::max(blocks, std::min<uint32_t>(blocks_for(repair.n / 8, kAdamThreads), 1024u));  // a skipped step: every block helps
+    }
+    if (tens.count == 0 && !repair.n) {  // nothing to update: the scaler's bookkeeping still happens
         if (tail.scale) {
             hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, st, tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor,
-                               tail.backoff_factor, tail.growth_interval);
+                               tail.backoff_factor, tail.growth_interval, tail.live);
             return check_launch("adam_half_step(amp)");
         }
         return NERFTEX_OK;
@@ -443,7 +505,7 @@ int adam_half_launch(int count, float* const* params, float* const* exp_avgs, fl
     const AdamConsts k{lr, beta1, beta2, eps};
     {
         KernelTimer kt("adam_half_kernel", st);
-        hipLaunchKernelGGL(adam_half_kernel, dim3(blocks), dim3(kAdamThreads), 0, st, tens, step, step_offset, k, grad_scale, found_inf, tail);
+        hipLaunchKernelGGL(adam_half_kernel, dim3(blocks), dim3(kAdamThreads), 0, st, tens, step, step_offset, k, grad_scale, found_inf, tail, repair);
     }
     return check_launch("adam_half_step");
 }
@@ -497,7 +559,7 @@ extern "C" int nerftex_amp_update(float* scale, int32_t* growth_tracker, float* 
     {
         KernelTimer kt("amp_update_kernel", st);
         hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, st, scale, growth_tracker, found_inf, step, growth_factor, backoff_factor,
-                           growth_interval);
+                           growth_interval, (uint32_t*)nullptr);
     }
     return check_launch("amp_update");
 }

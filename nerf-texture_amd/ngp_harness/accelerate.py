@@ -41,7 +41,8 @@ RING = 16
 
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
-                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0, skip_zero_gradient_steps=None):
+                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0, skip_zero_gradient_steps=None,
+                 fused_table_update=None):
         from .model import NGPField
 
         field = renderer.field
@@ -98,6 +99,15 @@ class AcceleratedTrainer:
             import nerftex_hip
 
             nerftex_hip.check(nerftex_hip.lib.nerftex_tune_set(b"ffmlp_bwd_skip_zero", int(bool(skip_zero_gradient_steps))))
+        # fused_table_update (round 6; None = on wherever it exists): the hash-grid backward's summing kernel applies Adam to the hashed levels' rows
+        # from its LDS tiles -- the record walk of some workgroups beside the parameter stream of others -- instead of writing their gradient for
+        # the optimizer launch to read back (optim.FusedAmp.fuse_table_update).  Same parameters bit for bit, skipped overflow steps included; the
+        # optimizer state is double-buffered: the fp32 module parameters are current after `trainer.sync()` (state_dict() calls it).
+        can_fuse = bool(self.fused and self.amp is not None and hasattr(self.amp, "covered") and not self.pipeline_adam and field.mlp == "ffmlp")
+        self.fused_table_update = can_fuse if fused_table_update is None else bool(fused_table_update)
+        assert not self.fused_table_update or can_fuse, "fused_table_update needs the fused FFMLP field under FusedAmp (and no pipeline_adam)"
+        if self.fused_table_update:
+            self.amp.fuse_table_update(field.encoder)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
         self._graphs, self._M = None, 0
         # steps_per_call = k > 1: `step_group` takes the batches of k consecutive steps at once and replays ONE graph for their shade + backward +
@@ -336,6 +346,12 @@ class AcceleratedTrainer:
         else:
             self._ring_end(ready)
         return self.loss
+
+    def sync(self):
+        """Make the fp32 module parameters and the optimizer's moment tensors current (double-buffered optimizer state, `fused_table_update`): one
+        4-byte read-back.  The 16-bit copies the kernels read are always current."""
+        if self.fused:
+            self.opt.sync()
 
     def _side_stream(self):
         if self._side is None:

@@ -125,6 +125,7 @@ class _ngp_field(Function):
             ctx.mlp_dtype = mlp_dtype
             ctx.amp_sink = getattr(enc, "amp_sink", None)  # optim.FusedAmp.attach: the backward's kernels raise found_inf themselves
             ctx.grad_chunker = getattr(enc, "grad_chunker", None)  # dp.TableGradChunks: the table gradient is finished level group by level group
+            ctx.table_adam = getattr(enc, "table_adam", None)  # optim.FusedAmp.fuse_table_update: the summing kernel applies Adam to the tiles it owns
         else:
             check(field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
         ctx.set_materialize_grads(False)
@@ -187,7 +188,19 @@ class _ngp_field(Function):
                     sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
                 return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None, None
             chunker.begin(grad_table, None, keep=None)  # (small batch / unknown table: the one-call backward below; the groups are complete already)
-        if sink is not None:
+        fuse = ctx.table_adam.table_adam_for(table_h) if (ctx.table_adam is not None and ctx.table_adam is sink and chunker is None) else None
+        if fuse is not None:
+            # round 6: the hashed levels' tiles never leave LDS as a gradient -- their owners run Adam on the rows (double-buffered state, so that a
+            # step GradScaler skips leaves no trace); grad_table receives the coarse levels' rows [0, first) only, the rest stays uninitialised
+            import ctypes
+
+            first = ctypes.c_uint32(0)
+            check(lib.nerftex_grid_encode_backward_adam(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
+                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(fuse), ctypes.byref(first),
+                                                        stream()))
+            sink.opt.fused_table = (sink.table_index, int(first.value))
+            sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
+        elif sink is not None:
             check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H,
                                                        0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],
                                                        affine[1], found, stream()))

@@ -45,7 +45,7 @@ class HalfLeafAdam(torch.optim.Optimizer):
         kernels under autocast.  The 16-bit type is per owner (round 5): a bf16 field keeps its hash table in fp16 -- gridencoder/grid.py:38-41
         casts it to half under ANY autocast -- and its MLP weights in bf16; one launch updates all of them."""
         assert 1 <= len(owners) <= 8
-        self.masters, self.leaves = [], []
+        self.masters, self.leaves, self._owners = [], [], []
         self.bf16_mask = 0
         for i, owner in enumerate(owners):
             mod, name = owner[0], owner[1]
@@ -56,12 +56,59 @@ class HalfLeafAdam(torch.optim.Optimizer):
             assert (master.is_cuda or not self._needs_device) and master.dtype == torch.float32 and master.is_contiguous()
             leaf = master.detach().to(dt).requires_grad_(True)
             mod.half_leaf = leaf
+            self._owners.append(mod)
             self.masters.append(master)
             self.leaves.append(leaf)
         super().__init__([{"params": list(self.leaves)}], dict(lr=lr, betas=betas, eps=eps))
         self.exp_avg = [torch.zeros_like(m.data) for m in self.masters]
         self.exp_avg_sq = [torch.zeros_like(m.data) for m in self.masters]
         self.step_count = torch.zeros((), dtype=torch.float32, device=self.masters[0].device)  # completed steps; device-side for graph replay
+        self.live = None  # double-buffered form (enable_double_buffer): device word, which of the two state sets holds the current state
+        self.fused_table = None  # (leaf index, first row) of a table whose rows from there on this step's backward has updated already
+
+    # ---- double-buffered state (round 6): what lets the hash-grid backward apply the update of the hashed levels from its LDS tiles -----------
+    def enable_double_buffer(self):
+        """Give every parameter a SECOND set of (fp32 master, exp_avg, exp_avg_sq) and a device word `live` that says which set is current.  Every
+        update then reads the live set and writes the other one, and the word flips -- on the device, by the step's last launch -- only when the
+        step is applied: a step GradScaler has to skip leaves no trace, whichever kernels of it had already written (csrc/gridencoder_binned.hip
+        TileAdam, nerftex_adam_mixed_step_amp_db).  +12 B per parameter (151 MB for the fox table).
+        The module parameters (`encoder.embeddings`, ...) and `exp_avg` / `exp_avg_sq` are Python references to ONE of the two sets: call `sync()`
+        (one 4-byte read-back) before looking at them -- `state_dict()`, `load_state_dict()`, `resync()` and the owners' `state_dict()` do."""
+        if self.live is not None:
+            return self
+        dev = self.masters[0].device
+        self._p = [[m.data for m in self.masters], [torch.empty_like(m.data) for m in self.masters]]
+        self._m = [list(self.exp_avg), [torch.empty_like(t) for t in self.exp_avg]]
+        self._v = [list(self.exp_avg_sq), [torch.empty_like(t) for t in self.exp_avg_sq]]
+        self.live = torch.zeros((), dtype=torch.int32, device=dev)
+        self._hooks = [mod.register_state_dict_pre_hook(lambda *_a, **_k: self.sync()) for mod in self._owners]
+        return self
+
+    def sync(self):
+        """Double-buffered form: point the module parameters and `exp_avg` / `exp_avg_sq` at the live state set (reads one device word: blocks
+        until the steps launched so far are done).  Replayed graphs are not affected: they hold both sets' addresses."""
+        if self.live is None:
+            return
+        live = int(self.live.item()) & 1
+        for i, master in enumerate(self.masters):
+            master.data = self._p[live][i]
+            self.exp_avg[i] = self._m[live][i]
+            self.exp_avg_sq[i] = self._v[live][i]
+
+    def table_adam(self, i, amp):
+        """nerftex_table_adam for leaf i (the hash table) under the loss scaler `amp`: what nerftex_grid_encode_backward_adam needs to update the
+        table's hashed rows itself."""
+        from nerftex_hip import TableAdam
+
+        assert self.live is not None, "enable_double_buffer() first"
+        grp = self.param_groups[0]
+        t = TableAdam()
+        for k in range(2):
+            t.param[k], t.exp_avg[k], t.exp_avg_sq[k] = self._p[k][i].data_ptr(), self._m[k][i].data_ptr(), self._v[k][i].data_ptr()
+        t.param_half, t.live, t.step = self.leaves[i].data_ptr(), self.live.data_ptr(), self.step_count.data_ptr()
+        t.grad_scale, t.found_inf = amp.scale.data_ptr(), amp.found_inf.data_ptr()
+        t.lr, t.beta1, t.beta2, t.eps = float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"]
+        return t
 
     def trainable(self):
         """The tensors whose `.grad` the backward pass fills (what a gradient all-reduce has to cover)."""
@@ -71,12 +118,14 @@ class HalfLeafAdam(torch.optim.Optimizer):
     def resync(self):
         """Re-derive the fp16 leaves from the fp32 masters: after `load_state_dict` on the owning modules (a checkpoint) the kernels
         would otherwise keep reading the old copies."""
+        self.sync()
         for master, leaf in zip(self.masters, self.leaves):
             leaf.copy_(master)
 
     def state_dict(self):
         """torch.optim.Adam's layout (state: {index: {step, exp_avg, exp_avg_sq}}, param_groups), so that a checkpoint written here
         loads into `torch.optim.Adam` over the fp32 parameters and vice versa (nerf/utils.py:1505, 1581-1586)."""
+        self.sync()
         step = self.step_count.detach().clone()
         # the full key set of torch.optim.Adam's param_group: Adam.__setstate__ fills in amsgrad / maximize / ... when they are missing but
         # NOT weight_decay, and its step() reads every one of them
@@ -89,6 +138,7 @@ class HalfLeafAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def load_state_dict(self, sd):
+        self.sync()
         state = sd["state"]
         grp = sd["param_groups"][0]
         if grp.get("weight_decay", 0) or grp.get("amsgrad", False) or grp.get("maximize", False):
@@ -129,6 +179,8 @@ class HalfLeafAdam(torch.optim.Optimizer):
         found_inf, ticket, growth, backoff, interval): the loss scaler's update rides along (step number *step_count + 1; the launch advances
         step_count itself)."""
         idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None and i not in exclude]
+        if self.live is not None:
+            return self._launch_double_buffered(idx, amp, exclude)
         if not idx and amp is None:
             return
         grads = [self.leaves[i].grad for i in idx]
@@ -150,10 +202,42 @@ class HalfLeafAdam(torch.optim.Optimizer):
         for i in list(idx) + list(exclude):
             torch.autograd.graph.increment_version(self.masters[i])
 
+    def _launch_double_buffered(self, idx, amp, exclude):
+        """The step's last launch over double-buffered state (nerftex_adam_mixed_step_amp_db): reads the live set, writes the other one, flips
+        `live` iff the step is applied.  A table whose hashed rows the backward has updated already (`fused_table`) is passed from row 0 to the
+        first updated row only; the rows behind are the launch's REPAIR range (their fp16 copy is re-derived from the live set on a skipped step)."""
+        assert amp is not None and not exclude, "the double-buffered optimizer runs under FusedAmp, every leaf in one launch"
+        assert idx == list(range(len(self.leaves))), "double-buffered state: every parameter must be written every step (a leaf without a gradient would go stale when the sets flip)"
+        fused, self.fused_table = self.fused_table, None
+        cut = {}
+        repair = (None, None, None, 0)
+        if fused is not None:
+            i, first_row = fused
+            cut[i] = int(first_row)
+            leaf = self.leaves[i]
+            if first_row < leaf.shape[0]:
+                repair = (leaf.data[first_row:], self._p[0][i][first_row:], self._p[1][i][first_row:], leaf.data[first_row:].numel())
+        view = lambda t, i: t[:cut[i]] if i in cut else t  # noqa: E731
+        grads = [view(self.leaves[i].grad, i) for i in idx]
+        for i, g in zip(idx, grads):
+            assert g.dtype == self.leaves[i].dtype and g.is_contiguous()
+        mask = sum(1 << k for k, i in enumerate(idx) if (self.bf16_mask >> i) & 1)
+        grp = self.param_groups[0]
+        n = (ctypes.c_uint64 * max(len(idx), 1))(*[g.numel() for g in grads])
+        sets = [_ptr_array([view(s[k][i], i) for i in idx]) for k in range(2) for s in (self._p, self._m, self._v)]  # p0 m0 v0 p1 m1 v1
+        scale, tracker, found, ticket, growth, backoff, interval = amp
+        check(lib.nerftex_adam_mixed_step_amp_db(len(idx), *sets, _ptr_array(grads), _ptr_array([view(self.leaves[i].data, i) for i in idx]), n, mask,
+                                                 ptr(self.step_count), float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], ptr(scale), ptr(tracker),
+                                                 ptr(found), ptr(ticket), growth, backoff, interval, ptr(self.live), ptr(repair[0]), ptr(repair[1]), ptr(repair[2]),
+                                                 int(repair[3]), stream()))
+        for i in idx:
+            torch.autograd.graph.increment_version(self.masters[i])
+
     @torch.no_grad()
     def step(self, closure=None):
         """torch.optim protocol (plain, or driven by torch.amp.GradScaler through grad_scale / found_inf)."""
         assert closure is None
+        assert self.live is None, "the double-buffered optimizer is driven by FusedAmp.step()"
         _poll_deferred_error()
         grad_scale = getattr(self, "grad_scale", None)
         found_inf = getattr(self, "found_inf", None)
@@ -192,6 +276,28 @@ class FusedAmp:
         encoder.amp_sink = self
         return self
 
+    def fuse_table_update(self, encoder):
+        """Round 6: let the fused field's backward over this encoder apply Adam to the hash table's hashed levels FROM THE TILES of its summing
+        kernel (nerftex_grid_encode_backward_adam) instead of writing their gradient for the optimizer launch to read back: the VALU-bound record
+        walk of some workgroups then overlaps the HBM-bound parameter stream of others inside one kernel.  Same parameters, bit for bit, overflow
+        steps included (tests/test_gpu_round6.py); the optimizer state becomes double-buffered (HalfLeafAdam.enable_double_buffer: read `sync()`
+        there).  After such a step the table's `.grad` holds the gradient of the coarse levels' rows only -- the rest of that tensor is
+        uninitialised memory.  Single-process training (a gradient all-reduce needs the whole gradient); implies attach()."""
+        self.attach(encoder)
+        self.opt.enable_double_buffer()
+        tables = [i for i, mod in enumerate(self.opt._owners) if mod is encoder]
+        assert tables and not (self.opt.bf16_mask >> tables[0]) & 1, "the encoder's table must be one of the optimizer's fp16 leaves"
+        self.table_index = tables[0]
+        encoder.table_adam = self
+        return self
+
+    def table_adam_for(self, table_h):
+        """-> nerftex_table_adam when `table_h` is the optimizer's own fp16 leaf (else None: the ordinary backward)."""
+        i = getattr(self, "table_index", None)
+        if i is None or table_h.data_ptr() != self.opt.leaves[i].data_ptr():
+            return None
+        return self.opt.table_adam(i, self)
+
     def scale_loss(self, loss):
         return loss * self.scale
 
@@ -223,6 +329,9 @@ class FusedAmp:
         if covered:  # gradients whose producing kernels already raised found_inf (attach): the very tensors, untouched since
             grads = [g for g in grads if g.data_ptr() not in covered]
             self.covered = None
+        if self.opt.fused_table is not None:  # most of that tensor is uninitialised memory: it must not be scanned (nor be anything but the backward's own buffer)
+            g = self.opt.leaves[self.opt.fused_table[0]].grad
+            assert g is not None and all(g.data_ptr() != o.data_ptr() for o in grads), "the table gradient of a fused update must be the backward's own tensor"
         if grads:
             self._check(grads)
         # Adam (skipped on overflow) and the scale / step-counter update in one launch

@@ -1,0 +1,259 @@
+"""GPU: round 6.
+
+  * nerftex_grid_encode_backward_adam + nerftex_adam_mixed_step_amp_db (the hash-grid backward's summing kernel applies Adam to the tiles it owns,
+    over double-buffered optimizer state) against nerftex_grid_encode_backward_amp + nerftex_adam_mixed_step_amp: the same fp32 masters, moments
+    and fp16 table, bit for bit, over steps that include an inf in the incoming gradient, a row that overflows fp16 as a SUM of finite shares
+    (the case no tile can see coming) and a scale that is not a power of two;
+  * accelerate(fused_table_update=True) against accelerate(fused_table_update=False): same losses and parameters through priming, warm-up,
+    replayed graphs and a forced overflow.
+The optimizer being restated is the reference's: main_nerf.py:128 `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` under the GradScaler of
+nerf/utils.py:1003-1009 (tests/test_gpu_trainstep.py pins the streaming kernel to torch's fused Adam; this file pins the tile form to that kernel).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _bits(t):
+    return t.view(torch.int32 if t.dtype == torch.float32 else torch.int16)
+
+
+@pytest.mark.parametrize("B", [65536, 4096, 459264], ids=["two_shared_levels", "no_shared_level", "bench_size"])
+def test_backward_adam_equals_backward_then_adam(dev, oracle, B):
+    from nerftex_hip import F16, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, TableAdam, check, lib, ptr, stream
+
+    off_np, rows = oracle.grid_offsets(3, 16, 1.447269, 16, 19, True)
+    off = torch.from_numpy(off_np).to(dev)
+    check(lib.nerftex_grid_register_offsets(ptr(off), 16, off_np.ctypes.data))
+    S = float(np.log2(1.447269))
+    gen = torch.Generator(device=dev).manual_seed(B)
+    x = torch.rand(B, 3, device=dev, generator=gen) * 4 - 2
+    n_w = 7168  # a second, small tensor in the closing launch (an MLP's weights)
+
+    def fresh():
+        g = torch.Generator(device=dev).manual_seed(5)
+        p = (torch.rand(rows, 2, device=dev, generator=g) - 0.5) * 1e-2
+        st = dict(p=p, m=torch.zeros_like(p), v=torch.zeros_like(p), h=p.half(), wp=torch.rand(n_w, device=dev, generator=g) - 0.5)
+        st.update(wm=torch.zeros(n_w, device=dev), wv=torch.zeros(n_w, device=dev), wh=st["wp"].half())
+        st.update(step=torch.zeros((), device=dev), scale=torch.full((), 65536.0, device=dev), tracker=torch.zeros((), dtype=torch.int32, device=dev),
+                  found=torch.zeros((), device=dev), ticket=torch.zeros((), dtype=torch.int32, device=dev))
+        return st
+
+    hyper = (1e-2, 0.9, 0.99, 1e-15)
+    amp_consts = (2.0, 0.5, 3)  # growth every 3 clean steps: the scale moves during the test
+
+    def arr(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    def grads_for(step):
+        g = torch.Generator(device=dev).manual_seed(1000 + step)
+        gx = (torch.randn(B, 32, device=dev, generator=g) * 3e-2).half()
+        gw = (torch.randn(n_w, device=dev, generator=g) * 1e-1).half()
+        xs = x
+        if step == 2:
+            gx[B // 3, 9] = float("inf")
+        if step == 4:  # 48 samples at one position, 60000 each on one level: a row overflows as a sum of finite shares
+            xs = x.clone()
+            xs[B // 2 - 24:B // 2 + 24] = x[B // 2].clone()
+            gx[B // 2 - 24:B // 2 + 24, 2 * 11] = 60000.0
+        return xs, gx, gw
+
+    # ---- the two-launch path: backward writes the whole fp16 gradient, one Adam launch reads it
+    ref = fresh()
+    ref_trace = []
+    for step in range(8):
+        xs, gx, gw = grads_for(step)
+        if step == 6:
+            ref["scale"].fill_(3000.0)  # not a power of two: the division path of the unscale
+        gt = torch.empty(rows, 2, dtype=torch.float16, device=dev)
+        check(lib.nerftex_grid_encode_backward_amp(ptr(gx), ptr(xs), None, ptr(off), ptr(gt), B, 3, 2, 16, S, 16, 0, None, None, 0, 1, F16,
+                                                   LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25, ptr(ref["found"]), stream()))
+        n = (ctypes.c_uint64 * 2)(rows * 2, n_w)
+        check(lib.nerftex_adam_mixed_step_amp(2, arr([ref["p"], ref["wp"]]), arr([ref["m"], ref["wm"]]), arr([ref["v"], ref["wv"]]), arr([gt, gw]),
+                                              arr([ref["h"], ref["wh"]]), n, 0, ptr(ref["step"]), *hyper, ptr(ref["scale"]), ptr(ref["tracker"]), ptr(ref["found"]),
+                                              ptr(ref["ticket"]), *amp_consts, stream()))
+        ref_trace.append((float(ref["step"]), float(ref["scale"]), ref["h"].clone(), gt))
+    assert [t[0] for t in ref_trace] == [1, 2, 2, 3, 3, 4, 5, 6], "steps 2 (inf) and 4 (row-sum overflow) are skipped"
+
+    # ---- the fused path over double-buffered state
+    st = fresh()
+    sets = {k: [st[k], torch.full_like(st[k], float("nan"))] for k in ("p", "m", "v", "wp", "wm", "wv")}
+    live = torch.zeros((), dtype=torch.int32, device=dev)
+    ta = TableAdam()
+    for k in range(2):
+        ta.param[k], ta.exp_avg[k], ta.exp_avg_sq[k] = sets["p"][k].data_ptr(), sets["m"][k].data_ptr(), sets["v"][k].data_ptr()
+    ta.param_half, ta.live, ta.step, ta.grad_scale, ta.found_inf = st["h"].data_ptr(), live.data_ptr(), st["step"].data_ptr(), st["scale"].data_ptr(), st["found"].data_ptr()
+    ta.lr, ta.beta1, ta.beta2, ta.eps = hyper
+    lives = []
+    for step in range(8):
+        xs, gx, gw = grads_for(step)
+        if step == 6:
+            st["scale"].fill_(3000.0)
+        gt = torch.full((rows, 2), float("nan"), dtype=torch.float16, device=dev)
+        first = ctypes.c_uint32(12345)
+        check(lib.nerftex_grid_encode_backward_adam(ptr(gx), ptr(xs), ptr(off), ptr(gt), B, 3, 2, 16, S, 16, 0, 1, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25,
+                                                    ctypes.byref(ta), ctypes.byref(first), stream()))
+        f = int(first.value)
+        assert f in [int(o) for o in off_np], "the first updated row is a level boundary"
+        if B == 65536:
+            assert f == int(off_np[2])
+        if B == 4096:
+            assert f == 0
+        # the coarse levels' gradient rows are the ordinary backward's, the rest of the buffer was left alone
+        assert torch.equal(_bits(gt[:f]), _bits(ref_trace[step][3][:f]))
+        assert torch.isnan(gt[f:]).all()
+        n = (ctypes.c_uint64 * 2)(f * 2, n_w)
+        cut = lambda t: t[:f]  # noqa: E731
+        check(lib.nerftex_adam_mixed_step_amp_db(
+            2, arr([cut(sets["p"][0]), sets["wp"][0]]), arr([cut(sets["m"][0]), sets["wm"][0]]), arr([cut(sets["v"][0]), sets["wv"][0]]),
+            arr([cut(sets["p"][1]), sets["wp"][1]]), arr([cut(sets["m"][1]), sets["wm"][1]]), arr([cut(sets["v"][1]), sets["wv"][1]]),
+            arr([cut(gt), gw]), arr([cut(st["h"]), st["wh"]]), n, 0, ptr(st["step"]), *hyper, ptr(st["scale"]), ptr(st["tracker"]), ptr(st["found"]), ptr(st["ticket"]),
+            *amp_consts, ptr(live), ptr(st["h"][f:]), ptr(sets["p"][0][f:]), ptr(sets["p"][1][f:]), (rows - f) * 2, stream()))
+        lives.append(int(live.item()))
+        assert (float(st["step"]), float(st["scale"])) == ref_trace[step][:2], step
+        assert torch.equal(_bits(st["h"]), _bits(ref_trace[step][2])), f"fp16 table after step {step}"
+    assert lives == [1, 0, 0, 1, 1, 0, 1, 0], "the state sets flip on applied steps only"
+    k = lives[-1]
+    for name, rname in (("p", "p"), ("m", "m"), ("v", "v"), ("wp", "wp"), ("wm", "wm"), ("wv", "wv")):
+        assert torch.equal(_bits(sets[name][k]), _bits(ref[rname])), name
+    assert torch.equal(_bits(st["wh"]), _bits(ref["wh"]))
+
+
+def test_backward_adam_refuses_what_it_cannot_do(dev, oracle):
+    from nerftex_hip import F16, F32, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, TableAdam, lib, ptr, stream
+
+    off_np, rows = oracle.grid_offsets(3, 16, 1.447269, 16, 19, True)
+    off = torch.from_numpy(off_np).to(dev)
+    lib.nerftex_grid_register_offsets(ptr(off), 16, off_np.ctypes.data)
+    B = 4096
+    x = torch.rand(B, 3, device=dev)
+    gx = torch.zeros(B, 32, dtype=torch.float16, device=dev)
+    gt = torch.empty(rows, 2, dtype=torch.float16, device=dev)
+    bufs = [torch.zeros(rows, 2, device=dev) for _ in range(6)]
+    h = torch.zeros(rows, 2, dtype=torch.float16, device=dev)
+    words = torch.zeros(4, device=dev)
+    live = torch.zeros((), dtype=torch.int32, device=dev)
+    ta = TableAdam()
+    for k in range(2):
+        ta.param[k], ta.exp_avg[k], ta.exp_avg_sq[k] = bufs[3 * k].data_ptr(), bufs[3 * k + 1].data_ptr(), bufs[3 * k + 2].data_ptr()
+    ta.param_half, ta.live, ta.step, ta.grad_scale, ta.found_inf = h.data_ptr(), live.data_ptr(), words[0:].data_ptr(), 0, words[1:].data_ptr()
+    ta.lr, ta.beta1, ta.beta2, ta.eps = 1e-2, 0.9, 0.99, 1e-15
+    first = ctypes.c_uint32(0)
+
+    def call(dtype=F16, layout=LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, C=2, adam=ta):
+        return lib.nerftex_grid_encode_backward_adam(ptr(gx), ptr(x), ptr(off), ptr(gt), B, 3, C, 16, float(np.log2(1.447269)), 16, 0, 1, dtype, layout, 0.0, 1.0,
+                                                     ctypes.byref(adam) if adam is not None else None, ctypes.byref(first), stream())
+
+    assert call() == 0
+    assert call(dtype=F32) != 0 and b"fp16" in lib.nerftex_last_error()
+    assert call(layout=LAYOUT_BLC) != 0
+    assert call(C=4) != 0
+    assert call(adam=None) != 0
+    ta.live = 0
+    assert call() != 0 and b"NULL" in lib.nerftex_last_error()
+    torch.cuda.synchronize()
+
+
+def _trainer_pair(dev, fused_table_update, k):
+    from ngp_harness import scene
+    from ngp_harness.accelerate import accelerate
+    from ngp_harness.model import NGPField, Renderer
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+    r.set_occupancy(torch.from_numpy(grid).to(dev))
+    return field, accelerate(r, dt_gamma=1 / 128, steps_per_call=k, fused_table_update=fused_table_update)
+
+
+def test_fused_table_update_trains_like_the_two_launch_step(dev):
+    """accelerate(..., fused_table_update=True) -- the hashed levels updated from the summing kernel's tiles, double-buffered state -- against
+    fused_table_update=False (gradient tensor + one streaming Adam launch): the same losses and the same parameters, bit for bit, after
+    16 + 4 + 40 steps through `step_group` (priming on full-size buffers, warm-up, replayed graphs, marches ahead), with the loss scale forced
+    to overflow inside the replayed part (GradScaler skips that step whole: the tiles updated before the overflow was seen must leave no
+    trace) and one more overflow right after it."""
+    from ngp_harness import scene
+
+    n, n_pool, k = 4096, 8, 4
+    pool = []
+    for j in range(n_pool):
+        o, d = scene.train_batch(n, seed=500 + j, n_views=2)
+        pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
+    gt = torch.rand(n_pool, n, 3, generator=torch.Generator().manual_seed(23)).to(dev)
+    po = [torch.stack([pool[c * 4 + i][0] for i in range(4)]).contiguous() for c in range(2)]
+    pd = [torch.stack([pool[c * 4 + i][1] for i in range(4)]).contiguous() for c in range(2)]
+    pt = [gt[c * 4:(c + 1) * 4].contiguous() for c in range(2)]
+    total = 16 + 4 + 40
+    out = {}
+    for fuse in (False, True):
+        field, tr = _trainer_pair(dev, fuse, k)
+        assert tr.fused_table_update == fuse
+        losses, scales = [], []
+        for c in range(total // k):
+            if c == 9:
+                tr.amp.scale.fill_(2.0 ** 31)  # the next steps overflow until the scale has backed off far enough
+            nxt = (po[(c + 1) % 2], pd[(c + 1) % 2]) if c >= 7 and c % 2 == 1 else None
+            tr.step_group(po[c % 2], pd[c % 2], pt[c % 2], next_rays=nxt)
+            losses.append(tr.loss.clone())
+            scales.append(tr.amp.scale.clone())
+        torch.cuda.synchronize()
+        assert tr._groups is not None, "the grouped graphs were recorded"
+        steps = float(tr.opt.step_count)
+        tr.sync()
+        out[fuse] = (losses, scales, steps, {n_: p.detach().clone() for n_, p in field.named_parameters()},
+                     [t.clone() for t in tr.opt.exp_avg + tr.opt.exp_avg_sq], [leaf.detach().clone() for leaf in tr.opt.leaves],
+                     {n_: v.clone() for n_, v in field.state_dict().items()})
+    a, b = out[False], out[True]
+    assert a[2] == b[2] and a[2] < total, "some steps were skipped, the same ones"
+    for i, (la, lb) in enumerate(zip(a[0], b[0])):
+        assert torch.equal(la, lb), f"loss of call {i}"
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    for name in a[3]:
+        assert torch.equal(a[3][name], b[3][name]), name
+        assert torch.equal(a[6][name], b[6][name]), f"state_dict()['{name}']"
+    for x, y in zip(a[4] + a[5], b[4] + b[5]):
+        assert torch.equal(x, y)
+
+
+def test_fused_table_update_checkpoint_round_trip(dev, tmp_path):
+    """A checkpoint written from the double-buffered optimizer loads into a fresh trainer (and the reverse direction is the ordinary path):
+    training continues on the same parameters."""
+    from ngp_harness import checkpoint, scene
+
+    n = 4096
+    o, d = scene.train_batch(n, seed=77, n_views=2)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    tg = torch.rand(n, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    f1, t1 = _trainer_pair(dev, True, 1)
+    for _ in range(5):
+        t1.step(ro, rd, tg)
+    path = str(tmp_path / "ck.pth")
+    checkpoint.save_checkpoint(path, t1.renderer, optimizer=t1.opt, scaler=t1.amp)
+    f2, t2 = _trainer_pair(dev, True, 1)
+    checkpoint.load_checkpoint(path, t2.renderer, optimizer=t2.opt, scaler=t2.amp)
+    f3, t3 = _trainer_pair(dev, False, 1)
+    checkpoint.load_checkpoint(path, t3.renderer, optimizer=t3.opt, scaler=t3.amp)
+    for t in (t1, t2, t3):
+        t.renderer.local_step = 0
+        t.renderer.step_counter.zero_()
+    for _ in range(3):
+        for t in (t1, t2, t3):
+            t.step(ro, rd, tg)
+    for t in (t1, t2, t3):
+        t.sync()
+    for (n1, p1), (_, p2), (_, p3) in zip(f1.named_parameters(), f2.named_parameters(), f3.named_parameters()):
+        assert torch.equal(p1, p2) and torch.equal(p1, p3), n1
