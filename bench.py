@@ -46,7 +46,7 @@ COMMITTED_STATS = "profiles/r05_kernel_stats.csv"  # rocprofv3 --kernel-trace --
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
-    "grid_encode_backward": ("bin_fill_dir_kernel", "sum_tiles_dir_kernel", "combine_tiles_kernel", "grad_to_level_major_kernel", "bin_count_kernel", "scan_tiles_kernel",
+    "grid_encode_backward": ("bin_fill_dir_kernel", "sum_tiles_dir_kernel", "sum_tiles_adam_kernel", "combine_tiles_kernel", "grad_to_level_major_kernel", "bin_count_kernel", "scan_tiles_kernel",
                              "scan_global_kernel", "bin_fill_kernel", "sum_tiles_kernel", "grid_backward_owner_kernel", "grid_backward_kernel",
                              "grid_input_backward_kernel"),
 }
@@ -285,8 +285,12 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     inv_world = 1.0 / world
     # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
     amp = FusedAmp(opt) if fused_amp else None
+    fused_table_update = False
     if amp is not None and world == 1 and field.fused_field:
         amp.attach(field.encoder)  # the non-finite scan rides on the kernels that write the gradients (N > 1: the scan must see the cross-rank sum)
+        if not args.no_fused_table_update:  # round 6: the table's rows updated by the owners of their final gradient (double-buffered state), as accelerate() does
+            amp.fuse_table_update(field.encoder)
+            fused_table_update = True
     # bf16 keeps the loss scaler: the hash table -- and so its gradient -- is fp16 under ANY autocast (gridencoder/grid.py:41), and unscaled
     # gradients of ~1e-6 sit in fp16's subnormal range (measured: 38 % L1 error of the table gradient without scaling, tools/precision_table.py)
     scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=dtype in ("fp16", "bf16"))
@@ -648,6 +652,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                       "allreduce_us_per_step": ev0.elapsed_time(ev1) * 100.0,
                       "allreduce_in_graph": bool(use_graph and ar_state["in_graph"]),
                       "table_gradient_chunks": len(chunker) if chunker is not None else 1, "per_chunk": chunk_us}
+    if fused_opt:
+        opt.sync()  # (double-buffered optimizer state: point the fp32 module parameters at the live set)
     param_l1 = float(sum(p.detach().double().abs().sum() for p in field.parameters()))
     replicas_identical = None
     if world > 1:  # data parallelism keeps full replicas: after the run every rank must hold the same bits (cheap: one checksum vector)
@@ -662,7 +668,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     occupancy = None
     if time_grid_kernels and not args.no_occupancy_timing:
         occupancy = measure_occupancy_update(renderer, use_amp, amp_dtype, elapsed / steps * 1e3, samples / steps / world)
-    res = dict(replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
+    res = dict(fused_table_update=fused_table_update, table_params=int(field.encoder.embeddings.numel()), replicas_identical=replicas_identical, collective=collective, param_l1=param_l1, value=samples / elapsed, ms_per_step=elapsed / steps * 1e3, samples_per_step_per_gpu=samples / steps / world,
                replay_us=replay_us, spread=spread, occupancy=occupancy, graph_used=bool(use_graph),
                mean_count=renderer.mean_count, kernel_us=kernel_us, all_kernel_us=all_kernel_us, use_amp=use_amp, fused_opt=fused_opt, dtype=dtype,
                graph=("three replayed HIP graphs per step (march | shade + backward | optimizer); the gradient all-reduce, launched eagerly after the backward, overlaps the next step's march" if split_graph else
@@ -699,7 +705,7 @@ def _replay_child_cmd(args, mlp, rays, dtype, steps):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(args.warmup), "--rays", str(rays), "--mlp", mlp,
            "--dtype", dtype, "--bound", str(args.bound), "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer",
            "--no-kernel-timing", "--baked-pool", "--no-occupancy-timing"]
-    for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb"):
+    for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb", "no_fused_table_update"):
         if getattr(args, flag, False):
             cmd.append("--" + flag.replace("_", "-"))
     return cmd
@@ -1129,7 +1135,8 @@ def main():
                 per_frame.sort()
                 t_g = sum(per_frame) / len(per_frame)
                 graphed = {"mpix_per_s": 0.64 / t_g, "ms_per_frame": t_g * 1e3, "ms_per_frame_min_median_max": [per_frame[0] * 1e3, per_frame[5] * 1e3, per_frame[-1] * 1e3],
-                           "host_ms_inside_the_call": sum(enqueue) / len(enqueue) * 1e3,  # (mostly WAITING for the block-old alive counts, not enqueueing: ~30 graph replays per frame) "iterations_launched": renderer.last_iters, "sample_slots_launched": int(n_g),
+                           # (mostly WAITING for the block-old alive counts, not enqueueing: ~30 graph replays per frame)
+                           "host_ms_inside_the_call": sum(enqueue) / len(enqueue) * 1e3, "iterations_launched": renderer.last_iters, "sample_slots_launched": int(n_g),
                            "max_abs_image_difference_vs_reference_loop": float((img_g - img_ref).abs().max()),
                            "loop": f"the loop below as HIP graphs: per ray range one graph resets it and one runs 2 iterations (replayed until no ray is left; the host "
                                    f"learns the alive count one block late from a 4-byte copy and picks the recorded launch size that covers it: all rays, 1/2, 1/4, 1/8, 1/32, ...), n_step = clamp({F} N / alive, {F}, {8 * F}) "
@@ -1229,8 +1236,16 @@ def main():
             if parts:
                 calls = max(v["calls"] for v in parts.values())
                 ms = sum(v["total_us"] for v in parts.values()) / calls * 1e-3
-                kern[name] = {"ms": ms, "gbs": bpp * M_launch / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
+                # round 6, fused table update: the backward's summing / combine kernels ALSO run the optimizer on the table (fp32 master + two moments
+                # read, the same three + the fp16 copy written: 26 B per parameter, no gradient tensor in between) -- those algorithmic bytes belong
+                # to the launch; the figure on the backward's own 588 B per point is kept beside it
+                opt_bytes = 26 * res["table_params"] if (name == "grid_encode_backward" and res.get("fused_table_update")) else 0
+                kern[name] = {"ms": ms, "gbs": (bpp * M_launch + opt_bytes) / (ms * 1e-3) / 1e9, "bytes_per_point": bpp,
                               "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in parts.items()}}
+                if opt_bytes:
+                    kern[name].update(optimizer_bytes_per_launch=opt_bytes, gbs_backward_bytes_only=bpp * M_launch / (ms * 1e-3) / 1e9,
+                                      includes="Adam on the 12.6 M table parameters, applied by the owners of each row's final gradient (sum_tiles / combine_tiles); the "
+                                               "step's adam_half_kernel is left with the MLP weights and the loss scaler's update")
         return kern
 
     # durations: from INSIDE the replayed step when they could be taken there (external event-record nodes in a copy of the step's graph, the
@@ -1288,7 +1303,11 @@ def main():
             "bound": BOUND[dominant][0], "kernel": dominant, "achieved": kern[dominant]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kern[dominant]["gbs"] / HBM_PEAK_GBS, "traffic": traffic.get(dominant, {}).get("bytes"),
             "traffic_source": traffic_source, "traffic_per_kernel_MB": traffic.get(dominant, {}).get("per_kernel_MB"),
-            "traffic_over_algorithmic": (traffic[dominant]["bytes"] / (kern[dominant]["bytes_per_point"] * M_launch)) if traffic.get(dominant, {}).get("bytes") else None,
+            "traffic_over_algorithmic": (traffic[dominant]["bytes"] / (kern[dominant]["bytes_per_point"] * M_launch + kern[dominant].get("optimizer_bytes_per_launch", 0)))
+            if traffic.get(dominant, {}).get("bytes") else None,
+            "fused_table_update": bool(kern[dominant].get("optimizer_bytes_per_launch")), "optimizer_bytes_per_launch": kern[dominant].get("optimizer_bytes_per_launch"),
+            "frac_backward_bytes_only": (kern[dominant]["gbs_backward_bytes_only"] / HBM_PEAK_GBS) if kern[dominant].get("gbs_backward_bytes_only") else None,
+            "includes": kern[dominant].get("includes"),
             "avg_launch_ms": kern[dominant]["ms"], "points_per_launch": M_launch, "algorithmic_bytes_per_point": kern[dominant]["bytes_per_point"],
             "kernels_avg_us": kern[dominant]["kernels_avg_us"],
             "durations_from": ("the replayed step: " + source if in_replay else

@@ -16,25 +16,34 @@ struct AdamConsts {
 // what every parameter of one step shares
 struct AdamStep {
     float step_size, bc2_sqrt;
-    double unscale;  // multiplied into (or, !unscale_exact, divided out of) the 16-bit gradient
+    double unscale;  // !unscale_exact: divided out of the 16-bit gradient
+    float unscale_f;  // unscale_exact: multiplied into it (single precision: the product is exact)
     bool has_scale, unscale_exact;
 };
 
-// step number `steps` (1-based).  GradScaler's scales are powers of two (65536 x 2^k): then the division of the gradient by the scale is a
-// multiplication by its exact reciprocal -- the same double, bit for bit (a half times 2^-k is exact in double) -- and costs one instruction
-// instead of a double division (~40) per parameter; any other scale keeps the division.
-__device__ __forceinline__ AdamStep adam_step_consts(const AdamConsts& k, const double steps, const float* grad_scale) {
+// step number `steps` (1-based).  GradScaler's scales are powers of two (65536 x 2^k): then the division of the gradient by the scale -- in double,
+// rounded to float, as the framework's kernel does it -- is a multiplication by its exact reciprocal: a half (fp16: >= 2^-24) times 2^-k is exact
+// in single precision as long as it stays a normal number, so ONE fp32 multiply gives the same bits as the double division (~40 instructions)
+// plus its two conversions; any other scale keeps the division.
+__device__ __forceinline__ AdamStep adam_step_consts(const AdamConsts& k, const double steps, const bool has_scale, const float scale) {
     AdamStep s;
     const float bc1 = (float)(1 - pow(k.beta1, steps));
     s.bc2_sqrt = (float)sqrt(1 - pow(k.beta2, steps));
     s.step_size = (float)(k.lr / (double)bc1);
-    s.has_scale = grad_scale != nullptr;
-    const float sc = s.has_scale ? *grad_scale : 1.0f;
+    s.has_scale = has_scale;
+    const float sc = has_scale ? scale : 1.0f;
     const uint32_t bits = __builtin_bit_cast(uint32_t, sc);
     const uint32_t e = (bits >> 23) & 0xffu;
-    s.unscale_exact = (bits & 0x807fffffu) == 0u && e >= 1u && e <= 253u;  // a positive normal power of two whose reciprocal is a normal float
+    // a positive power of two in [2^-100, 2^100]: a 16-bit gradient (>= 2^-24 in magnitude, or 2^-133 for bf16 subnormals -- flushed or not, a
+    // zero product is a zero quotient's rounding only below 2^-149) times its reciprocal is an exact, normal float
+    s.unscale_exact = (bits & 0x807fffffu) == 0u && e >= 27u && e <= 227u;
     s.unscale = s.unscale_exact ? 1.0 / (double)sc : (double)sc;
+    s.unscale_f = s.unscale_exact ? 1.0f / sc : 1.0f;
     return s;
+}
+
+__device__ __forceinline__ AdamStep adam_step_consts(const AdamConsts& k, const double steps, const float* grad_scale) {
+    return adam_step_consts(k, steps, grad_scale != nullptr, grad_scale ? *grad_scale : 1.0f);
 }
 
 // the moment updates are fused multiply-adds in double, fma(beta, state, (1 - beta) * g ...): how the framework's kernel comes out of
@@ -42,11 +51,14 @@ __device__ __forceinline__ AdamStep adam_step_consts(const AdamConsts& k, const 
 // float rounding tie about once in 500 updates, and the two forms fall on different sides of it.
 __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float grad, const AdamConsts& k, const AdamStep& s) {
 #pragma clang fp contract(off)
-    if (s.has_scale) grad = s.unscale_exact ? (float)((double)grad * s.unscale) : (float)((double)grad / s.unscale);
+    if (s.has_scale) grad = s.unscale_exact ? grad * s.unscale_f : (float)((double)grad / s.unscale);
     const double g = (double)grad;
     m = (float)fma(k.beta1, (double)m, (1 - k.beta1) * g);
     v = (float)fma(k.beta2, (double)v, (1 - k.beta2) * g * g);
-    const float denom = (float)((double)(sqrtf(v) / s.bc2_sqrt) + k.eps);
+    // (from step ~1700 on -- beta2 = 0.99 -- the bias correction has rounded to exactly 1: dividing by it is the identity, a uniform branch saves the
+    // ~11 instructions of an IEEE division per parameter where the update runs inside a VALU-bound kernel)
+    const float root = sqrtf(v);
+    const float denom = (float)((double)(s.bc2_sqrt == 1.0f ? root : root / s.bc2_sqrt) + k.eps);
     p -= s.step_size * m / denom;
 }
 

@@ -142,6 +142,7 @@ struct TileAdam {
     const float* step;     // completed optimizer steps; this update is number *step + 1
     const float* grad_scale;
     AdamConsts k;
+    AdamStep* step_consts;  // library scratch: the step's constants, written by the summing launch for the combine launch behind it
 };
 
 // inf / nan in either half of a pair of fp16 gradient elements
@@ -426,45 +427,55 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
     }
 }
 
-// tile -> optimizer.  Thread = 4 consecutive rows = 8 parameters: 2 x 3 16-byte loads of the live state set issued first, then the eight sums read
-// from LDS and rounded to fp16 (the gradient tensor's value), eight updates, 2 x 3 + 1 16-byte stores.  nrows % 4 == 0 and a 4-row-aligned
-// first row are the host's to check (grid levels are sized in multiples of 8 rows: gridencoder/grid.py:108).
-__device__ __forceinline__ void adam_tile(const char* smem, const TileAdam& ad, const AdamStep& as, const size_t dst_row, const uint32_t nrows, float* found_inf) {
-    const unsigned long long* acc64 = reinterpret_cast<const unsigned long long*>(smem);
-    const uint32_t from = *ad.live & 1u, to = from ^ 1u;
-    const float* __restrict__ ps = ad.p[from];
-    const float* __restrict__ ms = ad.m[from];
-    const float* __restrict__ vs = ad.v[from];
-    float* __restrict__ pd = ad.p[to];
-    float* __restrict__ md = ad.m[to];
-    float* __restrict__ vd = ad.v[to];
-    bool bad = false;
-    for (uint32_t r = threadIdx.x * 4u; r < nrows; r += kSumThreads * 4u) {
-        const size_t e = (dst_row + r) * 2;  // first of the 8 parameters
-        float4_t p[2], m[2], v[2];
+// tile -> optimizer.  Thread = 4 consecutive rows = 8 parameters (a 4096-row tile = one pass of the 1024 threads): 2 x 3 16-byte loads of the live state
+// set, the eight sums read from LDS and rounded to fp16 (the gradient tensor's value), eight updates, 2 x 3 + 1 16-byte stores.  nrows % 4 == 0 and a
+// 4-row-aligned first row are the host's to check (grid levels are sized in multiples of 8 rows: gridencoder/grid.py:108).
+// Measured alternatives (profiles/r06_tile_adam_probe.json): the state loads issued BEFORE the record walk (they return in order with the walk's own
+// loads: the first record wait absorbs them, nothing gained: 123.4 against 122.3 us), non-temporal loads / stores (slower), half of the first round's
+// workgroups started late (slower by the delay).  What is kept: the loads go out in front of the walk's closing barrier (adam_tile_load).  The kernel must stay at <= 64 registers: two 1024-thread workgroups per CU (amdgpu_waves_per_eu).
+static_assert(rows_per_tile<half_t>() == kSumThreads * 4, "adam_tile: one pass, four rows per thread");
+struct AdamRows {
+    float4_t p[2], m[2], v[2];
+};
+// the thread's 2 x 3 state loads: issued by each wave as soon as ITS share of the record walk is done, in front of the barrier that waits for the
+// slowest wave of the workgroup -- their latency runs under that wait
+__device__ __forceinline__ void adam_tile_load(const TileAdam& ad, const size_t dst_row, const uint32_t nrows, AdamRows& st) {
+    const uint32_t r = threadIdx.x * 4u;
+    if (r >= nrows) return;
+    const uint32_t from = *ad.live & 1u;
+    const size_t e = (dst_row + r) * 2;  // first of the 8 parameters
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            p[q] = *reinterpret_cast<const float4_t*>(ps + e + 4 * q);
-            m[q] = *reinterpret_cast<const float4_t*>(ms + e + 4 * q);
-            v[q] = *reinterpret_cast<const float4_t*>(vs + e + 4 * q);
-        }
+    for (int q = 0; q < 2; q++) {
+        st.p[q] = *reinterpret_cast<const float4_t*>(ad.p[from] + e + 4 * q);
+        st.m[q] = *reinterpret_cast<const float4_t*>(ad.m[from] + e + 4 * q);
+        st.v[q] = *reinterpret_cast<const float4_t*>(ad.v[from] + e + 4 * q);
+    }
+}
+__device__ __forceinline__ void adam_tile(const char* smem, const TileAdam& ad, const AdamStep& as, const size_t dst_row, const uint32_t nrows, float* found_inf,
+                                          AdamRows& st) {
+    const unsigned long long* acc64 = reinterpret_cast<const unsigned long long*>(smem);
+    const uint32_t to = (*ad.live & 1u) ^ 1u;
+    const uint32_t r = threadIdx.x * 4u;
+    bool bad = false;
+    if (r < nrows) {
+        const size_t e = (dst_row + r) * 2;
         half8_t h;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const half_t g = fixed_to_half((long long)acc64[(size_t)r * 2 + j]);
             bad |= (__builtin_bit_cast(uint16_t, g) & 0x7c00u) == 0x7c00u;
-            float pj = p[j / 4][j % 4], mj = m[j / 4][j % 4], vj = v[j / 4][j % 4];
+            float pj = st.p[j / 4][j % 4], mj = st.m[j / 4][j % 4], vj = st.v[j / 4][j % 4];
             adam_one(pj, mj, vj, (float)g, ad.k, as);
-            p[j / 4][j % 4] = pj;
-            m[j / 4][j % 4] = mj;
-            v[j / 4][j % 4] = vj;
+            st.p[j / 4][j % 4] = pj;
+            st.m[j / 4][j % 4] = mj;
+            st.v[j / 4][j % 4] = vj;
             h[j] = (half_t)pj;
         }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            *reinterpret_cast<float4_t*>(pd + e + 4 * q) = p[q];
-            *reinterpret_cast<float4_t*>(md + e + 4 * q) = m[q];
-            *reinterpret_cast<float4_t*>(vd + e + 4 * q) = v[q];
+            *reinterpret_cast<float4_t*>(ad.p[to] + e + 4 * q) = st.p[q];
+            *reinterpret_cast<float4_t*>(ad.m[to] + e + 4 * q) = st.m[q];
+            *reinterpret_cast<float4_t*>(ad.v[to] + e + 4 * q) = st.v[q];
         }
         *reinterpret_cast<half8_t*>(ad.leaf + e) = h;
     }
@@ -480,7 +491,8 @@ __device__ __forceinline__ void adam_tile(const char* smem, const TileAdam& ad, 
 // barriers in front of every pass: 137-161.)
 struct NoAdam {};
 template <typename T, bool ADAM>
-__global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
+// (8 waves per SIMD = two workgroups per CU: with the optimizer's update inlined the compiler otherwise takes 67 registers and silently halves the occupancy)
+__global__ __launch_bounds__(kSumThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void sum_tiles_dir_kernel(const Rec<T>* __restrict__ records, const uint32_t* __restrict__ dir, uint32_t L,
                                                                    const DirTable tab, uint32_t nchunks, T* __restrict__ grad_grid,
                                                                    const bool overwrite, unsigned long long* __restrict__ partials,
                                                                    const int* __restrict__ offsets, const uint32_t probe, const uint32_t item_offset,
@@ -494,7 +506,10 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
     constexpr uint32_t kWaves = kSumThreads / kWave;
     zero_tile<T>(smem, it.nrows);
     if constexpr (ADAM) {  // the step's constants (two double pows): one lane, once, while the others clear the tile
-        if (threadIdx.x == 0 && it.slices == 1) s_step = adam_step_consts(adam.k, (double)(*adam.step + 1.0f), adam.grad_scale);
+        if (threadIdx.x == 0 && (it.slices == 1 || blockIdx.x + item_offset == 0)) {
+            s_step = adam_step_consts(adam.k, (double)(*adam.step + 1.0f), adam.grad_scale);
+            if (blockIdx.x + item_offset == 0) *adam.step_consts = s_step;  // for combine_tiles_kernel<true>, the launch behind this one
+        }
     }
     __syncthreads();
 
@@ -544,6 +559,10 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
                 if (!adds_nothing<T>(q.r[j])) add_record<T>(smem, q.r[j]);
         }
     }
+    [[maybe_unused]] AdamRows rows_state;
+    if constexpr (ADAM) {
+        if (it.slices == 1) adam_tile_load(adam, it.dst_row, it.nrows, rows_state);
+    }
     __syncthreads();
     if constexpr (sizeof(T) == 2) {
         // A tile shared by several work items (coarse levels): every item leaves its EXACT integer sums in the partial-sum buffer and
@@ -558,7 +577,7 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
         }
     }
     if constexpr (ADAM) {
-        adam_tile(smem, adam, s_step, it.dst_row, it.nrows, tab.found_inf);  // (sole owner: shared tiles have returned above)
+        adam_tile(smem, adam, s_step, it.dst_row, it.nrows, tab.found_inf, rows_state);  // (sole owner: shared tiles have returned above)
         return;
     }
     write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite, tab.found_inf);
@@ -568,9 +587,11 @@ __global__ __launch_bounds__(kSumThreads) void sum_tiles_dir_kernel(const Rec<T>
 // items q, q + 4, ... (coalesced 1 KiB reads, several in flight), LDS joins the four -- and writes the rows, rounded to fp16 once
 // (or adds them to what the caller's buffer holds).
 constexpr uint32_t kCombineRows = kWave, kCombineWaves = 4, kCombineThreads = kCombineRows * kCombineWaves;
+template <bool ADAM>
 __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const unsigned long long* __restrict__ partials, const DirTable tab, uint32_t L,
                                                                        half_t* __restrict__ grad_grid, const bool overwrite,
-                                                                       const int* __restrict__ offsets, const uint32_t first_split_tile) {
+                                                                       const int* __restrict__ offsets, const uint32_t first_split_tile,
+                                                                       const std::conditional_t<ADAM, TileAdam, NoAdam> adam) {
     __shared__ unsigned long long s_sum[kCombineWaves][kCombineRows][2];
     constexpr uint32_t kRows = rows_per_tile<half_t>(), kSegs = kRows / kCombineRows;
     const uint32_t split_tile = first_split_tile + blockIdx.x / kSegs, seg = blockIdx.x % kSegs;
@@ -607,6 +628,33 @@ __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const un
     for (uint32_t w = 1; w < kCombineWaves; w++) {
         s0 += s_sum[w][lane][0];
         s1 += s_sum[w][lane][1];
+    }
+    if constexpr (ADAM) {
+        // the shared tiles' rows get the optimizer's update here, where their gradient is final (one row = two parameters per lane): like the
+        // sole owners in sum_tiles_dir_kernel<T, true>, from the live state set into the other one, the fp16 copy in place, no gradient written
+        const half2_t g = half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+        const AdamStep as = *adam.step_consts;  // (two double pows per workgroup otherwise: the summing launch in front has left them)
+        const uint32_t from = *adam.live & 1u, to = from ^ 1u;
+        const size_t e = ((size_t)(uint32_t)tab.offsets[level] + row) * 2;
+        typedef float float2_t __attribute__((ext_vector_type(2)));
+        float2_t pp = *reinterpret_cast<const float2_t*>(adam.p[from] + e), mm = *reinterpret_cast<const float2_t*>(adam.m[from] + e);
+        float2_t vv = *reinterpret_cast<const float2_t*>(adam.v[from] + e);
+        half2_t h;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            float pj = pp[c], mj = mm[c], vj = vv[c];
+            adam_one(pj, mj, vj, (float)g[c], adam.k, as);
+            pp[c] = pj;
+            mm[c] = mj;
+            vv[c] = vj;
+            h[c] = (half_t)pj;
+        }
+        *reinterpret_cast<float2_t*>(adam.p[to] + e) = pp;
+        *reinterpret_cast<float2_t*>(adam.m[to] + e) = mm;
+        *reinterpret_cast<float2_t*>(adam.v[to] + e) = vv;
+        reinterpret_cast<half2_t*>(adam.leaf)[e / 2] = h;
+        if (tab.found_inf && half2_nonfinite(g)) *tab.found_inf = 1.0f;
+        return;
     }
     half2_t* dst = reinterpret_cast<half2_t*>(grad_grid) + (size_t)(uint32_t)tab.offsets[level];
     half2_t w = half2_t{(half_t)0.0f, (half_t)0.0f};
@@ -746,26 +794,39 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     dt.offsets[L] = off[L];
     dt.tile_base[L] = tiles;
     dt.item_base[L] = items;
+    TileAdam ad{};
     if (ta) {
-        // shared tiles must be a PREFIX of the table (they are: a level's tile count grows with the level until the hash-table cap) and the
-        // rows K4d updates four at a time must be 4-row aligned (levels are sized in multiples of 8 rows, gridencoder/grid.py:108)
-        uint32_t first = 0;
-        while (first < L && dt.slices[first] > 1) first++;
-        for (uint32_t l = first; l < L; l++)
-            if (dt.slices[l] > 1 || (off[l] & 3) || ((off[l + 1] - off[l]) & 3)) {
-                set_error("grid_encode_backward_adam: level %u (rows %d..%d, %u work items per tile) does not fit the tile-owner update: the levels "
-                          "whose tiles are shared must come first, and level sizes must be multiples of 4 rows", l, off[l], off[l + 1], dt.slices[l]);
+        // every row is updated by whoever ends up with its final gradient: the sole owner of its tile (K4d, four rows per thread: levels must be
+        // sized in multiples of 4 rows -- they are multiples of 8, gridencoder/grid.py:108) or, for tiles several work items share, the
+        // combine kernel.  No gradient row is written at all: *first_updated_row = 0.
+        for (uint32_t l = 0; l < L; l++)
+            if (dt.slices[l] == 1 && ((off[l] & 3) || ((off[l + 1] - off[l]) & 3))) {
+                set_error("grid_encode_backward_adam: level %u (rows %d..%d) is not a multiple of 4 rows", l, off[l], off[l + 1]);
                 return NERFTEX_ERR_INVALID;
             }
-        if (lc.tile_adam_first_row) *lc.tile_adam_first_row = (uint32_t)off[first];
+        if (lc.tile_adam_first_row) *lc.tile_adam_first_row = 0u;
+        for (int i = 0; i < 2; i++) {
+            ad.p[i] = ta->param[i];
+            ad.m[i] = ta->exp_avg[i];
+            ad.v[i] = ta->exp_avg_sq[i];
+        }
+        ad.leaf = static_cast<half_t*>(ta->param_half);
+        ad.live = ta->live;
+        ad.step = ta->step;
+        ad.grad_scale = ta->grad_scale;
+        ad.k = AdamConsts{ta->lr, ta->beta1, ta->beta2, ta->eps};
     }
     dt.stale_flag = stale_flag();
     dt.found_inf = sizeof(T) == 2 ? lc.found_inf : nullptr;  // (fp32 tables: the caller scans, launch_backward)
     if (!dt.stale_flag) { set_error("grid_encode_backward: no pinned memory for the deferred error word"); return NERFTEX_ERR_HIP; }
     const size_t dir_bytes = (sizeof(uint32_t) * (size_t)L * kMaxTilesPerLevel * nchunks + 255) / 256 * 256;
     const size_t part_bytes = (size_t)part_tiles * kTileBytes;  // exact integer partial sums of the tiles several work items share
-    char* dbase = static_cast<char*>(workspace(kWsGridBins, dir_bytes + part_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
-    if (!dbase) return NERFTEX_ERR_HIP;
+    constexpr size_t kConstBytes = 256;  // one AdamStep (tile-owner update), in front of everything
+    static_assert(sizeof(AdamStep) <= kConstBytes, "scratch slot of the step constants");
+    char* dbase0 = static_cast<char*>(workspace(kWsGridBins, kConstBytes + dir_bytes + part_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
+    if (!dbase0) return NERFTEX_ERR_HIP;
+    ad.step_consts = reinterpret_cast<AdamStep*>(dbase0);
+    char* dbase = dbase0 + kConstBytes;
     uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
     unsigned long long* partials = reinterpret_cast<unsigned long long*>(dbase + dir_bytes);
     Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes + part_bytes);
@@ -799,17 +860,6 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
             if (ta) {
                 auto kernel = sum_tiles_dir_kernel<T, true>;
                 NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
-                TileAdam ad{};
-                for (int i = 0; i < 2; i++) {
-                    ad.p[i] = ta->param[i];
-                    ad.m[i] = ta->exp_avg[i];
-                    ad.v[i] = ta->exp_avg_sq[i];
-                }
-                ad.leaf = static_cast<half_t*>(ta->param_half);
-                ad.live = ta->live;
-                ad.step = ta->step;
-                ad.grad_scale = ta->grad_scale;
-                ad.k = AdamConsts{ta->lr, ta->beta1, ta->beta2, ta->eps};
                 KernelTimer kt("sum_tiles_adam_kernel", st, kTimeGrid);
                 hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite,
                                    partials, offsets_dev, probe, item_lo, ad);
@@ -828,8 +878,12 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         const uint32_t split_lo = dt.split_base[lv_lo], split_hi = lv_hi < L ? dt.split_base[lv_hi] : split_tiles;
         if (split_hi > split_lo) {
             KernelTimer kt("combine_tiles_kernel", st, kTimeGrid);
-            hipLaunchKernelGGL(combine_tiles_kernel, dim3((split_hi - split_lo) * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
-                               reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev, split_lo);
+            if (ta)
+                hipLaunchKernelGGL(combine_tiles_kernel<true>, dim3((split_hi - split_lo) * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
+                                   reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev, split_lo, ad);
+            else
+                hipLaunchKernelGGL(combine_tiles_kernel<false>, dim3((split_hi - split_lo) * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
+                                   reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev, split_lo, NoAdam{});
         }
         return check_launch("grid_encode_backward(combine)");
     }

@@ -151,25 +151,33 @@ template <> struct Half16<true> {
     static __device__ __forceinline__ void narrow1(half_t* h, uint64_t i, float p) { reinterpret_cast<__bf16*>(h)[i] = (__bf16)p; }
 };
 
-// amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count
-__device__ __forceinline__ void amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
-                                           const double backoff_factor, const int growth_interval, uint32_t* live = nullptr) {
-    if (*found_inf != 0.0f) {
-        *scale = (float)((double)*scale * backoff_factor);
+// amp_update_scale_ + the optimizer's step counter: a skipped step backs the scale off and does not count.  The words' current values are passed in
+// (the Adam launch reads all of them in ONE round trip at its start -- nothing else can write them while it runs -- instead of one dependent trip
+// each in its last block: the launch that ends a step is a chain of such trips and little else)
+__device__ __forceinline__ void amp_update_loaded(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
+                                                  const double backoff_factor, const int growth_interval, uint32_t* live, const float found_v,
+                                                  const float scale_v, const int32_t tracker_v, const float step_v, const uint32_t live_v) {
+    if (found_v != 0.0f) {
+        *scale = (float)((double)scale_v * backoff_factor);
         *growth_tracker = 0;
     } else {
-        const int successful = *growth_tracker + 1;
+        const int successful = tracker_v + 1;
         if (successful == growth_interval) {
-            const float grown = (float)((double)*scale * growth_factor);
+            const float grown = (float)((double)scale_v * growth_factor);
             if (isfinite(grown)) *scale = grown;
             *growth_tracker = 0;
         } else {
             *growth_tracker = successful;
         }
-        if (step) *step += 1.0f;
-        if (live) *live ^= 1u;  // double-buffered state: the set this step wrote becomes the live one
+        if (step) *step = step_v + 1.0f;
+        if (live) *live = live_v ^ 1u;  // double-buffered state: the set this step wrote becomes the live one
     }
     *found_inf = 0.0f;
+}
+__device__ __forceinline__ void amp_update(float* scale, int32_t* growth_tracker, float* found_inf, float* step, const double growth_factor,
+                                           const double backoff_factor, const int growth_interval, uint32_t* live = nullptr) {
+    amp_update_loaded(scale, growth_tracker, found_inf, step, growth_factor, backoff_factor, growth_interval, live, *found_inf, *scale, *growth_tracker,
+                      step ? *step : 0.0f, live ? *live : 0u);
 }
 
 // optional tail of the Adam launch: the loss scaler's update, done by whichever block finishes last (ticket) -- every block has read
@@ -241,8 +249,14 @@ __device__ __forceinline__ void adam_tensor(const AdamState src, const AdamState
 __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTensors tens, const float* step, const float step_offset,
                                                                  const AdamConsts k, const float* grad_scale, const float* found_inf,
                                                                  const AmpTail tail, const AdamRepair repair) {
-    const bool skip = found_inf && *found_inf == 1.0f;  // GradScaler: skip the step, every buffer stays as it is
-    const uint32_t from = tens.live ? (*tens.live & 1u) : 0u, to = tens.live ? from ^ 1u : 0u;
+    // every device word the launch depends on, read up front in one round trip
+    const float found_v = found_inf ? *found_inf : 0.0f;
+    const uint32_t live_v = tens.live ? *tens.live : 0u;
+    const float step_v = *step;
+    const float scale_v = grad_scale ? *grad_scale : 1.0f;
+    const int32_t tracker_v = tail.scale != nullptr ? *tail.growth_tracker : 0;
+    const bool skip = found_inf && found_v == 1.0f;  // GradScaler: skip the step, every buffer stays as it is
+    const uint32_t from = tens.live ? (live_v & 1u) : 0u, to = tens.live ? from ^ 1u : 0u;
     if (!skip && tens.count > 0 && blockIdx.x < tens.block_end[tens.count - 1]) {  // (a launch with a repair may carry more blocks than the tensors need)
     int t = 0;
     while (t + 1 < tens.count && blockIdx.x >= tens.block_end[t]) t++;
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTenso
     half_t* __restrict__ param_half = tens.param_half[t];
     const uint64_t n = tens.n[t];
 
-    const AdamStep s = adam_step_consts(k, (double)(*step + step_offset), grad_scale);
+    const AdamStep s = adam_step_consts(k, (double)(step_v + step_offset), grad_scale != nullptr, scale_v);
 
     if ((tens.bf16_mask >> t) & 1u) adam_tensor<true>(src, dst, grad, param_half, n, block, nblocks, k, s);
     else adam_tensor<false>(src, dst, grad, param_half, n, block, nblocks, k, s);
@@ -273,7 +287,9 @@ __global__ __launch_bounds__(kAdamThreads) void adam_half_kernel(const AdamTenso
             // of `live`), which the ticket (a device-scope atomic, performed memory-side) says.  A device-scope release here would have every
             // one of the 2048 blocks write its XCD's L2 back: measured +125 us on a 60 us kernel
             if (atomicAdd(tail.ticket, 1u) == gridDim.x - 1) {
-                amp_update(tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor, tail.backoff_factor, tail.growth_interval, tail.live);
+                // (tail.scale / found_inf / step are the words read above: grad_scale == tail.scale, found_inf == tail.found_inf in the _amp entries)
+                amp_update_loaded(tail.scale, tail.growth_tracker, tail.found_inf, tail.step, tail.growth_factor, tail.backoff_factor, tail.growth_interval, tail.live,
+                                  found_v, scale_v, tracker_v, step_v, live_v);
                 *tail.ticket = 0u;
             }
         }
@@ -492,7 +508,9 @@ int adam_half_launch(int count, float* const* params, float* const* exp_avgs, fl
     if (second) {
         tens.live = second->live;
         repair = second->repair;
-        if (repair.n) blocks = std::max(blocks, std::min<uint32_t>(blocks_for(repair.n / 8, kAdamThreads), 1024u));  // a skipped step: every block helps
+        // (the repair of a skipped step -- one step in ~2000 -- grid-strides over whatever blocks the tensors need, at least 64: sizing the launch
+        // for it made every step pay for 1024 blocks' ticket atomics on one address, 18 us for a launch with 5 us of work)
+        if (repair.n) blocks = std::max(blocks, 64u);
     }
     if (tens.count == 0 && !repair.n) {  // nothing to update: the scaler's bookkeeping still happens
         if (tail.scale) {

@@ -29,7 +29,8 @@ def _bits(t):
 
 
 @pytest.mark.parametrize("B", [65536, 4096, 459264], ids=["two_shared_levels", "no_shared_level", "bench_size"])
-def test_backward_adam_equals_backward_then_adam(dev, oracle, B):
+def test_backward_adam_equals_backward_then_adam(dev, oracle, knobs, B):
+    knobs(grid_bwd=2)  # the two-launch side on the binned path at every size (small batches would take the fp16-atomics path: another rounding order)
     from nerftex_hip import F16, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, TableAdam, check, lib, ptr, stream
 
     off_np, rows = oracle.grid_offsets(3, 16, 1.447269, 16, 19, True)
@@ -104,14 +105,8 @@ def test_backward_adam_equals_backward_then_adam(dev, oracle, B):
         check(lib.nerftex_grid_encode_backward_adam(ptr(gx), ptr(xs), ptr(off), ptr(gt), B, 3, 2, 16, S, 16, 0, 1, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25,
                                                     ctypes.byref(ta), ctypes.byref(first), stream()))
         f = int(first.value)
-        assert f in [int(o) for o in off_np], "the first updated row is a level boundary"
-        if B == 65536:
-            assert f == int(off_np[2])
-        if B == 4096:
-            assert f == 0
-        # the coarse levels' gradient rows are the ordinary backward's, the rest of the buffer was left alone
-        assert torch.equal(_bits(gt[:f]), _bits(ref_trace[step][3][:f]))
-        assert torch.isnan(gt[f:]).all()
+        assert f == 0, "every row is updated by the owner of its final gradient (sole tile owners, or the combine kernel for shared tiles)"
+        assert torch.isnan(gt).all(), "no gradient row is written"
         n = (ctypes.c_uint64 * 2)(f * 2, n_w)
         cut = lambda t: t[:f]  # noqa: E731
         check(lib.nerftex_adam_mixed_step_amp_db(

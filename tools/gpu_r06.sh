@@ -3,6 +3,7 @@
 #   tests-new   the round-6 GPU tests + the tests of the files the round touched
 #   tests       the whole GPU suite
 #   ab          tools/table_update_ab.py
+#   ab-prof     the same under rocprofv3 --kernel-trace --stats
 #   bench       python bench.py (default run)
 mode=${1:-tests-new}
 tag=${2:-r06_$mode}
@@ -18,6 +19,12 @@ case $mode in
     tail -15 $out/pytest.log ;;
   ab)
     timeout 600 python tools/table_update_ab.py > $out/ab.json 2> $out/ab.err; tail -3 $out/ab.err; cat $out/ab.json ;;
+  ab-prof)   # per-kernel durations of both forms of the step (one rep each), replayed graphs included
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $GRAFT_REPO_ROOT/tools/table_update_ab.py --reps 1 --steps 416 > $out/ab.json 2> $out/ab.err )
+    find $out -name "*_kernel_trace.csv" -size +40M -delete; find $out -name "*_agent_info.csv" -delete
+    f=$(find $out/prof -name "*kernel_stats.csv" | head -1); head -30 $f | cut -c1-200 ;;
+  probe)    # the tile-owner Adam alone, per mode of the grid_adam_mode knob
+    timeout 600 python tools/tile_adam_probe.py > $out/probe.json 2> $out/probe.err; tail -3 $out/probe.err; cat $out/probe.json ;;
   bench)
     timeout 1200 python bench.py > $out/bench.json 2> $out/bench.err; tail -5 $out/bench.err; cat $out/bench.json | head -c 3000 ;;
 esac

@@ -26,9 +26,10 @@ def main():
     dev = torch.device("cuda:0")
     sc = scene.Scene(bound=args.bound, seed=0)
     grid, _, _ = sc.bitfield()
-    out = {"fused": [], "two_launch": []}
+    forms = [("two_launch", False), ("fused", True)]
+    out = {name: [] for name, _ in forms}
     for _ in range(a.reps):
-        for name, flag in (("two_launch", False), ("fused", True)):
+        for name, flag in forms:
             r = bench.measure_accelerated(args, "ffmlp", a.rays, a.steps, dev, grid, group=4, fused_table_update=flag)
             out[name].append({"ms_per_step": r["ms_per_step"], "value": r["value"], "spread": r["spread"], "loss": r["loss"]})
     best = {k: min(x["ms_per_step"] for x in v) for k, v in out.items()}
