@@ -99,6 +99,10 @@ def parse():
                     "and run each group's Adam on a second stream while the next group is being summed (A/B, off by default: DESIGN.md 4.5)")
     ap.add_argument("--no-fused-table-update", action="store_true", help="1 GPU, the fresh-ray headline loop (accelerate): write the whole table gradient and update "
                     "the table with the streaming Adam launch (rounds 1-5) instead of applying Adam from the summing kernel's tiles (round 6)")
+    ap.add_argument("--no-skip-dead-samples", action="store_true", help="walk every 32-sample step in the MLP / hash-grid backward instead of the steps the compositing "
+                    "backward flagged as carrying a gradient (round 6; no difference on the headline's young field, see other_config 'trained state')")
+    ap.add_argument("--trained-steps", type=int, default=1008, help="training steps against rendered targets of the analytic scene before the 'trained state' entry "
+                    "of other_config is timed (0 = skip it)")
     ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
     ap.add_argument("--allreduce-chunks", type=int, default=1, help="N > 1: exchange the table gradient as this many level-group chunks, each started as soon "
                     "as the backward has produced its rows (default 1 = one all-reduce after the backward)")
@@ -285,6 +289,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     inv_world = 1.0 / world
     # loss scaling: GradScaler's rules either way; with the fused optimizer its device side is three launches (optim.FusedAmp)
     amp = FusedAmp(opt) if fused_amp else None
+    renderer.skip_dead_samples = bool(fused_opt and getattr(field, "fused_field", False) and not args.no_skip_dead_samples)  # (round 6; as accelerate() does)
     fused_table_update = False
     if amp is not None and world == 1 and field.fused_field:
         amp.attach(field.encoder)  # the non-finite scan rides on the kernels that write the gradients (N > 1: the scan must see the cross-rank sum)
@@ -705,7 +710,8 @@ def _replay_child_cmd(args, mlp, rays, dtype, steps):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(args.warmup), "--rays", str(rays), "--mlp", mlp,
            "--dtype", dtype, "--bound", str(args.bound), "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer",
            "--no-kernel-timing", "--baked-pool", "--no-occupancy-timing"]
-    for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb", "no_fused_table_update"):
+    for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb", "no_fused_table_update",
+                 "no_skip_dead_samples"):
         if getattr(args, flag, False):
             cmd.append("--" + flag.replace("_", "-"))
     return cmd
@@ -869,7 +875,8 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     # marches may start behind the ring's read-back, as they do in the baked-pool loop)
     trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1, amp_dtype=amp_dt,
                          pipeline_adam=getattr(args, "pipeline_adam", 0),
-                         fused_table_update=False if getattr(args, "no_fused_table_update", False) else fused_table_update)
+                         fused_table_update=False if getattr(args, "no_fused_table_update", False) else fused_table_update,
+                         skip_dead_samples=False if getattr(args, "no_skip_dead_samples", False) else None)
     if group > 1:
         assert n_pool % group == 0 and steps % group == 0
         po = [torch.stack([pool[c * group + i][0] for i in range(group)]).contiguous() for c in range(n_pool // group)]
@@ -944,6 +951,101 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     spread = {"min": per_ring_ms[0], "median": per_ring_ms[len(per_ring_ms) // 2], "max": per_ring_ms[-1], "rings": len(per_ring_ms)} if len(per_ring_ms) >= 3 else None
     return {"value": samples / (t1 - t0), "ms_per_step": (t1 - t0) / steps * 1e3, "loss": float(trainer.loss), "spread": spread, "samples": samples, "steps": steps,
             "steps_per_call": per_call}
+
+
+def measure_trained_state(args, dev, sc, grid, rays=8192, train_steps=1008, timed_steps=208):
+    """the same scene TRAINED against rendered targets of the analytic scene (not noise) -- the field turns opaque, and the
+    compositing backward hands exactly zero gradients to every sample behind the point where its ray's transmittance has underflowed
+    (raymarching.cu:843-870) -- then timed with and without the dead-sample skip (accelerate(skip_dead_samples=...)): ms per step, the dead fraction,
+    and the backward kernels' device time from the library's own timers over eager steps."""
+    import nerftex_hip
+    from ngp_harness import scene
+    from ngp_harness.accelerate import accelerate
+    from ngp_harness.model import NGPField, Renderer
+
+    torch.manual_seed(0)
+    field = NGPField(bound=args.bound, mlp="ffmlp", fused_glue=True).to(dev).train()
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
+    renderer.set_occupancy(torch.from_numpy(grid).to(dev))
+    k, n_pool = 4, 8
+    pool = []
+    for j in range(n_pool):
+        o, d = scene.train_batch(rays, seed=100 + j, n_views=4)
+        ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        pool.append((ro, rd, torch.cat([scene.render_targets(sc, ro[i:i + 2048], rd[i:i + 2048]) for i in range(0, rays, 2048)])))
+    po = [torch.stack([pool[c * k + i][0] for i in range(k)]).contiguous() for c in range(n_pool // k)]
+    pd = [torch.stack([pool[c * k + i][1] for i in range(k)]).contiguous() for c in range(n_pool // k)]
+    pt = [torch.stack([pool[c * k + i][2] for i in range(k)]).contiguous() for c in range(n_pool // k)]
+    trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=k, march_across_ring_end=True)
+    n_calls = len(po)
+
+    def call(c, ahead=True):
+        trainer.step_group(po[c % n_calls], pd[c % n_calls], pt[c % n_calls], next_rays=(po[(c + 1) % n_calls], pd[(c + 1) % n_calls]) if ahead else None)
+
+    c = 0
+    loss0 = None
+    while c * k < train_steps:  # the trainer's loop: the occupancy grid follows the field every 16 steps (nerf/utils.py:1011)
+        call(c, ahead=(c * k + k) % 16 != 0)
+        c += 1
+        if loss0 is None and c * k >= 32:
+            loss0 = float(trainer.loss)
+        if (c * k) % 16 == 0:
+            with torch.autocast("cuda", dtype=torch.float16):
+                renderer.update_extra_state_device()
+
+    def timed(skip):
+        nonlocal c
+        renderer.skip_dead_samples = trainer.skip_dead_samples = skip
+        trainer._graphs, trainer._groups, trainer._warm = None, None, 0  # record the graphs again with / without the flags
+        for _ in range(8 + 16 // k * 2):
+            call(c, ahead=False)
+            c += 1
+        while renderer.local_step != 0:
+            call(c, ahead=False)
+            c += 1
+        torch.cuda.synchronize()
+        rings = []
+        t0 = time.perf_counter()
+        for i in range(timed_steps // k):
+            call(c)
+            c += 1
+            if (i + 1) * k % 16 == 0:
+                rings.append(renderer.last_ring_samples)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the backward kernels' own durations: a few eager steps under the library's timers
+        trainer_eager = trainer.use_graph
+        trainer.use_graph = False
+        nerftex_hip.lib.nerftex_profile_reset()
+        nerftex_hip.lib.nerftex_profile_enable(1)
+        for _ in range(8 // k):
+            call(c, ahead=False)
+            c += 1
+        torch.cuda.synchronize()
+        prof = nerftex_hip.kernel_profile()
+        nerftex_hip.lib.nerftex_profile_enable(0)
+        trainer.use_graph = trainer_eager
+        want = ("field_color_backward_kernel", "field_sigma_backward_kernel", "bin_fill_dir_kernel", "sum_tiles_adam_kernel", "sum_tiles_dir_kernel", "combine_tiles_kernel",
+                "composite_tail_bwd_kernel", "grid_forward_level_kernel", "field_forward_train_kernel")
+        kern = {n: round(prof[n]["avg_us"], 1) for n in want if n in prof}
+        mlp_bwd = sum(v for n, v in kern.items() if n.startswith("field_") and "backward" in n)
+        return {"ms_per_step": dt / timed_steps * 1e3, "value": sum(rings) / dt if rings else None, "samples_per_step": (sum(rings) / (len(rings) * 16)) if rings else None,
+                "mlp_backward_us_eager": round(mlp_bwd, 1), "hash_grid_backward_us_eager": round(sum(v for n, v in kern.items() if n.split("_")[0] in ("bin", "sum", "combine")), 1),
+                "kernels_avg_us_eager": kern}
+
+    with_skip = timed(True)
+    holder = getattr(renderer, "last_step_live", None) or {}
+    flags = holder.get("last")
+    dead_steps = float((flags == 0).float().mean()) if flags is not None else None
+    without = timed(False)
+    return {"workload": f"configs[2], TRAINED STATE: {c * k} steps of accelerate(steps_per_call={k}).step_group against rendered targets of the analytic scene (ngp_harness.scene."
+                        "render_targets: the blobs' density composited with a smooth colour field), the occupancy grid updated every 16 steps; then timed with the "
+                        "dead-sample skip (the compositing backward flags the 32-sample steps that carry a gradient; the MLP backward and the hash-grid record builder "
+                        "walk those only) and without it.  Same parameters either way, bit for bit (tests/test_gpu_round6.py)",
+            "rays_per_batch": rays, "dtype": "fp16", "loss_after_32_steps": loss0, "loss_now": float(trainer.loss), "dead_32_sample_steps_fraction": dead_steps,
+            "with_skip": with_skip, "without_skip": without, "value": with_skip["value"], "unit": "ray-samples/s", "ms_per_step": with_skip["ms_per_step"]}
 
 
 def measure_curved(dev, n_points=262144, reps=10):
@@ -1197,6 +1299,11 @@ def main():
                           "loss_after_run": r5["loss"]})
         except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
             print(f"[bench] randint-ray measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
+        if args.trained_steps > 0:
+            try:  # the scene trained against rendered targets, then timed with and without the dead-sample skip
+                other.append(measure_trained_state(args, dev, sc, grid, train_steps=args.trained_steps))
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
+                print(f"[bench] trained-state measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
         try:  # the headline's loop (fresh rays, 4 steps per call) with bf16 networks
             r4 = measure_accelerated(args, "ffmlp", 8192, 64, dev, grid, group=4, dtype="bf16")
             other.append({"workload": "configs[2] in bf16 through ngp_harness.accelerate(renderer, steps_per_call=4, amp_dtype=torch.bfloat16).step_group: the headline's loop "

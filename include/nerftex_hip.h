@@ -331,6 +331,19 @@ int nerftex_field_forward_bf16(const void* feats_lbc, const float* dirs, const v
 int nerftex_field_backward_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
                                 const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                                 void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream);
+/* Extension (round 6): nerftex_field_backward_amp / _bf16 over the 32-row steps the compositing backward flagged as carrying a gradient
+ * (step_live[B / 32], 0 = all 32 rows have exactly zero grad_sigma and grad_rgbs: nerftex_composite_tail_backward_live).  A dead step adds exact
+ * zeros to the weight gradients and has a zero input gradient (ffmlp/src/ffmlp.cu:410-518 computes those zeros): it issues no loads and no MFMAs,
+ * and its rows of grad_cin / grad_x are NOT WRITTEN (hand the same flags to nerftex_grid_encode_backward_opts).  The step -> wave assignment is
+ * that of the plain call, so the weight gradients are the plain call's, bit for bit.  found_inf may be NULL.                                */
+int nerftex_field_backward_live(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                void* grad_x, void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live, float* found_inf,
+                                void* stream);
+int nerftex_field_backward_live_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                     const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                     void* grad_x, void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live, float* found_inf,
+                                     void* stream);
 /* ... and the two no-grad forms of the bf16 field: the density query of the occupancy-grid update (nerftex_field_density) and the inference
  * iteration sized by a device count (nerftex_field_forward_rows, declared below), weights bf16, feats_lbc fp16, outputs fp32.  Same values as
  * nerftex_field_forward_bf16's sigma / (sigma, rgbs) on the rows they compute. */
@@ -387,6 +400,19 @@ int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, con
                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                                       int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
                                       void* stream);
+/* Extension (round 6): the table backward with every extension as an OPTION.  step_live: one word per 32 consecutive points (B / 32, rounded up),
+ * 0 = those 32 rows of `grad` carry exactly zero and are NOT READ -- the compositing backward flags them (nerftex_composite_tail_backward_live:
+ * raymarching.cu:843-870 hands exactly zero to every sample behind the point where its ray's transmittance has underflowed) and the MLP backward
+ * that skipped them never wrote them (nerftex_field_backward_live).  Binned path only (C = 2, a registered level table); NULL members = not used. */
+typedef struct nerftex_grid_backward_options {
+    float* found_inf;                /* as nerftex_grid_encode_backward_amp */
+    const nerftex_table_adam* adam;  /* as nerftex_grid_encode_backward_adam (its own found_inf is used unless the member above is set) */
+    uint32_t* first_updated_row;     /* with adam */
+    const uint32_t* step_live;       /* device */
+} nerftex_grid_backward_options;
+int nerftex_grid_encode_backward_opts(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                      int layout, float in_add, float in_mul, const nerftex_grid_backward_options* opts, void* stream);
 
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).
@@ -630,6 +656,19 @@ int nerftex_composite_tail_backward(const float* grad_loss, const float* scale, 
                                     const float* target, float bg, const float* sigmas, const float* rgbs, const float* deltas,
                                     const int32_t* rays, const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                     float* grad_sigmas, float* grad_rgbs, void* stream);
+
+/* Extension (round 6): the two launches above with the STEP FLAGS of the dead-sample skip.  nerftex_render_tail_forward_live also clears
+ * step_live[0 .. n_steps) (n_steps = ceil(M / 32) words; rides on a launch the step has anyway); nerftex_composite_tail_backward_live sets the word
+ * of every 32-sample step that holds a sample whose grad_sigma or grad_rgb is not exactly zero (ballot + one leader lane per step; nan / inf count
+ * as non-zero).  step_live NULL = the plain calls.                                                                                        */
+int nerftex_render_tail_forward_live(const float* weights_sum, const float* depth, const float* image, const float* nears, const float* fars,
+                                     const float* target, float bg, float loss_mul, uint32_t N, float* image_out, float* depth_out, float* partial,
+                                     uint32_t* ticket, float* loss, const float* scale, float* scaled_loss, uint32_t* step_live, uint32_t n_steps,
+                                     void* stream);
+int nerftex_composite_tail_backward_live(const float* grad_loss, const float* scale, float loss_mul, const float* image_out, const float* target,
+                                         float bg, const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                         const float* weights_sum, const float* image, uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs,
+                                         uint32_t* step_live, void* stream);
 
 /* One Adam step (main_nerf.py:128: betas (0.9, 0.99), eps 1e-15, no weight decay) of an fp32 master table from the
  * fp16 gradient the encoder backward produced, writing the fp16 copy the next forward reads: param, exp_avg,

@@ -68,7 +68,6 @@ enum Knob {
     kKnobFfmlpBwdSplit,  // 1: dgrad kernel + wgrad kernel through backward_buffer instead of the fused backward
     kKnobMarchLean,      // 1: the training march's count pass compiled for 64 registers (spills; slower alone, a better neighbour on a shared CU)
     kKnobFfmlpBwdTr,     // 1: fused MLP backward builds its weight-gradient operands with ds_read_b64_tr_b16 instead of selection-matrix MFMAs (slower: A/B)
-    kKnobFfmlpBwdSkipZero,  // 1: the field's fused MLP backward skips 32-row steps whose incoming gradients are all zero (a trained scene: most of them; costs 9 % when there are none)
     kKnobGridBwdStage,   // binning: LDS record slots per fill workgroup (0 = default; the rest of a workgroup's block goes straight to memory)
     kKnobCount
 };

@@ -91,6 +91,14 @@ extern "C" int nerftex_field_backward_amp(const float* grad_sigma, const float* 
     return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                            grad_sigma_weights, grad_color_weights, found_inf, stream);
 }
+// nerftex_field_backward_amp over the steps the compositing backward flagged (round 6): step_live[B / 32], one word per 32 consecutive rows, 0 = all 32
+// rows have exactly zero grad_sigma / grad_rgbs.  Dead steps issue no loads and no MFMAs; their rows of grad_cin / grad_x are NOT written.
+extern "C" int nerftex_field_backward_live(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin, const void* x_rows,
+                                           const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin, void* grad_x,
+                                           void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live, float* found_inf, void* stream) {
+    return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                           grad_sigma_weights, grad_color_weights, found_inf, stream, step_live);
+}
 extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
                                           float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {
     return ffmlp_f16::field_forward_entry(feats_lbc, dirs, sigma_weights, color_weights, B, sigma, rgbs, nullptr, nullptr, nullptr, nullptr, units_dev,

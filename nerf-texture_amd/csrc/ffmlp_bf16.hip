@@ -54,6 +54,13 @@ extern "C" int nerftex_field_backward_bf16(const float* grad_sigma, const float*
     return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                             grad_sigma_weights, grad_color_weights, found_inf, stream);
 }
+extern "C" int nerftex_field_backward_live_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                                const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                                void* grad_x, void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live,
+                                                float* found_inf, void* stream) {
+    return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                            grad_sigma_weights, grad_color_weights, found_inf, stream, step_live);
+}
 extern "C" int nerftex_field_density_bf16(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream) {
     return ffmlp_bf16::field_density_entry(feats_lbc, sigma_weights, B, sigma, stream);
 }

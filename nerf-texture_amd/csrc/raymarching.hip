@@ -873,6 +873,11 @@ constexpr uint32_t kCompBlock = 256;
 struct TailBackward {
     const float *grad_loss, *scale, *image_out, *target;
     float bg, loss_mul;
+    // optional (nerftex_composite_tail_backward_live, round 6): one word per 32 consecutive samples, ZERO on entry; the launch sets the words of
+    // the 32-sample steps that hold at least one sample with a non-zero gradient (any of grad_sigma, grad_rgb; nan counts).  In a trained
+    // scene most samples sit behind the point where their ray's transmittance has underflowed and get EXACTLY zero from the arithmetic below
+    // (raymarching.cu:843-870 computes the same zeros): the MLP backward and the hash-grid backward skip the steps whose word stays 0.
+    uint32_t* step_live;
 };
 
 __global__ __launch_bounds__(kCompBlock) void composite_train_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
@@ -992,15 +997,30 @@ __global__ __launch_bounds__(kCompBlock) void composite_train_bwd_kernel(const f
         const float g = g_c + wave_scan_add(weight * c1g);
         const float b = b_c + wave_scan_add(weight * c2b);
         const float ws = ws_c + wave_scan_add(weight);
+        bool live = false;
         if (on) {
-            grad_rgbs[3 * i] = gi0 * weight;
-            grad_rgbs[3 * i + 1] = gi1 * weight;
-            grad_rgbs[3 * i + 2] = gi2 * weight;
+            const float g0w = gi0 * weight, g1w = gi1 * weight, g2w = gi2 * weight;
+            grad_rgbs[3 * i] = g0w;
+            grad_rgbs[3 * i + 1] = g1w;
+            grad_rgbs[3 * i + 2] = g2w;
             float acc = gi0 * fmaf(T, c0r, -(r_final - r));
             acc = fmaf(gi1, fmaf(T, c1g, -(g_final - g)), acc);
             acc = fmaf(gi2, fmaf(T, c2b, -(b_final - b)), acc);
             acc = fmaf(gws, T - (ws_final - ws), acc);
-            grad_sigmas[i] = d0 * acc;
+            const float gs = d0 * acc;
+            grad_sigmas[i] = gs;
+            live = !(gs == 0.0f && g0w == 0.0f && g1w == 0.0f && g2w == 0.0f);  // (+-0 are zeros; nan / inf are not)
+        }
+        if constexpr (TAIL) {
+            if (tail.step_live != nullptr) {
+                // ballot + leader per 32-sample step: the first live lane of a step (the lanes of one step are consecutive) sets its word
+                const unsigned long long mask = __ballot(live);
+                const uint32_t s = (uint32_t)(i >> 5);
+                const int lo = (int)(s << 5) - (int)(offset + c0);  // first lane of this lane's step inside the 64-sample window (may be < 0)
+                const uint32_t first_lane = lo > 0 ? (uint32_t)lo : 0u;
+                const unsigned long long before = (mask >> first_lane) & ((1ull << (lane - first_lane)) - 1ull);
+                if (live && before == 0ull) tail.step_live[s] = 1u;
+            }
         }
         T_carry *= __shfl(incl, kWave - 1, kWave);
         r_c = __shfl(r, kWave - 1, kWave); g_c = __shfl(g, kWave - 1, kWave); b_c = __shfl(b, kWave - 1, kWave);
@@ -1372,7 +1392,19 @@ extern "C" int nerftex_composite_tail_backward(const float* grad_loss, const flo
                                                float* grad_rgbs, void* stream) {
     clear_error();
     if (N == 0) return NERFTEX_OK;
-    const TailBackward tail{grad_loss, scale, image_out, target, bg, loss_mul};
+    return nerftex_composite_tail_backward_live(grad_loss, scale, loss_mul, image_out, target, bg, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas,
+                                                grad_rgbs, nullptr, stream);
+}
+
+// nerftex_composite_tail_backward + the step flags of TailBackward::step_live (step_live[ceil(M / 32)], zero on entry -- nerftex_render_tail_forward_live
+// clears it; NULL: none).  [extension, round 6]
+extern "C" int nerftex_composite_tail_backward_live(const float* grad_loss, const float* scale, float loss_mul, const float* image_out, const float* target,
+                                                    float bg, const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                                    const float* weights_sum, const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
+                                                    float* grad_rgbs, uint32_t* step_live, void* stream) {
+    clear_error();
+    if (N == 0) return NERFTEX_OK;
+    const TailBackward tail{grad_loss, scale, image_out, target, bg, loss_mul, step_live};
     {
         KernelTimer kt("composite_tail_bwd_kernel", as_stream(stream));
         hipLaunchKernelGGL(composite_train_bwd_kernel<true>, dim3(div_up(N, kCompBlock / (uint32_t)kWave)), dim3(kCompBlock), 0, as_stream(stream), nullptr, nullptr,

@@ -42,11 +42,15 @@ __global__ __launch_bounds__(kTailThreads) void render_tail_forward_kernel(const
                                                                            float* __restrict__ image_out, float* __restrict__ depth_out,
                                                                            float* __restrict__ partial, uint32_t* __restrict__ ticket,
                                                                            float* __restrict__ loss, const float* __restrict__ scale,
-                                                                           float* __restrict__ scaled_loss) {
+                                                                           float* __restrict__ scaled_loss, uint32_t* __restrict__ step_live,
+                                                                           const uint32_t n_steps) {
 #pragma clang fp contract(off)  // the framework's blend is a multiply, then an add
     __shared__ float lds[kTailThreads / 64];
     __shared__ bool last;
     const uint32_t n = blockIdx.x * kTailThreads + threadIdx.x;
+    // optional: clear the step flags the compositing backward of this step will set (nerftex_composite_tail_backward_live) -- rides here for free
+    if (step_live != nullptr)
+        for (uint32_t i = n; i < n_steps; i += gridDim.x * kTailThreads) step_live[i] = 0u;
     float err = 0.0f;
     if (n < N) {
         const float back = (1.0f - weights_sum[n]) * bg;
@@ -342,6 +346,15 @@ extern "C" int nerftex_render_tail_forward(const float* weights_sum, const float
                                            const float* fars, const float* target, float bg, float loss_mul, uint32_t N, float* image_out,
                                            float* depth_out, float* partial, uint32_t* ticket, float* loss, const float* scale,
                                            float* scaled_loss, void* stream) {
+    return nerftex_render_tail_forward_live(weights_sum, depth, image, nears, fars, target, bg, loss_mul, N, image_out, depth_out, partial, ticket, loss, scale,
+                                            scaled_loss, nullptr, 0, stream);
+}
+
+// the same launch also clears step_live[0 .. n_steps): the flags nerftex_composite_tail_backward_live sets later in the step.  [extension, round 6]
+extern "C" int nerftex_render_tail_forward_live(const float* weights_sum, const float* depth, const float* image, const float* nears,
+                                                const float* fars, const float* target, float bg, float loss_mul, uint32_t N, float* image_out,
+                                                float* depth_out, float* partial, uint32_t* ticket, float* loss, const float* scale,
+                                                float* scaled_loss, uint32_t* step_live, uint32_t n_steps, void* stream) {
     clear_error();
     if (N == 0) {
         set_error("render_tail: empty batch");
@@ -351,7 +364,7 @@ extern "C" int nerftex_render_tail_forward(const float* weights_sum, const float
     {
         KernelTimer kt("render_tail_forward_kernel", st);
         hipLaunchKernelGGL(render_tail_forward_kernel, dim3(div_up(N, kTailThreads)), dim3(kTailThreads), 0, st, weights_sum, depth, image, nears,
-                           fars, target, bg, loss_mul, N, image_out, depth_out, partial, ticket, loss, scale, scaled_loss);
+                           fars, target, bg, loss_mul, N, image_out, depth_out, partial, ticket, loss, scale, scaled_loss, step_live, n_steps);
     }
     return check_launch("render_tail_forward");
 }

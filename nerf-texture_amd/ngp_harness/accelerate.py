@@ -41,7 +41,7 @@ RING = 16
 
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
-                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0, skip_zero_gradient_steps=None,
+                 amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0, skip_dead_samples=None,
                  fused_table_update=None):
         from .model import NGPField
 
@@ -90,15 +90,15 @@ class AcceleratedTrainer:
             self._chunks = TableGradChunks(field.encoder, self.pipeline_adam)
             self._chunks.with_amp = True
             self._adam_stream = torch.cuda.Stream(device=self.dev)
-        # skip_zero_gradient_steps (fused field; round 5): the MLP backward kernels skip the 32-row steps whose incoming gradients are all zero -- exact,
-        # and in a trained scene most steps (the samples behind the point where a ray's transmittance has underflowed get exactly zero from the
-        # compositing backward), but a 9 % tax on those kernels while the field is young and every sample carries a gradient, and a gain of only
-        # 11 % when 99 % of the steps are skipped (they have paid for their loads already): profiles/r05_ffmlp_skip_zero.json.  An A/B, not advice.  A library knob (ffmlp_bwd_skip_zero), process-wide; the kernels are chosen at launch, so it must be
-        # set BEFORE the graphs are recorded: None leaves it as it is, True / False set it here.
-        if skip_zero_gradient_steps is not None:
-            import nerftex_hip
-
-            nerftex_hip.check(nerftex_hip.lib.nerftex_tune_set(b"ffmlp_bwd_skip_zero", int(bool(skip_zero_gradient_steps))))
+        # skip_dead_samples (round 6; None = on wherever it exists -- the fused FFMLP field): the compositing backward flags the 32-sample steps that
+        # carry a gradient and both MLP backward kernels and the hash-grid backward's record builder walk the flagged steps only.  In a trained scene
+        # most samples sit behind the point where their ray's transmittance has underflowed and get EXACTLY zero gradients (raymarching.cu:843-870:
+        # 42 % of the samples after 100 steps of the bench's scene, 99.6 % after 1000): the backward then costs what the live samples cost.  Exact: the
+        # same parameters bit for bit (tests/test_gpu_round6.py); a young field, where every sample carries a gradient, pays one ballot per 64 steps.
+        can_skip = bool(self.fused and field.mlp == "ffmlp" and not self.pipeline_adam)
+        self.skip_dead_samples = can_skip if skip_dead_samples is None else bool(skip_dead_samples)
+        assert not self.skip_dead_samples or can_skip, "skip_dead_samples needs the fused FFMLP field (and no pipeline_adam)"
+        renderer.skip_dead_samples = self.skip_dead_samples
         # fused_table_update (round 6; None = on wherever it exists): the hash-grid backward's summing kernel applies Adam to the hashed levels' rows
         # from its LDS tiles -- the record walk of some workgroups beside the parameter stream of others -- instead of writing their gradient for
         # the optimizer launch to read back (optim.FusedAmp.fuse_table_update).  Same parameters bit for bit, skipped overflow steps included; the

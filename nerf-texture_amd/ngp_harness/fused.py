@@ -126,6 +126,7 @@ class _ngp_field(Function):
             ctx.amp_sink = getattr(enc, "amp_sink", None)  # optim.FusedAmp.attach: the backward's kernels raise found_inf themselves
             ctx.grad_chunker = getattr(enc, "grad_chunker", None)  # dp.TableGradChunks: the table gradient is finished level group by level group
             ctx.table_adam = getattr(enc, "table_adam", None)  # optim.FusedAmp.fuse_table_update: the summing kernel applies Adam to the tiles it owns
+            ctx.live_holder = getattr(enc, "step_live_holder", None)  # Renderer.shade_train(skip_dead_samples): where composite_tail's backward leaves its step flags
         else:
             check(field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
         ctx.set_materialize_grads(False)
@@ -147,7 +148,20 @@ class _ngp_field(Function):
         grad_x, grad_ws = torch.empty(B, 32, **half), torch.empty_like(ws_h)  # (grad_x feeds the hash-grid backward: the TABLE's type, fp16)
         sink = ctx.amp_sink if ((FIELD_BACKWARD_FUSED or bf16) and t_dtype == torch.float16 and ws_dtype == wc_dtype == mlp_dtype) else None
         found = ptr(sink.found_inf) if sink is not None else None
-        if bf16:  # one entry point, found_inf optional (no split / unfused form of the bf16 field backward exists)
+        # round 6, dead-sample skip: one word per 32 samples, 0 = the compositing backward gave all 32 exactly zero gradients (composite_tail's
+        # backward, which has run just before this one, left them in the holder).  Both MLP backward kernels and the hash-grid backward's record
+        # builder walk the live steps only: dead steps issue no loads and no MFMAs, their rows of grad_cin / grad_x are never written nor read.
+        holder = ctx.live_holder
+        flags = holder.pop("flags", None) if holder is not None else None
+        grad_chunker = ctx.grad_chunker if ((sink is None or getattr(ctx.grad_chunker, "with_amp", False)) and t_dtype == torch.float16) else None
+        if flags is not None and not (flags.numel() * 32 >= B and (FIELD_BACKWARD_FUSED or bf16) and t_dtype == torch.float16 and grad_chunker is None
+                                      and grad_sigma is not None and grad_rgbs is not None):
+            flags = None
+        if flags is not None:
+            field_backward = lib.nerftex_field_backward_live_bf16 if bf16 else lib.nerftex_field_backward_live
+            check(field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin), ptr(grad_x),
+                                 ptr(grad_ws), ptr(grad_wc), ptr(flags), found, stream()))
+        elif bf16:  # one entry point, found_inf optional (no split / unfused form of the bf16 field backward exists)
             check(lib.nerftex_field_backward_bf16(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B,
                                                   ptr(grad_cin), ptr(grad_x), ptr(grad_ws), ptr(grad_wc), found, stream()))
         elif sink is not None:  # GradScaler's non-finite scan rides on the stores of the three gradients (no amp_check launch this step)
@@ -169,7 +183,7 @@ class _ngp_field(Function):
         dummy = torch.empty(1, **half)
         # (the chunked form hands autograd a gradient that is FINISHED LATER, in place: only valid when `.grad` becomes this very tensor --
         # an fp16 leaf, so that `.to(t_dtype)` below is the identity, and no earlier `.grad` to accumulate into: TableGradChunks.begin checks)
-        chunker = ctx.grad_chunker if ((sink is None or getattr(ctx.grad_chunker, "with_amp", False)) and t_dtype == torch.float16) else None
+        chunker = grad_chunker
         if chunker is not None:
             # only BIN the contributions here; the caller sums the level groups one by one (chunker.sum_chunk) -- data parallelism: each group's
             # all-reduce starts while the next group is being summed; single GPU (round 5, with_amp): each group's Adam runs on a second stream
@@ -194,12 +208,24 @@ class _ngp_field(Function):
             # step GradScaler skips leaves no trace); grad_table receives the coarse levels' rows [0, first) only, the rest stays uninitialised
             import ctypes
 
+            from nerftex_hip import GridBackwardOptions
+
             first = ctypes.c_uint32(0)
-            check(lib.nerftex_grid_encode_backward_adam(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
-                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(fuse), ctypes.byref(first),
-                                                        stream()))
+            opts = GridBackwardOptions(found_inf=None, adam=ctypes.pointer(fuse), first_updated_row=ctypes.pointer(first), step_live=ptr(flags))
+            check(lib.nerftex_grid_encode_backward_opts(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
+                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(opts), stream()))
             sink.opt.fused_table = (sink.table_index, int(first.value))
             sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
+        elif flags is not None:
+            import ctypes
+
+            from nerftex_hip import GridBackwardOptions
+
+            opts = GridBackwardOptions(found_inf=found, adam=None, first_updated_row=None, step_live=ptr(flags))
+            check(lib.nerftex_grid_encode_backward_opts(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
+                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(opts), stream()))
+            if sink is not None:
+                sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
         elif sink is not None:
             check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H,
                                                        0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],
@@ -341,7 +367,7 @@ class _composite_tail(Function):
     -> (image_out, depth_out, loss * loss_mul, that times `scale`); backward through the last one reaches sigmas and rgbs."""
 
     @staticmethod
-    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale):
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale, live_holder=None):
         sigmas, rgbs, deltas = sigmas.contiguous().float(), rgbs.contiguous().float(), deltas.contiguous().float()
         nears, fars, target = nears.contiguous().float(), fars.contiguous().float(), target.contiguous().float()
         rays = rays.contiguous()
@@ -354,9 +380,14 @@ class _composite_tail(Function):
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         scratch = _tail_scratch(dev, (N + 255) // 256)
         check(lib.nerftex_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(weights_sum), ptr(depth), ptr(image), stream()))
-        check(lib.nerftex_render_tail_forward(ptr(weights_sum), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(target), float(bg), float(loss_mul), N,
-                                              ptr(image_out), ptr(depth_out), ptr(scratch[1]), ptr(scratch[0]), ptr(losses), ptr(scale),
-                                              losses.data_ptr() + 4, stream()))
+        # live_holder (a dict the field's backward shares: Renderer.shade_train): this node's backward leaves one flag per 32 samples in it -- 0 = all 32
+        # got exactly zero gradients -- for the MLP and hash-grid backward to skip; the flags are cleared by the render tail's launch
+        ctx.live_holder, ctx.step_live = live_holder, None
+        if live_holder is not None and M > 0:
+            ctx.step_live = torch.empty((M + 31) // 32, dtype=torch.int32, device=dev)
+        check(lib.nerftex_render_tail_forward_live(ptr(weights_sum), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(target), float(bg), float(loss_mul), N,
+                                                   ptr(image_out), ptr(depth_out), ptr(scratch[1]), ptr(scratch[0]), ptr(losses), ptr(scale),
+                                                   losses.data_ptr() + 4, ptr(ctx.step_live), 0 if ctx.step_live is None else ctx.step_live.numel(), stream()))
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, image_out, target, scale)
         ctx.consts = (float(bg), float(loss_mul))
         loss, scaled = losses[0], losses[1]
@@ -368,11 +399,11 @@ class _composite_tail(Function):
     def backward(ctx, _gi, _gd, _gl, grad_scaled):
         sigmas, rgbs, deltas, rays, weights_sum, image, image_out, target, scale = ctx.saved_tensors
         if grad_scaled is None:
-            return (None,) * 10
+            return (None,) * 11
         bg, loss_mul = ctx.consts
         M, N = sigmas.shape[0], rays.shape[0]
         if N == 0 or M == 0:
-            return torch.zeros_like(sigmas), torch.zeros_like(rgbs), None, None, None, None, None, None, None, None
+            return torch.zeros_like(sigmas), torch.zeros_like(rgbs), None, None, None, None, None, None, None, None, None
         grad_scaled = grad_scaled.contiguous().float()
         # PRECONDITION of the uninitialised gradient buffers below: `rays` are the records of THIS library's march with the counter at zero
         # on entry (march_rays_train / march_rays_train_fresh: record n = ray n, offsets an exclusive prefix sum from 0), so that the rows past
@@ -381,14 +412,17 @@ class _composite_tail(Function):
         # rows the rays do not cover (the tail of a buffer sized by the mean count) get no gradient: zeros, like the reference's buffers --
         grads = torch.empty(4 * M, dtype=torch.float32, device=sigmas.device)  # (zeroed where no ray writes by the launch itself)
         grad_sigmas, grad_rgbs = grads[:M], grads[M:].view(M, 3)
-        check(lib.nerftex_composite_tail_backward(ptr(grad_scaled), ptr(scale), loss_mul, ptr(image_out), ptr(target), bg, ptr(sigmas), ptr(rgbs), ptr(deltas),
-                                                  ptr(rays), ptr(weights_sum), ptr(image), M, N, ptr(grad_sigmas), ptr(grad_rgbs), stream()))
-        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None
+        check(lib.nerftex_composite_tail_backward_live(ptr(grad_scaled), ptr(scale), loss_mul, ptr(image_out), ptr(target), bg, ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                                       ptr(rays), ptr(weights_sum), ptr(image), M, N, ptr(grad_sigmas), ptr(grad_rgbs), ptr(ctx.step_live), stream()))
+        if ctx.step_live is not None:
+            ctx.live_holder["flags"] = ctx.live_holder["last"] = ctx.step_live  # ("last" stays for whoever wants to look: bench.py's dead-step fraction)
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None
 
 
-def composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, bg=1.0, loss_mul=1.0, scale=None):
-    """-> (image_out, depth_out, loss, scaled_loss): compositing, background blend, depth normalisation and MSE; one backward launch."""
-    return _composite_tail.apply(sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale)
+def composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, bg=1.0, loss_mul=1.0, scale=None, live_holder=None):
+    """-> (image_out, depth_out, loss, scaled_loss): compositing, background blend, depth normalisation and MSE; one backward launch.
+    live_holder: a dict shared with the fused field's backward (Renderer.shade_train, skip_dead_samples): the backward leaves its step flags there."""
+    return _composite_tail.apply(sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale, live_holder)
 
 
 _SCRATCH = {}

@@ -433,14 +433,28 @@ class Renderer(nn.Module):
         kernel (ngp_harness/fused.py render_tail); returns (image, depth, loss * loss_mul, that times the loss scaler's `scale`)
         instead of (image, depth); backward goes through the last one."""
         nears, fars, xyzs, dirs, deltas, rays = marched
-        sigmas, rgbs, _ = self.field(xyzs, dirs)
+        # skip_dead_samples (round 6; accelerate sets it): the compositing backward flags the 32-sample steps that carry a gradient -- in a trained
+        # scene most samples sit behind the point where their ray's transmittance has underflowed and get exactly zero (raymarching.cu:843-870) --
+        # and the fused field's backward (both MLPs, the hash-grid record builder) walks the flagged steps only.  The two autograd nodes share a dict.
+        holder = None
+        enc = getattr(self.field, "encoder", None)
+        if (target is not None and getattr(self, "skip_dead_samples", False) and getattr(self, "fused_composite_tail", True) and enc is not None
+                and torch.is_grad_enabled()):
+            holder = {}
+            enc.step_live_holder = holder
+            self.last_step_live = holder  # (after the backward: holder["last"] = the step's flags)
+        try:
+            sigmas, rgbs, _ = self.field(xyzs, dirs)
+        finally:
+            if holder is not None:
+                enc.step_live_holder = None
         if self.density_scale != 1:  # x * 1.0 is x: not launched
             sigmas = self.density_scale * sigmas
         if target is not None:
             from . import fused
 
             if getattr(self, "fused_composite_tail", True):  # compositing + blend + depth + MSE: one launch per direction
-                return fused.composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, float(bg_color), loss_mul, scale)
+                return fused.composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, float(bg_color), loss_mul, scale, holder)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
             return fused.render_tail(weights_sum, depth, image, nears, fars, target, float(bg_color), loss_mul, scale)
         weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)

@@ -131,3 +131,33 @@ def train_batch(n_rays, H=800, W=800, radius=2.0, seed=0, n_views=1):
         o.append(ro)
         d.append(rd)
     return np.concatenate(o), np.concatenate(d)
+
+
+def render_targets(sc, rays_o, rays_d, n_samples=384, near=0.2, far=None, bg=1.0):
+    """Target colours of rays through the ANALYTIC scene `sc` (torch, on the rays' device; bench / test preparation, never timed): the blobs' density
+    composited front to back over `n_samples` uniform samples with a smooth analytic colour field c(x) = 0.5 + 0.5 sin(4 x + phase), white
+    background.  What a trainer of this scene would be given as ground truth -- a field trained against it turns opaque where the blobs are."""
+    import torch
+
+    dev = rays_o.device
+    far = float(far if far is not None else 2.0 * sc.bound * 1.75)
+    t = torch.linspace(near, far, n_samples, device=dev)
+    dt = (far - near) / (n_samples - 1)
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * t[None, :, None]  # [N, S, 3]
+    centers = torch.from_numpy(sc.centers).to(dev)
+    radii = torch.from_numpy(sc.radii).to(dev)
+    amps = torch.from_numpy(sc.amps).to(dev)
+    sigma = torch.zeros(pts.shape[:2], device=dev)
+    for c, r, a in zip(centers, radii, amps):
+        d2 = ((pts - c) ** 2).sum(-1)
+        if sc.kind == "ball":
+            sigma += a * (d2 < r * r)
+        else:
+            sigma += a * torch.exp(-0.5 * d2 / (0.45 * r) ** 2) * (d2 < (1.6 * r) ** 2)
+    sigma = sigma * (pts.abs().amax(-1) <= sc.bound)
+    phase = torch.tensor([0.0, 2.1, 4.2], device=dev)
+    col = 0.5 + 0.5 * torch.sin(4.0 * pts + phase)
+    alpha = 1.0 - torch.exp(-sigma * dt)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha[:, :-1]], 1), 1)
+    w = alpha * T
+    return (w[..., None] * col).sum(1) + (1.0 - w.sum(1, keepdim=True)) * bg

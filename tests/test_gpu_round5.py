@@ -296,64 +296,6 @@ def test_pipelined_adam_gives_the_parameters_of_the_single_update(dev):
         assert torch.equal(p0, p4), n0
 
 
-# ------------------------------------------------------------------------------------------------- zero-gradient steps of the field backward
-def test_field_backward_skips_all_zero_steps_without_changing_anything(dev, knobs):
-    """nerftex_field_backward with the knob ffmlp_bwd_skip_zero: 32-row steps whose incoming gradients (grad_sigma, grad_rgbs) are all zero are skipped by both MLP backward kernels.
-    Per row the result must be what it is without the skip: rows with a gradient bit-identical to a run in which every row has one, rows
-    without exactly zero in grad_x, and the weight gradients those of the rows that have a gradient (the zero rows add nothing)."""
-    from nerftex_hip import check, lib, ptr, stream
-
-    torch.manual_seed(0)
-    from ngp_harness.model import NGPField
-
-    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
-    torch.manual_seed(1)
-    field.encoder.embeddings.data.uniform_(-1, 1)
-    B = 128 * 160  # (>= 16384: the hash-grid backward's deterministic large-batch path; smaller batches use fp16 atomics, whose order is not fixed)
-    g = torch.Generator(device=dev).manual_seed(2)
-    x = (torch.rand(B, 3, device=dev, generator=g) * 2 - 1) * 1.9
-    d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g), dim=-1)
-    gs_full = torch.randn(B, device=dev, generator=g) * 1e-2
-    gc_full = torch.randn(B, 3, device=dev, generator=g) * 1e-2
-    # gradient only on rows [0, 1000) and [12000, 12100): whole 32-row steps (and whole 128-row workgroup steps) in between carry none
-    keep = torch.zeros(B, dtype=torch.bool, device=dev)
-    keep[:1000] = True
-    keep[12000:12100] = True
-
-    def run(gs, gc):
-        for p in field.parameters():
-            p.grad = None
-        xx = x.clone().requires_grad_(False)
-        with torch.autocast("cuda", dtype=torch.float16):
-            sigma, rgbs, _ = field(xx, d)
-            torch.autograd.backward([sigma, rgbs], [gs, gc])
-        return field.encoder.embeddings.grad.clone(), field.sigma_net.weights.grad.clone(), field.color_net.weights.grad.clone()
-
-    knobs(ffmlp_bwd_skip_zero=1)
-    gt_full, gws_full, gwc_full = run(gs_full, gc_full)
-    gs, gc = gs_full * keep, gc_full * keep.unsqueeze(-1)
-    gt, gws, gwc = run(gs, gc)
-    knobs(ffmlp_bwd_skip_zero=0)
-    gt_full0, gws_full0, gwc_full0 = run(gs_full, gc_full)  # nothing to skip: the two kernel forms agree bit for bit
-    assert torch.equal(gt_full, gt_full0) and torch.equal(gws_full, gws_full0) and torch.equal(gwc_full, gwc_full0)
-    gt0, gws0, gwc0 = run(gs, gc)  # ... and on the masked gradients
-    assert torch.equal(gt, gt0) and torch.equal(gws, gws0) and torch.equal(gwc, gwc0)
-    # reference for the masked gradients: the six-launch form of the same backward (glue kernels + the generic MLP backward kernels, which have no
-    # skip; ngp_harness/fused.py FIELD_BACKWARD_FUSED = False -- bit-identical to the fused form by construction, tests/test_gpu_field_glue.py)
-    from ngp_harness import fused
-
-    sink, field.encoder.amp_sink = getattr(field.encoder, "amp_sink", None), None
-    fused.FIELD_BACKWARD_FUSED = False
-    try:
-        gt_ref, gws_ref, gwc_ref = run(gs, gc)
-    finally:
-        fused.FIELD_BACKWARD_FUSED = True
-        field.encoder.amp_sink = sink
-    assert torch.equal(gws, gws_ref) and torch.equal(gwc, gwc_ref), "weight gradients: the skipped steps added exactly nothing"
-    assert torch.equal(gt, gt_ref), "table gradient: the skipped rows' dL/dfeatures are exactly zero"
-    assert float(gt.abs().sum()) > 0 and not torch.equal(gt, gt_full)
-
-
 # ------------------------------------------------------------------------------------------------- graph-replayed inference
 def test_graphed_inference_gives_the_image_of_the_reference_loop(dev):
     """Renderer.render_infer_graphed (per ray range: one graph that resets it, one that runs a block of iterations; n_step derived on the device)

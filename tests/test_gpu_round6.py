@@ -252,3 +252,152 @@ def test_fused_table_update_checkpoint_round_trip(dev, tmp_path):
         t.sync()
     for (n1, p1), (_, p2), (_, p3) in zip(f1.named_parameters(), f2.named_parameters(), f3.named_parameters()):
         assert torch.equal(p1, p2) and torch.equal(p1, p3), n1
+
+
+# ------------------------------------------------------------------------------------------------- dead-sample skip (step flags)
+def _opaque_case(dev, n_rays=2048, density_scale=400.0):
+    """A renderer whose field is dense enough that most samples sit behind the point where their ray's transmittance has underflowed."""
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev).train()
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-1e-2, 1e-2)
+    r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+    r.set_occupancy(torch.from_numpy(grid).to(dev))
+    r.density_scale = density_scale
+    o, d = scene.train_batch(n_rays, seed=31, n_views=2)
+    return field, r, torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+
+
+def test_compositing_backward_flags_exactly_the_steps_that_carry_a_gradient(dev):
+    """nerftex_render_tail_forward_live clears, nerftex_composite_tail_backward_live sets: word s != 0 <=> some sample of rows [32 s, 32 s + 32) has a
+    non-zero grad_sigma or grad_rgb.  The gradients themselves are the plain launch's (the reference's arithmetic, raymarching.cu:843-870)."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    field, r, ro, rd = _opaque_case(dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        marched, _ = r.march_train(ro, rd, dt_gamma=1 / 128, perturb=True, mean_count=300000)
+        nears, fars, xyzs, dirs, deltas, rays = marched
+        sigmas, rgbs, _ = field(xyzs, dirs)
+    sigmas = (sigmas.float() * r.density_scale).contiguous()
+    rgbs = rgbs.float().contiguous()
+    M, N = sigmas.shape[0], rays.shape[0]
+    tgt = torch.rand(N, 3, device=dev)
+    per_ray = torch.empty(9, N, device=dev)
+    ws, depth, depth_out, image, image_out = per_ray[0], per_ray[1], per_ray[2], per_ray[3:6].view(N, 3), per_ray[6:9].view(N, 3)
+    losses = torch.empty(2, device=dev)
+    ticket, partial = torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1024, device=dev)
+    one = torch.ones((), device=dev)
+    flags = torch.full(((M + 31) // 32,), 7, dtype=torch.int32, device=dev)
+    check(lib.nerftex_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(ws), ptr(depth), ptr(image), stream()))
+    check(lib.nerftex_render_tail_forward_live(ptr(ws), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(tgt), 1.0, 1.0, N, ptr(image_out), ptr(depth_out), ptr(partial),
+                                               ptr(ticket), ptr(losses), None, losses.data_ptr() + 4, ptr(flags), flags.numel(), stream()))
+    assert int(flags.abs().sum()) == 0, "cleared by the render tail"
+    g = torch.full((4 * M,), float("nan"), device=dev)
+    g_plain = torch.full((4 * M,), float("nan"), device=dev)
+    args = (ptr(one), None, 1.0, ptr(image_out), ptr(tgt), 1.0, ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(ws), ptr(image), M, N)
+    check(lib.nerftex_composite_tail_backward_live(*args, ptr(g[:M]), ptr(g[M:]), ptr(flags), stream()))
+    check(lib.nerftex_composite_tail_backward(*args, ptr(g_plain[:M]), ptr(g_plain[M:]), stream()))
+    assert torch.equal(g.view(torch.int32), g_plain.view(torch.int32))
+    live = (g[:M] != 0) | (g[M:].view(M, 3) != 0).any(-1)
+    pad = (-M) % 32
+    want = torch.nn.functional.pad(live, (0, pad)).view(-1, 32).any(-1)
+    assert torch.equal(flags != 0, want)
+    frac_dead = 1.0 - float(want.float().mean())
+    assert 0.3 < frac_dead < 0.999, f"the case must have dead and live steps ({frac_dead:.3f} dead)"
+
+
+@pytest.mark.parametrize("mlp_dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_field_backward_over_the_live_steps_equals_the_plain_backward(dev, oracle, mlp_dtype):
+    """nerftex_field_backward_live + nerftex_grid_encode_backward_opts(step_live) against nerftex_field_backward_amp / _bf16 + nerftex_grid_encode_backward_amp on
+    gradients that are exactly zero on the dead steps: weight gradients and table gradient bit-identical, grad_cin / grad_x identical on the live
+    steps and UNTOUCHED on the dead ones."""
+    from nerftex_hip import F16, LAYOUT_BLC, LAYOUT_GRAD_OVERWRITE, LAYOUT_LBC, GridBackwardOptions, check, lib, ptr, stream
+
+    bf16 = mlp_dtype == torch.bfloat16
+    B = 128 * 300
+    off_np, rows = oracle.grid_offsets(3, 16, 1.447269, 16, 19, True)
+    off = torch.from_numpy(off_np).to(dev)
+    check(lib.nerftex_grid_register_offsets(ptr(off), 16, off_np.ctypes.data))
+    S = float(np.log2(1.447269))
+    g = torch.Generator(device=dev).manual_seed(9)
+    table = ((torch.rand(rows, 2, device=dev, generator=g) - 0.5) * 2).half()
+    x = torch.rand(B, 3, device=dev, generator=g) * 3.8 - 1.9
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g), dim=-1)
+    ws = ((torch.rand(64 * (32 + 64 + 16), device=dev, generator=g) - 0.5) * 0.3).to(mlp_dtype)
+    wc = ((torch.rand(64 * (32 + 128 + 16), device=dev, generator=g) - 0.5) * 0.3).to(mlp_dtype)
+    feats = torch.empty(16, B, 2, dtype=torch.float16, device=dev)
+    dummy = torch.empty(1, dtype=torch.float16, device=dev)
+    check(lib.nerftex_grid_encode_forward_affine(ptr(x), ptr(table), ptr(off), ptr(feats), B, 3, 2, 16, S, 16, 0, ptr(dummy), 0, 1, F16, LAYOUT_LBC, 2.0, 0.25, stream()))
+    sigma, rgbs = torch.empty(B, device=dev), torch.empty(B, 3, device=dev)
+    x_rows, h, cin = torch.empty(B, 32, dtype=mlp_dtype, device=dev), torch.empty(B, 16, dtype=mlp_dtype, device=dev), torch.empty(B, 32, dtype=mlp_dtype, device=dev)
+    fwd = lib.nerftex_field_forward_bf16 if bf16 else lib.nerftex_field_forward
+    check(fwd(ptr(feats), ptr(dirs), ptr(ws), ptr(wc), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), None, stream()))
+    # live steps: a random third of the 32-row steps, plus whole stretches of dead ones (a wave's 64-step ballot comes back empty somewhere)
+    n_steps = B // 32
+    live = torch.rand(n_steps, device=dev, generator=g) < 0.33
+    live[200:500] = False
+    live[0] = True
+    live[-1] = True
+    rows_live = live.repeat_interleave(32)
+    gs = torch.randn(B, device=dev, generator=g) * 1e-2 * rows_live
+    gc = torch.randn(B, 3, device=dev, generator=g) * 1e-2 * rows_live.unsqueeze(-1)
+    gs[64] = 0.0  # (a dead SAMPLE inside a live step is just a zero row)
+    flags = live.to(torch.int32)
+
+    def run(use_flags):
+        grad_cin = torch.full((B, 32), float("nan"), dtype=mlp_dtype, device=dev)
+        grad_x = torch.full((B, 32), float("nan"), dtype=torch.float16, device=dev)
+        gws, gwc = torch.empty_like(ws), torch.empty_like(wc)
+        found = torch.zeros((), device=dev)
+        common = (ptr(gs), ptr(gc), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws), ptr(wc), B, ptr(grad_cin), ptr(grad_x), ptr(gws), ptr(gwc))
+        gt = torch.full((rows, 2), float("nan"), dtype=torch.float16, device=dev)
+        if use_flags:
+            check((lib.nerftex_field_backward_live_bf16 if bf16 else lib.nerftex_field_backward_live)(*common, ptr(flags), ptr(found), stream()))
+            opts = GridBackwardOptions(found_inf=ptr(found), adam=None, first_updated_row=None, step_live=ptr(flags))
+            check(lib.nerftex_grid_encode_backward_opts(ptr(grad_x), ptr(x), ptr(off), ptr(gt), B, 3, 2, 16, S, 16, 0, 1, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25,
+                                                        ctypes.byref(opts), stream()))
+        else:
+            check((lib.nerftex_field_backward_bf16 if bf16 else lib.nerftex_field_backward_amp)(*common, ptr(found), stream()))
+            check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), None, ptr(off), ptr(gt), B, 3, 2, 16, S, 16, 0, None, None, 0, 1, F16,
+                                                       LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, 2.0, 0.25, ptr(found), stream()))
+        return grad_cin, grad_x, gws, gwc, gt, float(found)
+
+    a, b = run(False), run(True)
+    assert a[5] == b[5] == 0.0
+    for i, name in ((2, "sigma weight gradient"), (3, "colour weight gradient"), (4, "table gradient")):
+        assert torch.equal(_bits(a[i]), _bits(b[i])), name
+    for i, name in ((0, "grad_cin"), (1, "grad_x")):
+        assert torch.equal(_bits(a[i][rows_live]), _bits(b[i][rows_live])), name
+        assert torch.isnan(b[i][~rows_live].float()).all(), name + ": the dead steps' rows are not written"
+        assert float(a[i][~rows_live].float().abs().max()) == 0.0, name + ": ... and are exactly zero in the plain call"
+    assert float(a[4].float().abs().sum()) > 0
+
+
+def test_skip_dead_samples_trains_like_the_full_backward(dev):
+    """accelerate(skip_dead_samples=True) against skip_dead_samples=False on a dense field (most samples dead), replayed graphs included: the same
+    losses and parameters bit for bit; and the flags really are mostly zero there."""
+    from ngp_harness.accelerate import accelerate
+
+    out = {}
+    for skip in (False, True):
+        field, r, ro, rd = _opaque_case(dev, n_rays=4096, density_scale=300.0)
+        tgt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+        tr = accelerate(r, dt_gamma=1 / 128, skip_dead_samples=skip)
+        assert r.skip_dead_samples == skip
+        losses = []
+        for _ in range(16 + 2 + 14):
+            tr.step(ro, rd, tgt)
+            losses.append(tr.loss.clone())
+        torch.cuda.synchronize()
+        assert tr._graphs is not None
+        tr.sync()
+        out[skip] = (losses, {n_: p.detach().clone() for n_, p in field.named_parameters()})
+    for i, (la, lb) in enumerate(zip(out[False][0], out[True][0])):
+        assert torch.equal(la, lb), f"loss of step {i}"
+    for name in out[False][1]:
+        assert torch.equal(out[False][1][name], out[True][1][name]), name

@@ -4,6 +4,7 @@
 #   tests       the whole GPU suite
 #   ab          tools/table_update_ab.py
 #   ab-prof     the same under rocprofv3 --kernel-trace --stats
+#   trained     bench.py's 'trained state' entry alone
 #   bench       python bench.py (default run)
 mode=${1:-tests-new}
 tag=${2:-r06_$mode}
@@ -25,6 +26,18 @@ case $mode in
     f=$(find $out/prof -name "*kernel_stats.csv" | head -1); head -30 $f | cut -c1-200 ;;
   probe)    # the tile-owner Adam alone, per mode of the grid_adam_mode knob
     timeout 600 python tools/tile_adam_probe.py > $out/probe.json 2> $out/probe.err; tail -3 $out/probe.err; cat $out/probe.json ;;
+  trained)  # only the 'trained state' entry of the bench (train against rendered targets, then time with / without the dead-sample skip)
+    timeout 900 python - > $out/trained.json 2> $out/trained.err <<'PY'
+import json, sys, torch
+sys.argv = [sys.argv[0]]
+import bench
+from ngp_harness import scene
+args = bench.parse()
+sc = scene.Scene(bound=args.bound, seed=0)
+grid, _, _ = sc.bitfield()
+print(json.dumps(bench.measure_trained_state(args, torch.device("cuda:0"), sc, grid), indent=1))
+PY
+    tail -5 $out/trained.err; cat $out/trained.json ;;
   bench)
     timeout 1200 python bench.py > $out/bench.json 2> $out/bench.err; tail -5 $out/bench.err; cat $out/bench.json | head -c 3000 ;;
 esac
