@@ -997,6 +997,9 @@ def measure_trained_state(args, dev, sc, grid, rays=8192, train_steps=1008, time
 
     def timed(skip):
         nonlocal c
+        if trainer._ahead is not None:  # a march started for the next call: that call, without another one behind it
+            call(c, ahead=False)
+            c += 1
         renderer.skip_dead_samples = trainer.skip_dead_samples = skip
         trainer._graphs, trainer._groups, trainer._warm = None, None, 0  # record the graphs again with / without the flags
         for _ in range(8 + 16 // k * 2):
@@ -1016,6 +1019,9 @@ def measure_trained_state(args, dev, sc, grid, rays=8192, train_steps=1008, time
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         # the backward kernels' own durations: a few eager steps under the library's timers
+        if trainer._ahead is not None:
+            call(c, ahead=False)
+            c += 1
         trainer_eager = trainer.use_graph
         trainer.use_graph = False
         nerftex_hip.lib.nerftex_profile_reset()

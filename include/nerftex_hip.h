@@ -333,9 +333,10 @@ int nerftex_field_backward_bf16(const float* grad_sigma, const float* grad_rgbs,
                                 void* grad_x, void* grad_sigma_weights, void* grad_color_weights, float* found_inf, void* stream);
 /* Extension (round 6): nerftex_field_backward_amp / _bf16 over the 32-row steps the compositing backward flagged as carrying a gradient
  * (step_live[B / 32], 0 = all 32 rows have exactly zero grad_sigma and grad_rgbs: nerftex_composite_tail_backward_live).  A dead step adds exact
- * zeros to the weight gradients and has a zero input gradient (ffmlp/src/ffmlp.cu:410-518 computes those zeros): it issues no loads and no MFMAs,
- * and its rows of grad_cin / grad_x are NOT WRITTEN (hand the same flags to nerftex_grid_encode_backward_opts).  The step -> wave assignment is
- * that of the plain call, so the weight gradients are the plain call's, bit for bit.  found_inf may be NULL.                                */
+ * zeros to the weight gradients and has a zero input gradient (ffmlp/src/ffmlp.cu:410-518 computes those zeros): it issues no loads and no MFMAs;
+ * its rows of grad_x are written as zeros (two stores per lane: the hash-grid backward reads every row), its rows of grad_cin -- which only the
+ * second kernel of this call reads, on live steps -- are NOT WRITTEN.  The step -> wave assignment is that of the plain call, so every gradient
+ * is the plain call's, bit for bit.  found_inf may be NULL.                                                                               */
 int nerftex_field_backward_live(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
                                 const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                                 void* grad_x, void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live, float* found_inf,
@@ -400,19 +401,6 @@ int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, con
                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                                       int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
                                       void* stream);
-/* Extension (round 6): the table backward with every extension as an OPTION.  step_live: one word per 32 consecutive points (B / 32, rounded up),
- * 0 = those 32 rows of `grad` carry exactly zero and are NOT READ -- the compositing backward flags them (nerftex_composite_tail_backward_live:
- * raymarching.cu:843-870 hands exactly zero to every sample behind the point where its ray's transmittance has underflowed) and the MLP backward
- * that skipped them never wrote them (nerftex_field_backward_live).  Binned path only (C = 2, a registered level table); NULL members = not used. */
-typedef struct nerftex_grid_backward_options {
-    float* found_inf;                /* as nerftex_grid_encode_backward_amp */
-    const nerftex_table_adam* adam;  /* as nerftex_grid_encode_backward_adam (its own found_inf is used unless the member above is set) */
-    uint32_t* first_updated_row;     /* with adam */
-    const uint32_t* step_live;       /* device */
-} nerftex_grid_backward_options;
-int nerftex_grid_encode_backward_opts(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
-                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
-                                      int layout, float in_add, float in_mul, const nerftex_grid_backward_options* opts, void* stream);
 
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).

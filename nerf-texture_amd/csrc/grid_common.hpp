@@ -36,9 +36,6 @@ struct LevelConsts {
     // owners themselves (nerftex_grid_encode_backward_adam, gridencoder_binned.hip TileAdam)
     const struct TableAdamArgs* tile_adam;
     uint32_t* tile_adam_first_row;
-    // optional (backward, binned path; device pointer): one word per 32 consecutive points, 0 = the 32 gradient rows are all zero and are NOT read
-    // (the MLP backward that skipped those steps never wrote them: nerftex_field_backward_live)
-    const uint32_t* step_live;
 };
 
 // nerftex_table_adam of include/nerftex_hip.h (the header is C and knows no namespaces) without found_inf, which travels as LevelConsts::found_inf

@@ -839,17 +839,6 @@ int launch_backward(const T* grad, const float* inputs, const int* offsets, T* g
     const long force = knob(kKnobGridBwd);  // 1 atomic | 2 owner: A/B switch for profiling
     bool owner = C == 2 && (force ? force == 2 : (B >= kOwnerMinBatch));
     int rc = NERFTEX_OK;
-    if (lc.step_live != nullptr && lc.tile_adam == nullptr) {  // step flags (nerftex_grid_encode_backward_opts): only the binned path reads them
-        if constexpr (C == 2) {
-            if (!calc_grad && lc.bwd_phase == 0) {
-                rc = grid_backward_binned<T, D>(grad, blc, inputs, offsets, grad_emb, B, L, lc, gridtype, align, overwrite, st);
-                if (rc >= 0) return rc;
-            }
-        }
-        set_error("grid_encode_backward_opts: step flags exist on the binned table-gradient path only (C = 2, no input gradient, at most %u rows per "
-                  "level, a level table the library knows: nerftex_grid_register_offsets)", 128u * 4096u);
-        return NERFTEX_ERR_INVALID;
-    }
     if (lc.tile_adam != nullptr) {  // the optimizer's update applied by the tile owners (nerftex_grid_encode_backward_adam): the binned path or nothing
         if constexpr (C == 2) {
             if (!calc_grad) {
@@ -1014,7 +1003,7 @@ int grid_backward_entry(const void* grad, const float* inputs, const int32_t* of
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                         int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf = nullptr,
                         uint32_t phase = 0, uint32_t level_lo = 0, uint32_t level_hi = 0, const gridenc::TableAdamArgs* tile_adam = nullptr,
-                        uint32_t* tile_adam_first_row = nullptr, const uint32_t* step_live = nullptr);
+                        uint32_t* tile_adam_first_row = nullptr);
 }  // namespace
 
 extern "C" int nerftex_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
@@ -1103,38 +1092,10 @@ extern "C" int nerftex_grid_encode_backward_phase_amp(const void* grad, const fl
 // main_nerf.py:128).  The tiles of the hashed levels -- one owner each -- never leave LDS as a gradient: their owner rounds the row sums to fp16 and
 // runs Adam on the rows (gridencoder_binned.hip TileAdam).  grad_embeddings receives ONLY rows [0, *first_updated_row) -- the coarse levels whose
 // tiles several work items share -- and the caller finishes the step with nerftex_adam_mixed_step_amp_db over those rows and its other tensors.
-static int grid_backward_adam_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
-                                   uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul,
-                                   const nerftex_table_adam* adam, uint32_t* first_updated_row, const uint32_t* step_live, void* stream);
 extern "C" int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
                                                  uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                                                  int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
                                                  void* stream) {
-    return grid_backward_adam_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners, dtype, layout, in_add, in_mul, adam,
-                                    first_updated_row, nullptr, stream);
-}
-
-// The table backward with every extension as an option (round 6): found_inf (nerftex_grid_encode_backward_amp), adam + first_updated_row
-// (nerftex_grid_encode_backward_adam), step_live -- one word per 32 consecutive points, 0 = those 32 rows of `grad` are all zero and are not read
-// (nerftex_field_backward_live left them unwritten).  NULL members = not used; opts == NULL = nerftex_grid_encode_backward_affine.
-extern "C" int nerftex_grid_encode_backward_opts(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
-                                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
-                                                 int layout, float in_add, float in_mul, const nerftex_grid_backward_options* opts, void* stream) {
-    if (opts && opts->adam) {
-        nerftex_table_adam a = *opts->adam;
-        if (opts->found_inf) a.found_inf = opts->found_inf;
-        return grid_backward_adam_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners, dtype, layout, in_add, in_mul, &a,
-                                        opts->first_updated_row, opts->step_live, stream);
-    }
-    clear_error();
-    if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
-    return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype, align_corners, dtype, layout, true, in_add,
-                               in_mul, stream, opts ? opts->found_inf : nullptr, 0, 0, 0, nullptr, nullptr, opts ? opts->step_live : nullptr);
-}
-
-static int grid_backward_adam_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
-                                   uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul,
-                                   const nerftex_table_adam* adam, uint32_t* first_updated_row, const uint32_t* step_live, void* stream) {
     clear_error();
     if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
     if (!adam || !first_updated_row || !adam->param[0] || !adam->param[1] || !adam->exp_avg[0] || !adam->exp_avg[1] || !adam->exp_avg_sq[0] ||
@@ -1167,7 +1128,7 @@ static int grid_backward_adam_entry(const void* grad, const float* inputs, const
     ta.beta2 = adam->beta2;
     ta.eps = adam->eps;
     return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype, align_corners, dtype, layout, true,
-                               in_add, in_mul, stream, adam->found_inf, 0, 0, 0, &ta, first_updated_row, step_live);
+                               in_add, in_mul, stream, adam->found_inf, 0, 0, 0, &ta, first_updated_row);
 }
 
 namespace {
@@ -1190,8 +1151,7 @@ int grid_forward_entry(const float* inputs, const void* embeddings, const int32_
 int grid_backward_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                         int align_corners, int dtype, int layout, bool affine, float in_add, float in_mul, void* stream, float* found_inf, uint32_t phase,
-                        uint32_t level_lo, uint32_t level_hi, const gridenc::TableAdamArgs* tile_adam, uint32_t* tile_adam_first_row,
-                        const uint32_t* step_live) {
+                        uint32_t level_lo, uint32_t level_hi, const gridenc::TableAdamArgs* tile_adam, uint32_t* tile_adam_first_row) {
     if (!affine) clear_error();
     const bool overwrite = (layout & NERFTEX_LAYOUT_GRAD_OVERWRITE) != 0;
     layout &= ~NERFTEX_LAYOUT_GRAD_OVERWRITE;
@@ -1204,7 +1164,6 @@ int grid_backward_entry(const void* grad, const float* inputs, const int32_t* of
     lc.level_hi = level_hi;
     lc.tile_adam = tile_adam;
     lc.tile_adam_first_row = tile_adam_first_row;
-    lc.step_live = step_live;
     if (dtype == NERFTEX_F32)
         return dispatch_backward<float>(grad, inputs, offsets, grad_embeddings, B, D, C, L, lc, calc_grad_inputs != 0, dy_dx,
                                         grad_inputs, gridtype, align_corners != 0, layout, overwrite, as_stream(stream));

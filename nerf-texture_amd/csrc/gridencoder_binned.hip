@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
 
     if (threadIdx.x < kMaxTilesPerLevel) hist[threadIdx.x] = 0;
     const uint32_t b = chunk * kBinSamples + threadIdx.x;
-    const bool in_batch = b < B && (lc.step_live == nullptr || lc.step_live[b >> 5] != 0u);  // (a dead step's gradient rows were never written)
+    const bool in_batch = b < B;
     float xs[D], g[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int d = 0; d < D; d++) xs[d] = 0.0f;

@@ -58,7 +58,6 @@ _SIGNATURES = {
     "nerftex_amp_check_mixed": [_i, _vp, _vp, _u32, _vp, _vp],
     "nerftex_adam_mixed_step_amp_db": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, _i,
                                        _vp, _vp, _vp, _vp, _u64, _vp],
-    "nerftex_grid_encode_backward_opts": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _vp],
     "nerftex_field_backward_live": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_field_backward_live_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_render_tail_forward_live": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
@@ -122,11 +121,6 @@ class TableAdam(C.Structure):
     """nerftex_table_adam of include/nerftex_hip.h, field for field."""
     _fields_ = [("param", _vp * 2), ("exp_avg", _vp * 2), ("exp_avg_sq", _vp * 2), ("param_half", _vp), ("live", _vp), ("step", _vp),
                 ("grad_scale", _vp), ("found_inf", _vp), ("lr", _f64), ("beta1", _f64), ("beta2", _f64), ("eps", _f64)]
-
-
-class GridBackwardOptions(C.Structure):
-    """nerftex_grid_backward_options of include/nerftex_hip.h."""
-    _fields_ = [("found_inf", _vp), ("adam", C.POINTER(TableAdam)), ("first_updated_row", C.POINTER(_u32)), ("step_live", _vp)]
 
 
 EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get", "nerftex_workspace_slots_touched"] + list(_SIGNATURES)

@@ -149,13 +149,11 @@ class _ngp_field(Function):
         sink = ctx.amp_sink if ((FIELD_BACKWARD_FUSED or bf16) and t_dtype == torch.float16 and ws_dtype == wc_dtype == mlp_dtype) else None
         found = ptr(sink.found_inf) if sink is not None else None
         # round 6, dead-sample skip: one word per 32 samples, 0 = the compositing backward gave all 32 exactly zero gradients (composite_tail's
-        # backward, which has run just before this one, left them in the holder).  Both MLP backward kernels and the hash-grid backward's record
-        # builder walk the live steps only: dead steps issue no loads and no MFMAs, their rows of grad_cin / grad_x are never written nor read.
+        # backward, which has run just before this one, left them in the holder).  Both MLP backward kernels walk the live steps only: dead steps
+        # issue no loads and no MFMAs; their rows of grad_x are written as zeros (what the plain kernels compute: the hash-grid backward drops them).
         holder = ctx.live_holder
         flags = holder.pop("flags", None) if holder is not None else None
-        grad_chunker = ctx.grad_chunker if ((sink is None or getattr(ctx.grad_chunker, "with_amp", False)) and t_dtype == torch.float16) else None
-        if flags is not None and not (flags.numel() * 32 >= B and (FIELD_BACKWARD_FUSED or bf16) and t_dtype == torch.float16 and grad_chunker is None
-                                      and grad_sigma is not None and grad_rgbs is not None):
+        if flags is not None and not (flags.numel() * 32 >= B and (FIELD_BACKWARD_FUSED or bf16) and ws_dtype == wc_dtype == mlp_dtype):
             flags = None
         if flags is not None:
             field_backward = lib.nerftex_field_backward_live_bf16 if bf16 else lib.nerftex_field_backward_live
@@ -183,7 +181,7 @@ class _ngp_field(Function):
         dummy = torch.empty(1, **half)
         # (the chunked form hands autograd a gradient that is FINISHED LATER, in place: only valid when `.grad` becomes this very tensor --
         # an fp16 leaf, so that `.to(t_dtype)` below is the identity, and no earlier `.grad` to accumulate into: TableGradChunks.begin checks)
-        chunker = grad_chunker
+        chunker = ctx.grad_chunker if ((sink is None or getattr(ctx.grad_chunker, "with_amp", False)) and t_dtype == torch.float16) else None
         if chunker is not None:
             # only BIN the contributions here; the caller sums the level groups one by one (chunker.sum_chunk) -- data parallelism: each group's
             # all-reduce starts while the next group is being summed; single GPU (round 5, with_amp): each group's Adam runs on a second stream
@@ -208,24 +206,12 @@ class _ngp_field(Function):
             # step GradScaler skips leaves no trace); grad_table receives the coarse levels' rows [0, first) only, the rest stays uninitialised
             import ctypes
 
-            from nerftex_hip import GridBackwardOptions
-
             first = ctypes.c_uint32(0)
-            opts = GridBackwardOptions(found_inf=None, adam=ctypes.pointer(fuse), first_updated_row=ctypes.pointer(first), step_live=ptr(flags))
-            check(lib.nerftex_grid_encode_backward_opts(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
-                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(opts), stream()))
+            check(lib.nerftex_grid_encode_backward_adam(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
+                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(fuse), ctypes.byref(first),
+                                                        stream()))
             sink.opt.fused_table = (sink.table_index, int(first.value))
             sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
-        elif flags is not None:
-            import ctypes
-
-            from nerftex_hip import GridBackwardOptions
-
-            opts = GridBackwardOptions(found_inf=found, adam=None, first_updated_row=None, step_live=ptr(flags))
-            check(lib.nerftex_grid_encode_backward_opts(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
-                                                        F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(opts), stream()))
-            if sink is not None:
-                sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
         elif sink is not None:
             check(lib.nerftex_grid_encode_backward_amp(ptr(grad_x), ptr(x), ptr(table_h), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H,
                                                        0, ptr(dummy), ptr(dummy), gridtype, align, F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0],

@@ -38,6 +38,14 @@ grid, _, _ = sc.bitfield()
 print(json.dumps(bench.measure_trained_state(args, torch.device("cuda:0"), sc, grid), indent=1))
 PY
     tail -5 $out/trained.err; cat $out/trained.json ;;
+  dead)     # the dead-sample skip against the dead fraction
+    timeout 600 python tools/dead_skip_probe.py > $out/dead.json 2> $out/dead.err; tail -3 $out/dead.err; python - <<PY
+import json
+d = json.load(open("$out/dead.json"))
+for r in d["rows"]:
+    print(r["density_scale"], r.get("dead_step_fraction"), "mlp", r["plain"]["mlp_backward_us"], "->", r["skip"]["mlp_backward_us"], " bin_fill", r["plain"]["record_builder_us"], "->", r["skip"]["record_builder_us"], r["skip"]["kernels_avg_us"].get("composite_tail_bwd_kernel"), r["plain"]["kernels_avg_us"].get("composite_tail_bwd_kernel"))
+PY
+    ;;
   bench)
     timeout 1200 python bench.py > $out/bench.json 2> $out/bench.err; tail -5 $out/bench.err; cat $out/bench.json | head -c 3000 ;;
 esac
