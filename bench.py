@@ -238,6 +238,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
         if dist.get_backend() != "nccl":  # gloo moves device tensors through the host with stream synchronisations (and aborts the process in a capture)
             print(f"[bench] --graph-allreduce needs the nccl (RCCL) backend, not {dist.get_backend()}: using the split structure", file=sys.stderr)
             ar_state["in_graph"] = False
+            ar_state["fallback"] = f"--graph-allreduce needs the nccl (RCCL) backend, this group is {dist.get_backend()}: eager exchange between two graphs"
     # 1 GPU: the march of step k+1 needs nothing from step k (rays and the occupancy grid, not the weights): it is its own graph, replayed
     # on a second stream while step k shades, goes backward and updates -- latency-bound work on otherwise idle issue slots
     march_ahead = use_graph and not split_graph and not args.no_march_ahead
@@ -272,6 +273,9 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     chunker = None
     if world > 1 and args.allreduce_chunks > 1 and fused_opt and field.fused_field:
         chunker = dp.TableGradChunks(field.encoder, args.allreduce_chunks)
+    elif world > 1 and args.allreduce_chunks > 1:  # (said in the JSON line, not only here: config.collective.fallbacks)
+        ar_state["chunk_fallback"] = ("--allreduce-chunks needs the fused optimizer path and the fused fp16 field (FFMLP, --dtype fp16 or bf16, no --no-fused-opt): "
+                                      "one exchange of the whole table gradient per step")
 
     def exchange(grads=None, state=None):
         """One step's gradient exchange, start to finish (grads / state: the tensors and the per-group work of a captured backward)."""
@@ -436,6 +440,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                 except Exception as e:  # noqa: BLE001 -- this backend's collectives cannot be captured: the default structure
                     print(f"[bench] all-reduce inside the graph failed ({type(e).__name__}: {e}); using the split structure", file=sys.stderr)
                     ar_state["in_graph"] = False
+                    ar_state["fallback"] = f"--graph-allreduce: the collective could not be captured ({type(e).__name__}: {str(e)[:200]}): eager exchange between two graphs"
                     ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=mem, capture_error_mode="thread_local"):
                 body_fb(g, marches[g][1] if (split_graph or march_ahead) else None)
@@ -655,7 +660,7 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
                       "wire_dtype": str(wire_dtype).replace("torch.", "") if wire_dtype is not None else "the gradient's dtype",
                       "bytes_per_step": int(sum(g.numel() * (torch.finfo(wire_dtype).bits // 8 if wire_dtype else g.element_size()) for g in grads if g is not None)),
                       "allreduce_us_per_step": ev0.elapsed_time(ev1) * 100.0,
-                      "allreduce_in_graph": bool(use_graph and ar_state["in_graph"]),
+                      "allreduce_in_graph": bool(use_graph and ar_state["in_graph"]), "fallbacks": [v for v in (ar_state.get("fallback"), ar_state.get("chunk_fallback")) if v],
                       "table_gradient_chunks": len(chunker) if chunker is not None else 1, "per_chunk": chunk_us}
     if fused_opt:
         opt.sync()  # (double-buffered optimizer state: point the fp32 module parameters at the live set)
@@ -1180,6 +1185,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # N > 1: nothing is timed before the group has proven itself (world size, one all-reduce per wire type, barrier): dp.preflight raises with
+    # the rank and the failing check; its report goes into config.collective
+    pre = dp.preflight(world, dev) if world > 1 else None
 
     sc = scene.Scene(bound=args.bound, seed=0)
     grid, thresh, bits = sc.bitfield()
@@ -1469,7 +1477,7 @@ def main():
                 "samples_per_step_per_gpu": res["samples_per_step_per_gpu"], "mean_count": res["mean_count"], "parallelism": f"dp{world}",
                 "optimizer": ("Adam(eps=1e-15) + GradScaler rules, as HIP kernels on the fp16 gradients (fp32 masters + fp16 copies; bit-identical to torch fused Adam)"
                               if res.get("fused_opt") else "fused Adam(eps=1e-15)+GradScaler" if use_amp else "fused Adam(eps=1e-15)"),
-                "replicas_identical_after_run": res.get("replicas_identical"), "collective": res.get("collective"), "param_l1_after_run": res.get("param_l1"),
+                "replicas_identical_after_run": res.get("replicas_identical"), "collective": (dict(res["collective"], **pre) if (res.get("collective") and pre) else res.get("collective")), "param_l1_after_run": res.get("param_l1"),
                 "launch": (f"ngp_harness.accelerate(renderer, steps_per_call={args.steps_per_graph}).step_group: FRESH rays every call ([{args.steps_per_graph}, N, 3] tensors "
                            f"copied into the graphs' static buffers), one replayed HIP graph per {args.steps_per_graph} steps (shade + backward + optimizer), the marches of "
                            f"the next {args.steps_per_graph} batches (handed over one call early) as graphs of their own on a second stream.  The calls cycle 8 PRE-BUILT "
@@ -1485,6 +1493,8 @@ def main():
             "other_config": other,
         }
         print(json.dumps(out))
+    if res.get("replicas_identical") is False:  # (the line above says so too: config.replicas_identical_after_run) -- a multi-GPU number over diverged replicas is not a result
+        sys.exit(3)
 
 
 if __name__ == "__main__":

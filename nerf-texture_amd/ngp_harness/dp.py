@@ -63,6 +63,48 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def preflight(expected_world, dev=None):
+    """What a multi-GPU run checks BEFORE anything is timed (the first time an 8-GPU node appears the run must either measure or
+    say exactly why not): the process group has `expected_world` ranks, one small all-reduce per wire type returns the known sum on every rank
+    (fp16 and fp32 SUM -- the gradient exchange -- and an int32 MAX -- the mean_count agreement), a barrier completes.  Returns a dict for the
+    bench line's `config.collective` (backend, world size, the collective library's version, device names); raises RuntimeError with the rank and
+    the failing check otherwise.  Runs on gloo / CPU tensors as well (tests/test_dp_gloo.py at world 8).  The reference's only precedent for any of
+    this is its dormant DistributedDataParallel wrap, nerf/utils.py:439-441."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if expected_world != 1:
+            raise RuntimeError(f"preflight: no process group, but {expected_world} ranks were asked for")
+        return {"world_size": 1, "backend": None}
+    world, rank, backend = dist.get_world_size(), dist.get_rank(), dist.get_backend()
+    if world != expected_world:
+        raise RuntimeError(f"preflight: the process group has {world} ranks, {expected_world} were asked for (rank {rank})")
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    want_sum = world * (world + 1) // 2
+    for dt in (torch.float16, torch.float32):
+        if backend == "gloo" and dt == torch.float16 and dev.type == "cpu":
+            t = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)  # (gloo has no fp16 sum on CPU tensors)
+        else:
+            t = torch.full((1024,), float(rank + 1), dtype=dt, device=dev)
+        dist.all_reduce(t)
+        if not bool((t == want_sum).all()):
+            raise RuntimeError(f"preflight: {dt} all-reduce returned {float(t[0])} on rank {rank}, expected {want_sum}")
+    m = torch.tensor([rank + 7], dtype=torch.int32, device=dev)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    if int(m.item()) != world + 6:
+        raise RuntimeError(f"preflight: int32 MAX all-reduce returned {int(m.item())} on rank {rank}, expected {world + 6}")
+    dist.barrier()
+    info = {"world_size": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "preflight": "world size, fp16 / fp32 SUM and int32 MAX all-reduce, barrier: ok"}
+    if backend == "nccl":
+        try:
+            info["collective_library_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            info["collective_library_version"] = f"unknown ({type(e).__name__})"
+        names = [None] * world
+        dist.all_gather_object(names, torch.cuda.get_device_name(dev))
+        info["devices"] = names
+    return info
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

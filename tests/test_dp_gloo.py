@@ -238,3 +238,49 @@ def test_shard_covers_batch():
         spans = [dp.shard(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+
+
+# ------------------------------------------------------------------------------------------------- the multi-GPU pre-flight (round 6)
+def _preflight_worker(rank, world, port, q, expected):
+    import os
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ngp_harness import dp
+
+    dp.init_from_env(backend="gloo")
+    try:
+        q.put((rank, "ok", dp.preflight(expected, torch.device("cpu"))))
+    except RuntimeError as e:
+        q.put((rank, "error", str(e)))
+
+
+@pytest.mark.parametrize("world, expected", [(8, 8), (2, 4)], ids=["world8_ok", "wrong_world_size_is_refused"])
+def test_preflight_checks_the_group_before_anything_is_timed(world, expected):
+    """dp.preflight -- what `bench.py --gpus N` runs before its first timed step: the group has N ranks, one all-reduce per wire type returns the
+    known sum on every rank, a barrier completes; its report goes into the bench line (config.collective).  At world 8, configs[4]'s rank
+    count, on gloo; and a group of the wrong size is refused on every rank with a message that names both sizes."""
+    import multiprocessing as mp
+
+    port = 29350 + os.getpid() % 200 + 7 * world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, q, expected)) for r in range(world)]
+    [p.start() for p in procs]
+    results = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    [p.join(30) for p in procs]
+    if world == expected:
+        assert all(r[1] == "ok" for r in results), results
+        info = results[0][2]
+        assert info["world_size"] == 8 and info["backend"] == "gloo" and "ok" in info["preflight"]
+    else:
+        assert all(r[1] == "error" and "has 2 ranks, 4 were asked for" in r[2] for r in results), results
+
+
+def test_bench_reports_why_it_fell_back():
+    """The two opt-in exchange structures never fail the run: a backend that cannot capture the collective, or a configuration without the fused
+    optimizer path, falls back to the eager exchange and the REASON travels in the JSON line (config.collective.fallbacks).  Checked on the source:
+    every assignment of a fallback is next to the stderr message it mirrors, and the line carries the list."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert src.count('ar_state["fallback"] = ') == 2 and src.count('ar_state["chunk_fallback"] = ') == 1
+    assert '"fallbacks": [v for v in (ar_state.get("fallback"), ar_state.get("chunk_fallback")) if v]' in src
+    assert "pre = dp.preflight(world, dev) if world > 1 else None" in src and 'sys.exit(3)' in src

@@ -105,6 +105,18 @@ def test_every_stage_of_the_step_is_bit_reproducible_beside_another_process():
     assert rc == 0 and not any(res["iterations_differing_by_stage"].values()), res
 
 
+def test_framework_kernels_around_the_library_are_bit_reproducible_beside_another_process():
+    """Round 6: the fault of DESIGN 7.1 needs packed-fp32 chains beside fp16 MFMAs, and this library can only keep ITS OWN code
+    free of them.  BASELINE configs[1]'s step -- rocBLAS / hipBLASLt GEMMs for the nn.Linear MLPs and the framework's elementwise kernels between this
+    library's kernels -- torch's fused Adam on the step's gradients, and bench.py's on-device ray generation (randint, einsum, norms), 150 times beside
+    a process that trains with MFMA kernels on the same GPU: exact checksums of every stage against the quiet-GPU iteration."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    rc, res = _probe("step_concurrency_probe.py", ["--neighbour", "process", "--iters", "150", "--mlp", "torch", "--stages", "train,adam,draw"])
+    assert res["beside_the_neighbour"] >= 100, res
+    assert rc == 0 and not any(res["iterations_differing_by_stage"].values()), res
+
+
 @pytest.mark.parametrize("neighbour", ["stream", "process"])
 def test_table_gradient_is_bit_reproducible_beside_other_work(neighbour):
     """The same fixed hash-grid backward, 1000 launches, while an MLP runs on a second stream of the process / while another process trains:
