@@ -487,6 +487,14 @@ int nerftex_composite_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_de
 /* n_alive_dev[0]: alive entries of the old arrays; alive_counter[0] is overwritten with the number of survivors (a different word). */
 int nerftex_compact_rays_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old,
                              float* rays_t, const float* rays_t_old, int32_t* alive_counter, void* stream);
+/* Extension (round 6): nerftex_compact_rays_dev + the loop condition of nerf/renderer.py:459-483 (`while step < max_steps: ... step += n_step`) kept
+ * ON THE DEVICE, for a loop whose iterations are recorded HIP graphs: steps_done[0] (zero when the frame starts) is the sum of the n_step of the
+ * iterations so far; an iteration that finds it >= max_steps reports 0 survivors -- every later kernel of the recorded iterations then does
+ * nothing -- otherwise it adds this iteration's n_step (a plain number, or NERFTEX_ROWS_AUTO(N, F): derived from the survivors, as the
+ * iteration's other kernels derive it).                                                                                              */
+int nerftex_compact_rays_budget_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old,
+                                    float* rays_t, const float* rays_t_old, int32_t* alive_counter, uint32_t* steps_done, uint32_t max_steps,
+                                    uint32_t n_step, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Extension: occupancy-grid maintenance on the device --

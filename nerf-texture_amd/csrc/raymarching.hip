@@ -1140,7 +1140,8 @@ __global__ __launch_bounds__(kBlock) void compact_count_kernel(uint32_t n_alive,
 __global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive, int* __restrict__ rays_alive,
                                                                const int* __restrict__ rays_alive_old, float* __restrict__ rays_t,
                                                                const float* __restrict__ rays_t_old, int* __restrict__ alive_counter,
-                                                               const uint32_t* __restrict__ ws, const int* __restrict__ n_alive_dev) {
+                                                               const uint32_t* __restrict__ ws, const int* __restrict__ n_alive_dev,
+                                                               uint32_t* __restrict__ steps_done, const uint32_t max_steps, const uint32_t n_step_code) {
     __shared__ uint32_t red[kBlock / kWave];
     __shared__ uint32_t wave_tot[kBlock / kWave];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1174,7 +1175,15 @@ __global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive,
         uint32_t prior = ws[0];
 #pragma unroll
         for (uint32_t i = 0; i < kBlock / kWave; i++) prior += red[i];
-        alive_counter[0] = (int)(prior + block_total);
+        uint32_t survivors = prior + block_total;
+        if (steps_done != nullptr) {
+            // the loop's step budget kept on the device (nerf/renderer.py:459-483: `while step < max_steps: ... step += n_step`): an iteration whose
+            // predecessors have used the budget up finds no ray alive, whatever survived; otherwise it books the n_step its kernels will derive
+            const uint32_t done = steps_done[0];
+            if (done >= max_steps) survivors = 0u;
+            else steps_done[0] = done + unit_rows(n_step_code, survivors);
+        }
+        alive_counter[0] = (int)survivors;
     }
 }
 
@@ -1471,7 +1480,8 @@ extern "C" int nerftex_composite_rays_dev(uint32_t n_alive_bound, const int32_t*
 }
 
 static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
-                             const float* rays_t_old, int32_t* alive_counter, void* stream);
+                             const float* rays_t_old, int32_t* alive_counter, void* stream, uint32_t* steps_done = nullptr, uint32_t max_steps = 0,
+                             uint32_t n_step_code = 0);
 
 extern "C" int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
                                     const float* rays_t_old, int32_t* alive_counter, void* stream) {
@@ -1485,8 +1495,23 @@ extern "C" int nerftex_compact_rays_dev(uint32_t n_alive_bound, const int32_t* n
     return compact_rays_impl(n_alive_bound, n_alive_dev, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter, stream);
 }
 
+// nerftex_compact_rays_dev for a loop whose iterations are recorded (HIP graphs) and whose n_step the kernels derive from the alive count
+// (n_step = NERFTEX_ROWS_AUTO code, or a plain number): the loop condition of nerf/renderer.py:459 -- `while step < max_steps` with `step += n_step`
+// per iteration -- is kept in the device word steps_done[0] (zero it when the frame starts): once it has reached max_steps the compaction reports 0
+// survivors and every later kernel of the recorded iterations does nothing.  [extension, round 6]
+extern "C" int nerftex_compact_rays_budget_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old,
+                                               float* rays_t, const float* rays_t_old, int32_t* alive_counter, uint32_t* steps_done, uint32_t max_steps,
+                                               uint32_t n_step, void* stream) {
+    if (!steps_done || !n_alive_dev) {
+        clear_error();
+        set_error("compact_rays_budget_dev: steps_done and n_alive_dev must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    return compact_rays_impl(n_alive_bound, n_alive_dev, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter, stream, steps_done, max_steps, n_step);
+}
+
 static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
-                             const float* rays_t_old, int32_t* alive_counter, void* stream) {
+                             const float* rays_t_old, int32_t* alive_counter, void* stream, uint32_t* steps_done, uint32_t max_steps, uint32_t n_step_code) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
     const uint32_t nblocks = div_up(n_alive, kBlock);
@@ -1502,7 +1527,7 @@ static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32
     {
         KernelTimer kt("compact_write_kernel", st);
         hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_alive, rays_alive_old, rays_t,
-                           rays_t_old, alive_counter, ws, n_alive_dev);
+                           rays_t_old, alive_counter, ws, n_alive_dev, steps_done, max_steps, n_step_code);
     }
     return check_launch("compact_rays(write)");
 }

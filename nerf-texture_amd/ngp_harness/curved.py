@@ -258,6 +258,9 @@ class LipMLP(torch.nn.Module):
         super().__init__()
         dims = [in_dim] + [n_neurons] * num_layers
         self.layers = torch.nn.ModuleList([LipLayer(a, b) for a, b in zip(dims[:-1], dims[1:])] + [LipLayer(dims[-1], out_dim, act=False)])
+        # the reference registers its layers twice (tools/map.py:190-199: `self.layers` and `self.layers_seq = nn.Sequential(*layers)`): its checkpoints
+        # carry both `layers.N.*` and `layers_seq.N.*` keys for the same tensors.  The same modules under the second name: a strict load succeeds
+        self.layers_seq = torch.nn.Sequential(*self.layers)
 
     def forward(self, x):
         for layer in self.layers:

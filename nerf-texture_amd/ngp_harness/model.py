@@ -579,8 +579,14 @@ class Renderer(nn.Module):
         parts = max(1, min(int(parts), N))
         field = self.field
         leaves = [getattr(m, "half_leaf", None) for m in (getattr(field, "encoder", None), getattr(field, "sigma_net", None), getattr(field, "color_net", None))]
-        stamp = (N, parts, int(slots_per_ray), int(block), float(dt_gamma), int(max_steps), self.density_bitfield.data_ptr(), torch.get_autocast_dtype("cuda"),
-                 torch.is_autocast_enabled(), tuple((p.data_ptr(), p._version) for p in field.parameters()), tuple((t.data_ptr(), t._version) for t in leaves if t is not None))
+        # what the recorded graphs bake in: shapes and loop constants, the bitfield's and the aabb's storage, the scene scalars, and the tensors the
+        # field's kernels read -- the 16-bit leaves when an optimizer keeps them (their ADDRESSES: HalfLeafAdam updates them in place, the graphs stay
+        # valid across training steps), else the fp32 parameters with their versions (a changed parameter means a new cached 16-bit copy)
+        have_leaves = all(t is not None for t in leaves) and len(leaves) > 0
+        stamp = (N, parts, int(slots_per_ray), int(block), float(dt_gamma), int(max_steps), self.density_bitfield.data_ptr(), self.aabb_infer.data_ptr(),
+                 float(self.density_scale), float(self.bound), int(self.cascade), int(self.grid_size), float(self.min_near), torch.get_autocast_dtype("cuda"),
+                 torch.is_autocast_enabled(),
+                 tuple(t.data_ptr() for t in leaves) if have_leaves else tuple((p.data_ptr(), p._version) for p in field.parameters()))
         st = getattr(self, "_infer_graphs", None)
         main = torch.cuda.current_stream()
         if st is None or st["stamp"] != stamp:
@@ -653,6 +659,7 @@ class _InferGraphPart:
         self.rays_alive = torch.zeros(2, N, dtype=torch.int32, device=dev)
         self.rays_t = torch.zeros(2, N, dtype=torch.float32, device=dev)
         self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.steps_done = torch.zeros(1, dtype=torch.int32, device=dev)  # the loop's `step` (renderer.py:459-483), kept on the device: ADVICE r5
         self.all_rays = torch.arange(N, dtype=torch.int32, device=dev)
         self.start_counts = torch.tensor([0, N], dtype=torch.int32, device=dev)
         self.M = (N * F + 127) // 128 * 128
@@ -679,6 +686,7 @@ class _InferGraphPart:
         self.rays_alive[1].copy_(self.all_rays)
         self.rays_t[1].copy_(self.nears)
         self.counters.copy_(self.start_counts)
+        self.steps_done.zero_()
 
     def _iteration(self, j, bound):
         """One iteration recorded for at most `bound` alive rays (the launches' size; the kernels read the true count and derive n_step from it)."""
@@ -688,7 +696,10 @@ class _InferGraphPart:
         M = (min(self.N * self.F, bound * 8 * self.F) + 127) // 128 * 128  # count * n_step <= min(F N, count * 8 F)
         cur, old = j % 2, (j + 1) % 2
         c, ra, rt = self.counters, self.rays_alive, self.rays_t
-        check(lib.nerftex_compact_rays_dev(N, ptr(c[old:]), ptr(ra[cur]), ptr(ra[old]), ptr(rt[cur]), ptr(rt[old]), ptr(c[cur:]), stream()))
+        # (the compaction also keeps the reference loop's condition `step < max_steps`, step += n_step: a ray still alive when the budget is used
+        # up is not marched any further -- the kernels derive n_step >= F, up to 8 F, so counting F per iteration on the host would overshoot)
+        check(lib.nerftex_compact_rays_budget_dev(N, ptr(c[old:]), ptr(ra[cur]), ptr(ra[old]), ptr(rt[cur]), ptr(rt[old]), ptr(c[cur:]), ptr(self.steps_done),
+                                                  self.max_steps, self.auto, stream()))
         buf = self.buf
         xyzs, dirs, deltas = buf[:3 * M].view(M, 3), buf[3 * M:6 * M].view(M, 3), buf[6 * M:8 * M].view(M, 2)
         check(lib.nerftex_march_rays_dev(N, ptr(c[cur:]), self.auto, ptr(ra[cur]), ptr(rt[cur]), ptr(self.rays_o), ptr(self.rays_d), float(r.bound), self.dt_gamma,

@@ -40,7 +40,9 @@ def test_the_makefile_covers_every_source():
 
 def _compile_line(source):
     dry = subprocess.run(["make", "-C", CSRC, "-n", "-W", f"{source}.hip", f"../lib/obj/{source}.o"], capture_output=True, text=True, check=True).stdout
-    return [ln for ln in dry.splitlines() if f" {source}.hip" in ln and " -c " in ln][-1].split(" 2>")[0].split()
+    # (the rule echoes the command, then runs it inside a stderr filter: take the echoed one, without its quotes)
+    ln = [ln for ln in dry.splitlines() if f" {source}.hip" in ln and " -c " in ln][0]
+    return re.split(r'"| 2>|;', ln[ln.index("hipcc"):])[0].split()
 
 
 @pytest.mark.parametrize("source", SOURCES)
@@ -51,6 +53,14 @@ def test_every_translation_unit_is_compiled_with_the_packed_fp32_feature_off(sou
     assert "-target-feature -Xclang -packed-fp32-ops" in " ".join(cmd), cmd
     assert ("-fno-slp-vectorize" in cmd and "-disable-vector-combine" in cmd) == (source not in MFMA_SOURCES), cmd
     assert ("-amdgpu-mfma-vgpr-form" in cmd) == (source in MFMA_SOURCES), cmd
+
+
+def test_safety_flags_survive_a_command_line_cxxflags():
+    """`make CXXFLAGS=...` overrides every plain `CXXFLAGS +=` in the Makefile -- the packed-fp32 ban must not be droppable that way."""
+    dry = subprocess.run(["make", "-C", CSRC, "-n", "-W", "knn.hip", "../lib/obj/knn.o", "CXXFLAGS=-O2 --offload-arch=gfx950"], capture_output=True, text=True,
+                         check=True).stdout
+    lines = [ln for ln in dry.splitlines() if " knn.hip" in ln and " -c " in ln]
+    assert lines and all("-target-feature -Xclang -packed-fp32-ops" in ln and "-fno-slp-vectorize" in ln for ln in lines), dry
 
 
 def test_the_built_library_contains_no_packed_fp32_instruction():

@@ -398,3 +398,36 @@ def test_skip_dead_samples_trains_like_the_full_backward(dev):
         assert torch.equal(la, lb), f"loss of step {i}"
     for name in out[False][1]:
         assert torch.equal(out[False][1][name], out[True][1][name]), name
+
+
+# ------------------------------------------------------------------------------------------------- graphed inference: the loop's step budget
+def test_graphed_inference_stops_at_the_step_budget_like_the_reference_loop(dev):
+    """nerf/renderer.py:459-483 runs `while step < max_steps: ... step += n_step`.  The graphed loop's kernels derive n_step (F .. 8 F) on the device, so
+    the budget has to be kept there too (nerftex_compact_rays_budget_dev): an all-occupied grid and a thin medium -- no ray ever saturates, every ray
+    outlives a small max_steps -- must give the image and depth of the reference loop and of the host-launched loop, bit for bit, and the
+    device-side step word must end at the same count the host loop's `step` reaches."""
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer
+
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev)
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    field.eval()
+    r = Renderer(field, bound=2.0, min_near=0.2).to(dev)
+    r.set_occupancy(torch.full((r.cascade, 128 ** 3), 100.0, device=dev))  # every cell occupied
+    r.density_scale = 1e-2  # thin: transmittance stays far above the 1e-4 cut
+    pose = scene.rand_poses(1, 2.0, np.random.default_rng(5))[0]
+    o, d = scene.get_rays(pose, scene.intrinsics(96, 80), 96, 80)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    for max_steps in (24, 40):
+        with torch.autocast("cuda", dtype=torch.float16):
+            img_ref, dep_ref, n_ref = r.render_infer(ro, rd, dt_gamma=0.0, max_steps=max_steps, slots_per_ray=4)
+            img_p, dep_p, _ = r.render_infer_pipelined(ro, rd, dt_gamma=0.0, max_steps=max_steps, slots_per_ray=4, parts=2)
+            img_g, dep_g, _ = r.render_infer_graphed(ro, rd, dt_gamma=0.0, max_steps=max_steps, slots_per_ray=4, parts=2, block=2)
+        assert float(img_ref.std()) > 1e-4 and float(dep_ref.max()) > 0
+        assert torch.equal(img_p, img_ref) and torch.equal(dep_p, dep_ref), f"host-launched loop, max_steps {max_steps}"
+        assert torch.equal(img_g, img_ref) and torch.equal(dep_g, dep_ref), f"graphed loop, max_steps {max_steps}"
+        for job in r._infer_graphs["jobs"]:
+            done = int(job.steps_done.item())
+            assert max_steps <= done < max_steps + 8 * 4, (done, max_steps)  # the loop ran until the budget was used up, and not past it
