@@ -1259,10 +1259,25 @@ def main():
                                    f"derived by the kernels from the alive count on the device (NERFTEX_ROWS_AUTO); {P} ranges side by side; same image bit for bit"}
             except Exception as e:  # noqa: BLE001 -- a side measurement
                 print(f"[bench] graphed inference failed ({type(e).__name__}: {e})", file=sys.stderr)
+        # how many of the sample SLOTS a frame shades hold a sample at all (delta > 0: march_rays pads a ray's row of n_step slots with zeros once it
+        # has left the volume): counted in the reference-shaped loop with the reference's schedule (1 slot-unit per ray) and with the fast loops'
+        # (F units: the same n_step rule, so the same slots as the graphed / host-launched loops) -- outside every timed frame
+        real = {}
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16 if res["dtype"] == "bf16" else torch.float16, enabled=use_amp):
+                for name, f_ in (("reference_schedule", 1), ("fast_loops_schedule", F)):
+                    renderer.count_real_samples, renderer.real_samples = True, 0
+                    _, _, slots = renderer.render_infer(ro, rd, dt_gamma=dt_gamma, slots_per_ray=f_)
+                    real[name] = {"sample_slots": int(slots), "real_samples": int(renderer.real_samples), "slots_per_ray_unit": f_}
+        except Exception as e:  # noqa: BLE001 -- a side measurement
+            print(f"[bench] real-sample count failed ({type(e).__name__}: {e})", file=sys.stderr)
+        finally:
+            renderer.count_real_samples = False
         host_form = {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3}
         use_graphed = graphed is not None and graphed["mpix_per_s"] >= host_form["mpix_per_s"]
         head_inf = graphed if use_graphed else host_form  # (the faster of the two forms of the same loop in THIS run; both are reported)
         mpix = {"mpix_per_s": head_inf["mpix_per_s"], "ms_per_frame": head_inf["ms_per_frame"], "mpix_per_s_is": "graphed" if use_graphed else "host_launched", "graphed": graphed,
+                "real_samples_per_frame": real,
                 "host_launched": {"mpix_per_s": 0.64 / t_big, "ms_per_frame": t_big * 1e3, "samples_per_frame": n_big, "iterations": it_big},
                 "samples_per_frame": n_big, "iterations": it_big,
                 "loop": f"run_cuda's inference loop, no per-iteration host stall (launches sized by an earlier alive count, the true count read on the "

@@ -498,6 +498,8 @@ class Renderer(nn.Module):
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
             raymarching.composite_rays(n_alive, n_step, rays_alive[i % 2], rays_t[i % 2], sigmas, rgbs, deltas, weights_sum, depth, image)
+            if getattr(self, "count_real_samples", False):  # (bench.py: how many of the slots an iteration shades hold a sample -- delta > 0 -- at all)
+                self.real_samples = getattr(self, "real_samples", 0) + (deltas[:n_alive * n_step, 0] > 0).sum()
             n_samples += xyzs.shape[0]
             step += n_step
             i += 1
