@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
 TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 85.3e6, "grid_encode_backward": 496.3e6}  # (the FALLBACK only: the run measures them itself, rocprof_traffic)
 TRAFFIC_PROFILE = "profiles/r05_pmc_grid.txt"
-COMMITTED_STATS = "profiles/r05_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
+COMMITTED_STATS = "profiles/r06_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
     "grid_encode_forward": ("grid_forward_level_kernel", "level_major_to_rows_kernel", "grid_forward_kernel"),
@@ -1113,6 +1113,14 @@ def measure_curved(dev, n_points=262144, reps=10):
             field.encoder(p_sur, bound=1.0).backward(go)
         t_fb, _ = timed(fb)
         t_field_fwd, (sigma, color, _) = timed(lambda: field(xyz, dirs))
+        t_field_graphed, graphed_equal = None, None
+        try:  # the same forward as one replayed HIP graph (round 6): what the ~40 launches of a call cost the host is gone
+            with torch.no_grad():
+                want_s, want_c, _ = field(xyz, dirs)
+                t_field_graphed, (gs_, gc_, _) = timed(lambda: field.forward_graphed(xyz, dirs))
+                graphed_equal = bool(torch.equal(gs_, want_s) and torch.equal(gc_, want_c))
+        except Exception as e:  # noqa: BLE001 -- a side measurement
+            print(f"[bench] graphed curved-field forward failed ({type(e).__name__}: {e})", file=sys.stderr)
         gs, gc = torch.randn_like(sigma) * 1e-3, torch.randn_like(color) * 1e-3
 
         def field_fb():
@@ -1124,14 +1132,15 @@ def measure_curved(dev, n_points=262144, reps=10):
     total = t_knn + t_proj + t_fb
     t_knn_r, nb_r = timed(lambda: proj.knn(xyz_random))
     t_proj_r, _ = timed(lambda: proj.project_fused(xyz_random, neighbours=nb_r))
-    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces), sample points in a renderer's order (64 per ray): K = 8 neighbour search (uniform vertex grid, "
+    return {"workload": "configs[3]: curved-field texture lookup on a star_flower-shaped synthetic mesh (%d faces), sample points in a RENDERER'S ORDER (64 consecutive samples per ray -- what march_rays_train feeds the reference's MeshFeatureField; the random-order workload of rounds 3-4 is `random_order` below and is the round-over-round comparable): K = 8 neighbour search (uniform vertex grid, "
                         "exact) + projector (K-neighbour normal + two BVH traces + select + frame + FreqEncoder, one kernel) + GridEncoder_clustering L=8 hash "
                         "lookup forward and table-gradient backward, 1 GPU" % len(f),
             "points_per_batch": n_points, "inside_height_threshold": float(mask.float().mean()), "value": n_points / (total * 1e-6), "unit": "sample points/s",
             "random_order": {"neighbour_search_us": t_knn_r, "projector_us": t_proj_r, "value": n_points / ((t_knn_r + t_proj_r + t_fb) * 1e-6),
                              "note": "the same number of points around randomly drawn vertices in random order (the workload of rounds 3-4): divergence-bound search, profiles/r05_pmc_curved.txt"},
             "neighbour_search_us": t_knn, "projector_us": t_proj, "lookup_forward_us": t_fwd, "lookup_forward_backward_us": t_fb,
-            "field_forward_us": t_field_fwd, "field_forward_backward_us": t_field_fb, "field_points_per_s_forward_backward": n_points / (t_field_fb * 1e-6),
+            "field_forward_us": t_field_fwd, "field_forward_graphed_us": t_field_graphed, "field_forward_graphed_equals_eager": graphed_equal,
+            "field_forward_backward_us": t_field_fb, "field_points_per_s_forward_backward": n_points / (t_field_fb * 1e-6),
             "dtype": "f32 geometry, f16 table and MLPs under autocast"}
 
 

@@ -10,6 +10,7 @@ The optimizer being restated is the reference's: main_nerf.py:128 `torch.optim.A
 nerf/utils.py:1003-1009 (tests/test_gpu_trainstep.py pins the streaming kernel to torch's fused Adam; this file pins the tile form to that kernel).
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -431,3 +432,39 @@ def test_graphed_inference_stops_at_the_step_budget_like_the_reference_loop(dev)
         for job in r._infer_graphs["jobs"]:
             done = int(job.steps_done.item())
             assert max_steps <= done < max_steps + 8 * 4, (done, max_steps)  # the loop ran until the budget was used up, and not past it
+
+
+# ------------------------------------------------------------------------------------------------- curved field: the forward as one graph (item 8)
+def test_curved_field_forward_as_one_graph_equals_the_eager_forward(dev):
+    """CurvedField.forward_graphed: neighbour search, projector, lookup, the two FFMLPs and the framework ops between them replayed as one HIP graph --
+    the values of forward() (tools/map.py:414-433, 620-641 through the harness), bit for bit, on a second batch too (the graph's static inputs are
+    overwritten), and a changed parameter re-records."""
+    from ngp_harness.curved import CurvedField
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, p = np.load(os.path.join(golden, "ref_python_curvedfield.npz")), np.load(os.path.join(golden, "ref_python_projector.npz"))
+    field = CurvedField(p["vertices"], p["faces"], bound=1.0, h_threshold=float(p["h_threshold"]), vertex_normals=p["vertex_normals"], tbn=p["tbn"])
+    gen = torch.Generator().manual_seed(int(g["table_seed"]))
+    with torch.no_grad():
+        field.encoder.embeddings.copy_(torch.rand(field.encoder.embeddings.shape, generator=gen) - 0.5)
+        field.sigma_net.weights.copy_(torch.from_numpy(g["w_sigma"]))
+        field.color_net.weights.copy_(torch.from_numpy(g["w_color"]))
+    field = field.to(dev).eval()
+    v = torch.from_numpy(p["vertices"]).float()
+    n = 128 * 64
+    for k in range(2):
+        base = v[torch.randint(0, v.shape[0], (n,), generator=gen)]
+        x = (base * (1 + (torch.rand(n, 1, generator=gen) - 0.5) * 0.1)).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).to(dev)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            want_s, want_c, _ = field(x, d)
+            got_s, got_c, _ = field.forward_graphed(x, d)
+            assert torch.equal(got_s, want_s) and torch.equal(got_c, want_c), k
+        assert float(want_s.abs().sum()) > 0
+    graph = field._fwd_graph["graph"]
+    with torch.no_grad():
+        field.encoder.embeddings.mul_(1.5)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        want_s, _, _ = field(x, d)
+        got_s, _, _ = field.forward_graphed(x, d)
+    assert field._fwd_graph["graph"] is not graph and torch.equal(got_s, want_s)
