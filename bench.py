@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 # passes (FETCH_SIZE, WRITE_SIZE; profiles/r05_pmc_grid.txt: the bench's own children over the replayed step).  Backward: 2 x FETCH_SIZE (the gfx950 correction of
 # MI355X_MICROARCH.md for wide coalesced streams: here the 8-B record stream) + WRITE_SIZE.  Forward: FETCH_SIZE as reported
 # (4-B gathers are uncalibrated, and gathers served by L2 never reach the counter) + WRITE_SIZE.  None = not collected.
-TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 85.3e6, "grid_encode_backward": 496.3e6}  # (the FALLBACK only: the run measures them itself, rocprof_traffic)
-TRAFFIC_PROFILE = "profiles/r05_pmc_grid.txt"
+TRAFFIC_BYTES_PER_LAUNCH = {"grid_encode_forward": 85.3e6, "grid_encode_backward": 800.8e6}  # (the FALLBACK only: the run measures them itself, rocprof_traffic)
+TRAFFIC_PROFILE = "profiles/r06_pmc_grid.txt"
 COMMITTED_STATS = "profiles/r06_kernel_stats.csv"  # rocprofv3 --kernel-trace --stats of this script: the fallback when no live profile can be taken
 # device kernels behind each hash-grid C-ABI call (whichever of them ran)
 GRID_KERNELS = {
