@@ -10,9 +10,10 @@ namespace gridenc {
 namespace {
 
 constexpr uint32_t kTileBytes = 64 * 1024;              // LDS accumulator tile of K4: two workgroups per CU overlap their phases
-// accumulator bytes per table row in K4d: fp16 -> 2 x int64 fixed point, fp32 -> 2 x float
+// accumulator bytes per table row in K4d: 2 x int64 fixed point for both table types (fp16: value * 2^24, exact; fp32, round 6: value * 2^sh with sh
+// from the level's largest incoming gradient -- gridencoder_binned.hip FixedF32)
 template <typename T>
-constexpr uint32_t rows_per_tile() { return sizeof(T) == 2 ? kTileBytes / 16u : kTileBytes / 8u; }
+constexpr uint32_t rows_per_tile() { return kTileBytes / 16u; }
 
 // lane i <- lane i + N of the same 16-lane row (0 past the row's end): one VALU move with a DPP row shift, no LDS crossbar
 template <int N>

@@ -15,7 +15,13 @@
 //              (round-to-nearest-even of the true sum) -- deterministic, and tighter than the reference's chain of fp16
 //              atomics.  A tile several work items share (coarse levels) is combined in integers too: the items publish their exact
 //              partial sums, the last to arrive adds them and rounds once -- the whole fp16 gradient is bit-reproducible.
-//              fp32 tables keep float LDS atomics (and float atomics for shared tiles).
+//              fp32 tables (round 6): the same integer tiles.  A float has no common quantum, so the scale comes from the data: K3d leaves the
+//              largest |incoming gradient| of every level in a device word, K4d accumulates round(value * 2^sh) with sh chosen so that the
+//              level's largest share stays below 2^38 -- quantum = 2^-38 of the level's largest gradient, 2^14 times finer than a float's own
+//              resolution at that magnitude, and up to 2^24 shares per row still fit 63 bits.  Order-independent, so the fp32 gradient is
+//              bit-reproducible too (the LDS float atomics of rounds 2-5 were neither that nor fast: one lane per ~3 clocks per CU --
+//              0.676 ms per backward against the fp16 path's 0.2).  A non-finite share (an overflowed loss-scaled backward) poisons its row:
+//              the row comes back as nan, which is all GradScaler asks.
 // Coarse dense levels first merge runs of consecutive samples that share a cell (wave64 segmented reduction), which
 // removes their same-row pile-ups before anything is written.
 // The level table lives on the device; its host copy (needed to size grids and buffers) is either registered by the caller
@@ -110,6 +116,7 @@ constexpr uint32_t kQuad = 4;                              // a tile's run insid
 constexpr uint32_t kRegionRecords = 2 * 4 * kBinSamples + (kQuad - 1) * kMaxTilesPerLevel + 128;  // capacity of one (chunk, level) region (worst case + padding), a multiple of kQuad
 static_assert(kRegionRecords % kQuad == 0 && kRegionRecords < 65536, "directory words hold 16-bit offsets and counts");
 constexpr uint32_t kDirLdsBytes = (kSumThreads / kWave) * 2 * kWave * 4;  // K4d: per-wave run tables
+constexpr uint32_t kPoisonWords = (kTileBytes / 16u) / 32u;                // K4d, fp32 tables: one bit per row (a non-finite share), behind the run tables
 
 struct DirTable {
     int32_t offsets[kMaxLevels + 1];
@@ -120,7 +127,52 @@ struct DirTable {
     uint32_t part_base[kMaxLevels];      //                         index of the level's first partial tile in the partial-sum buffer
     uint32_t* stale_flag;                // deferred error word (pinned host memory): set when the device table differs from `offsets`
     float* found_inf;                    // optional: set to 1 when a written gradient element is inf / nan (GradScaler's scan, folded in)
+    uint32_t nchunks;                    // K3d workgroups per level
+    float* chunk_max;                    // fp32 tables: [L][nchunks] largest finite |incoming gradient| of every K3d workgroup (plain stores, no atomics:
+                                         // 115 k atomicMax on 16 words cost the fill kernel 1.2 ms); K4d / combine take the level's maximum of them
 };
+
+// fp32 tables: the fixed-point scale of a level.  |share| <= |gradient| <= max < 2^e  ->  share * 2^(38 - e) < 2^38.
+struct FixedF32 {
+    int sh;        // fixed = round(value * 2^sh)
+    float pre;     // 2^(sh - 20): value * pre splits into an integer part below 2^18 and a fraction (both exact in a float)
+};
+__device__ __forceinline__ FixedF32 fixed_f32_scale(float level_max) {
+    const uint32_t max_bits = __builtin_bit_cast(uint32_t, level_max);
+    int e = (int)((max_bits >> 23) & 0xffu) - 126;  // max < 2^e (subnormal or zero maxima: e = -126)
+    e = e < -80 ? -80 : e;                           // (a level whose largest gradient is below 2^-80: the scale stops growing)
+    FixedF32 f;
+    f.sh = 38 - e;
+    f.pre = ldexpf(1.0f, f.sh - 20);
+    return f;
+}
+// the level's maximum over its K3d workgroups' maxima (all threads of the workgroup call it; `red`: one float per wave in LDS)
+__device__ __forceinline__ float level_maximum(const float* __restrict__ chunk_max, uint32_t level, uint32_t nchunks, float* red) {
+    float m = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nchunks; i += blockDim.x) m = fmaxf(m, chunk_max[(size_t)level * nchunks + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
+    __syncthreads();
+    float r = 0.0f;
+    for (uint32_t w = 0; w < blockDim.x / kWave; w++) r = fmaxf(r, red[w]);
+    __syncthreads();
+    return r;
+}
+constexpr long long kPoison = (long long)0x8000000000000000ull;  // a row that received a non-finite share
+__device__ __forceinline__ long long to_fixed_f32(float v, const FixedF32& f) {
+    const float t = v * f.pre;                 // exact (a power of two), |t| < 2^18
+    const float hi = truncf(t);
+    float lo = rintf((t - hi) * 1048576.0f);  // the fraction, to 2^-20 of t = 2^-sh of v, nearest
+    // ... but never to nothing: a share below half a quantum (2^-39 of the level's largest gradient) still marks its row as touched, as a float
+    // accumulation would -- one quantum instead of zero (the reference's fixtures count the rows that receive a gradient)
+    if (hi == 0.0f && lo == 0.0f && v != 0.0f) lo = v > 0.0f ? 1.0f : -1.0f;
+    return ((long long)(int)hi << 20) + (long long)(int)lo;
+}
+__device__ __forceinline__ float from_fixed_f32(long long s, const FixedF32& f) {
+    if (s == kPoison) return __builtin_nanf("");
+    return (float)ldexp((double)s, -f.sh);
+}
 
 // Round 6: the optimizer's update applied by K4d itself.  A workgroup that is the SOLE owner of a tile (every hashed level: slices == 1) ends with
 // the tile's exact gradient in LDS; instead of writing 16 KiB of fp16 gradient for a streaming Adam kernel to read back one launch later, it
@@ -166,6 +218,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
                                                                   uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe, const uint32_t stage_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1];
+    __shared__ float s_wmax[kBinSamples / kWave];
     constexpr int NP = Sample<T, D>::NP;
     constexpr uint32_t kRows = rows_per_tile<T>();
     // an LDS-qualified pointer: with a generic one the compiler merges the LDS store and the rare overflow store to global memory of
@@ -180,14 +233,6 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     if (!table_matches(tab, offsets, level)) return;  // stale host copy: deferred error, nothing written
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t hashmap_size = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
-    // caller handed over an uninitialised gradient table: the tiles of this level that several K4d work items will add into
-    // (coarse levels only) start from zero -- this level's workgroups clear one slice of its rows each; sole-owner tiles are
-    // written whole by K4d
-    if (sizeof(T) == 4 && zero_grid != nullptr && tab.slices[level] > 1) {  // fp16: K4d's last work item of a shared tile writes all of it
-        const uint32_t units = hashmap_size * 2, per = div_up(units, nchunks);  // elements (2 per row)
-        T* base = zero_grid + (size_t)(uint32_t)tab.offsets[level] * 2;
-        for (uint32_t i = chunk * per + threadIdx.x; i < min(units, (chunk + 1) * per); i += kBinSamples) base[i] = (T)0.0f;
-    }
     const uint32_t ntiles = tab.tile_base[level + 1] - tab.tile_base[level];
     Rec<T>* region = records + ((size_t)level * nchunks + chunk) * kRegionRecords;
 
@@ -199,6 +244,14 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     for (int d = 0; d < D; d++) xs[d] = 0.0f;
     if (in_batch) load_coords<D>(lc, inputs, (size_t)b, xs);
     if (in_batch) load_row<T, 2>(BLC ? grad + ((size_t)b * L + level) * 2 : grad + ((size_t)level * B + b) * 2, g);
+    if constexpr (sizeof(T) == 4) {
+        // fp32 tables: the workgroup's largest finite |incoming gradient| (K4d derives the level's fixed-point scale from these)
+        float m = fmaxf(fabsf(g[0]), fabsf(g[1]));
+        if (!(m <= 3.0e38f)) m = 0.0f;  // (inf / nan do not set the scale: they poison their rows in K4d)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+        if (lane == 0) s_wmax[threadIdx.x / kWave] = m;  // (joined behind the next barrier)
+    }
     if (probe == 4) {  // ablation: launch + loads only
         if (xs[0] == 1234.5f && xs[D - 1] == 77.0f && g[1] == 3.0f && g[0] == 2.0f) dir[0] = 1;
         return;
@@ -218,6 +271,14 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
         return;
     }
     __syncthreads();
+    if constexpr (sizeof(T) == 4) {  // the workgroup's largest incoming gradient: one plain store (K4d / combine take the level's maximum)
+        if (threadIdx.x == 0) {
+            float m = 0.0f;
+#pragma unroll
+            for (uint32_t w = 0; w < kBinSamples / kWave; w++) m = fmaxf(m, s_wmax[w]);
+            tab.chunk_max[(size_t)level * nchunks + chunk] = m;
+        }
+    }
 
     // ---- count per tile.  The counting atomic's RETURN value is the record's rank inside its tile's run: kept (two 16-bit ranks per
     // register) and added to the tile's base after the scan -- one LDS atomic per record instead of a count pass plus a slot pass
@@ -307,7 +368,7 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
 // The split without a 64-bit multiply: fixed(g') = ms << s with the half's signed significand ms (12 bits) and s = max(exponent - 1, 0),
 // so fixed(g') p16 = (ms p16) << s with ms p16 one full-rate 24-bit multiply.
 template <typename T>
-__device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
+__device__ __forceinline__ void add_record(char* smem, const Rec<T>& r, const FixedF32& fx) {
     constexpr uint32_t kBits = row_bits<T>();
     const uint32_t ra = r.word & ((1u << kBits) - 1u), code = (r.word >> kBits) & 15u;
     const uint32_t rb = ra ^ ((2u << code) - 1u);
@@ -337,16 +398,22 @@ __device__ __forceinline__ void add_record(char* smem, const Rec<T>& r) {
             if (!single) atomicAdd(acc64 + (size_t)rb * 2 + c, (unsigned long long)bshare);
         }
     } else {
-        float* acc32 = reinterpret_cast<float*>(smem);
-        if (code == kSingle) {
-            atomicAdd(acc32 + (size_t)ra * 2, r.g0);
-            atomicAdd(acc32 + (size_t)ra * 2 + 1, r.g1);
-        } else {
-            const float wa = 1 - r.p;
-            atomicAdd(acc32 + (size_t)ra * 2, wa * r.g0);
-            atomicAdd(acc32 + (size_t)ra * 2 + 1, wa * r.g1);
-            atomicAdd(acc32 + (size_t)rb * 2, r.p * r.g0);
-            atomicAdd(acc32 + (size_t)rb * 2 + 1, r.p * r.g1);
+        // fp32 (round 6): the same integer tile.  A non-finite share poisons its row (a flag word per 32 rows behind the run tables)
+        unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
+        uint32_t* poison = reinterpret_cast<uint32_t*>(smem + kTileBytes + kDirLdsBytes);
+        const bool single = code == kSingle;
+        const float gg[2] = {r.g0, r.g1};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (!(fabsf(gg[c]) <= 3.0e38f)) {
+                atomicOr(poison + (ra >> 5), 1u << (ra & 31u));
+                if (!single) atomicOr(poison + (rb >> 5), 1u << (rb & 31u));
+                continue;
+            }
+            const float vb = single ? 0.0f : r.p * gg[c];
+            const float va = single ? gg[c] : (1 - r.p) * gg[c];
+            atomicAdd(acc64 + (size_t)ra * 2 + c, (unsigned long long)to_fixed_f32(va, fx));
+            if (!single) atomicAdd(acc64 + (size_t)rb * 2 + c, (unsigned long long)to_fixed_f32(vb, fx));
         }
     }
 }
@@ -380,14 +447,18 @@ __device__ __forceinline__ bool sum_item(const DirTable& tab, uint32_t L, uint32
 template <typename T>
 __device__ __forceinline__ void zero_tile(char* smem, uint32_t nrows) {
     float4_t* z = reinterpret_cast<float4_t*>(smem);
-    const uint32_t nq = sizeof(T) == 2 ? nrows : (nrows + 1) / 2;  // 16 B per table row (fp16: 2 x int64), 8 B (fp32: 2 x float)
-    for (uint32_t i = threadIdx.x; i < nq; i += kSumThreads) z[i] = float4_t{0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < nrows; i += kSumThreads) z[i] = float4_t{0, 0, 0, 0};  // 16 B per table row: 2 x int64
+    if constexpr (sizeof(T) == 4) {
+        uint32_t* poison = reinterpret_cast<uint32_t*>(smem + kTileBytes + kDirLdsBytes);
+        if (threadIdx.x < kPoisonWords) poison[threadIdx.x] = 0u;
+    }
 }
 
 // tile -> table.  A tile with a single work item has a single writer in this launch: plain stores (or read-add-write),
 // deterministic.  Split tiles add their partial sums with atomics; consecutive lanes hit consecutive addresses.
 template <typename T>
-__device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst, uint32_t nrows, bool sole, bool overwrite, float* found_inf) {
+__device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst, uint32_t nrows, bool sole, bool overwrite, float* found_inf,
+                                           const FixedF32& fx) {
     if constexpr (sizeof(T) == 2) {
         const unsigned long long* acc64 = reinterpret_cast<const unsigned long long*>(smem);
         bool bad = false;
@@ -412,17 +483,17 @@ __device__ __forceinline__ void write_tile(const char* smem, T* __restrict__ dst
         }
         if (found_inf && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) *found_inf = 1.0f;
     } else {
-        const float* acc32 = reinterpret_cast<const float*>(smem);
+        // fp32: sole owners only (shared tiles leave their integer partials to combine_tiles_kernel, as for fp16)
+        const unsigned long long* acc64 = reinterpret_cast<const unsigned long long*>(smem);
         for (uint32_t i = threadIdx.x; i < nrows * 2; i += kSumThreads) {
-            const float v = acc32[i];
+            const long long sv = (long long)acc64[i];
             float* p = reinterpret_cast<float*>(dst) + i;
-            if (sole && overwrite) {
-                *p = v;
+            if (overwrite) {
+                *p = from_fixed_f32(sv, fx);
                 continue;
             }
-            if (v == 0.0f) continue;
-            if (sole) *p = *p + v;
-            else unsafeAtomicAdd(p, v);
+            if (sv == 0) continue;
+            *p = *p + from_fixed_f32(sv, fx);
         }
     }
 }
@@ -505,6 +576,9 @@ __global__ __launch_bounds__(kSumThreads) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     constexpr uint32_t kWaves = kSumThreads / kWave;
     zero_tile<T>(smem, it.nrows);
+    FixedF32 fx{0, 0.0f};
+    if constexpr (sizeof(T) == 4)  // (K3d, the launch in front, has left its workgroups' largest gradients; the run tables' LDS is free until the walk)
+        fx = fixed_f32_scale(level_maximum(tab.chunk_max, it.level, nchunks, reinterpret_cast<float*>(smem + kTileBytes)));
     if constexpr (ADAM) {  // the step's constants (two double pows): one lane, once, while the others clear the tile
         if (threadIdx.x == 0 && (it.slices == 1 || blockIdx.x + item_offset == 0)) {
             s_step = adam_step_consts(adam.k, (double)(*adam.step + 1.0f), adam.grad_scale);
@@ -556,7 +630,7 @@ __global__ __launch_bounds__(kSumThreads) __attribute__((amdgpu_waves_per_eu(8, 
             }
 #pragma unroll
             for (uint32_t j = 0; j < kQuad; j++)
-                if (!adds_nothing<T>(q.r[j])) add_record<T>(smem, q.r[j]);
+                if (!adds_nothing<T>(q.r[j])) add_record<T>(smem, q.r[j], fx);
         }
     }
     [[maybe_unused]] AdamRows rows_state;
@@ -564,9 +638,21 @@ __global__ __launch_bounds__(kSumThreads) __attribute__((amdgpu_waves_per_eu(8, 
         if (it.slices == 1) adam_tile_load(adam, it.dst_row, it.nrows, rows_state);
     }
     __syncthreads();
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 4) {  // rows that received a non-finite share: both accumulators <- the poison value (comes back as nan)
+        const uint32_t* poison = reinterpret_cast<const uint32_t*>(smem + kTileBytes + kDirLdsBytes);
+        unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(smem);
+        bool any = false;
+        for (uint32_t i = threadIdx.x; i < it.nrows; i += kSumThreads)
+            if ((poison[i >> 5] >> (i & 31u)) & 1u) {
+                acc64[(size_t)i * 2] = acc64[(size_t)i * 2 + 1] = (unsigned long long)kPoison;
+                any = true;
+            }
+        (void)any;
+        __syncthreads();
+    }
+    {
         // A tile shared by several work items (coarse levels): every item leaves its EXACT integer sums in the partial-sum buffer and
-        // combine_tiles_kernel adds them -- integer addition, any order, same result -- and rounds the tile to fp16 once.  No
+        // combine_tiles_kernel adds them -- integer addition, any order, same result -- and rounds the tile once.  No
         // floating-point atomics on the table: the gradient is the correctly rounded sum, the same bits on every run.
         if (it.slices > 1) {
             constexpr size_t kTileElems = (size_t)rows_per_tile<T>() * 2;
@@ -580,32 +666,39 @@ __global__ __launch_bounds__(kSumThreads) __attribute__((amdgpu_waves_per_eu(8, 
         adam_tile(smem, adam, s_step, it.dst_row, it.nrows, tab.found_inf, rows_state);  // (sole owner: shared tiles have returned above)
         return;
     }
-    write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite, tab.found_inf);
+    write_tile<T>(smem, grad_grid + it.dst_row * 2, it.nrows, it.slices == 1, overwrite, tab.found_inf, fx);
 }
 
 // The tiles several K4d work items shared: one workgroup per (tile, 64 rows) adds the items' integer partial sums -- wave q takes the
 // items q, q + 4, ... (coalesced 1 KiB reads, several in flight), LDS joins the four -- and writes the rows, rounded to fp16 once
 // (or adds them to what the caller's buffer holds).
 constexpr uint32_t kCombineRows = kWave, kCombineWaves = 4, kCombineThreads = kCombineRows * kCombineWaves;
-template <bool ADAM>
+template <typename T, bool ADAM>
 __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const unsigned long long* __restrict__ partials, const DirTable tab, uint32_t L,
-                                                                       half_t* __restrict__ grad_grid, const bool overwrite,
+                                                                       T* __restrict__ grad_grid, const bool overwrite,
                                                                        const int* __restrict__ offsets, const uint32_t first_split_tile,
                                                                        const std::conditional_t<ADAM, TileAdam, NoAdam> adam) {
+    static_assert(!ADAM || sizeof(T) == 2, "the tile-owner update: fp16 tables");
     __shared__ unsigned long long s_sum[kCombineWaves][kCombineRows][2];
-    constexpr uint32_t kRows = rows_per_tile<half_t>(), kSegs = kRows / kCombineRows;
+    constexpr uint32_t kRows = rows_per_tile<T>(), kSegs = kRows / kCombineRows;
     const uint32_t split_tile = first_split_tile + blockIdx.x / kSegs, seg = blockIdx.x % kSegs;
     uint32_t level = 0;  // the split level this tile belongs to: split_base is non-decreasing and steps only at split levels
     for (uint32_t l = 0; l < L; l++)
         if (tab.slices[l] > 1 && tab.split_base[l] <= split_tile) level = l;
     const uint32_t t = split_tile - tab.split_base[level], slices = tab.slices[level];
     if (!table_matches(tab, offsets, level)) return;
+    [[maybe_unused]] FixedF32 fx{0, 0.0f};
+    if constexpr (sizeof(T) == 4) {
+        __shared__ float s_red[kCombineWaves];
+        fx = fixed_f32_scale(level_maximum(tab.chunk_max, level, tab.nchunks, s_red));
+    }
     const uint32_t rows_level = (uint32_t)(tab.offsets[level + 1] - tab.offsets[level]);
     const uint32_t lane = threadIdx.x % kCombineRows, q = threadIdx.x / kCombineRows;
     const uint32_t local = seg * kCombineRows + lane, row = t * kRows + local;
     if (t * kRows + seg * kCombineRows >= rows_level) return;  // whole segment past the level's last row
     const ulonglong2* first = reinterpret_cast<const ulonglong2*>(partials + ((size_t)tab.part_base[level] + (size_t)t * slices) * kRows * 2);
     unsigned long long s0 = 0, s1 = 0;
+    [[maybe_unused]] bool poisoned = false;  // fp32 tables: some work item's partial of this row is the poison value (a non-finite share)
     if (row < rows_level) {
         uint32_t sl = q;
         for (; sl + 3 * kCombineWaves < slices; sl += 4 * kCombineWaves) {  // four independent loads in flight
@@ -613,12 +706,18 @@ __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const un
             const ulonglong2 c = first[(size_t)(sl + 2 * kCombineWaves) * kRows + local], d = first[(size_t)(sl + 3 * kCombineWaves) * kRows + local];
             s0 += (a.x + b.x) + (c.x + d.x);
             s1 += (a.y + b.y) + (c.y + d.y);
+            if constexpr (sizeof(T) == 4) poisoned |= a.x == (unsigned long long)kPoison || b.x == (unsigned long long)kPoison || c.x == (unsigned long long)kPoison ||
+                                                      d.x == (unsigned long long)kPoison;
         }
         for (; sl < slices; sl += kCombineWaves) {
             const ulonglong2 a = first[(size_t)sl * kRows + local];
             s0 += a.x;
             s1 += a.y;
+            if constexpr (sizeof(T) == 4) poisoned |= a.x == (unsigned long long)kPoison;
         }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (poisoned) s0 = s1 = (unsigned long long)kPoison;  // (survives the join below: see there)
     }
     s_sum[q][lane][0] = s0;
     s_sum[q][lane][1] = s1;
@@ -626,8 +725,12 @@ __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const un
     if (q != 0 || row >= rows_level) return;
 #pragma unroll
     for (uint32_t w = 1; w < kCombineWaves; w++) {
+        if constexpr (sizeof(T) == 4) poisoned |= s_sum[w][lane][0] == (unsigned long long)kPoison;
         s0 += s_sum[w][lane][0];
         s1 += s_sum[w][lane][1];
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (poisoned) s0 = s1 = (unsigned long long)kPoison;
     }
     if constexpr (ADAM) {
         // the shared tiles' rows get the optimizer's update here, where their gradient is final (one row = two parameters per lane): like the
@@ -656,16 +759,24 @@ __global__ __launch_bounds__(kCombineThreads) void combine_tiles_kernel(const un
         if (tab.found_inf && half2_nonfinite(g)) *tab.found_inf = 1.0f;
         return;
     }
-    half2_t* dst = reinterpret_cast<half2_t*>(grad_grid) + (size_t)(uint32_t)tab.offsets[level];
-    half2_t w = half2_t{(half_t)0.0f, (half_t)0.0f};
-    if (overwrite) {
-        w = half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
-        dst[row] = w;
-    } else if ((s0 | s1) != 0) {
-        w = dst[row] + half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
-        dst[row] = w;
+    if constexpr (sizeof(T) == 2) {
+        half2_t* dst = reinterpret_cast<half2_t*>(grad_grid) + (size_t)(uint32_t)tab.offsets[level];
+        half2_t w = half2_t{(half_t)0.0f, (half_t)0.0f};
+        if (overwrite) {
+            w = half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+            dst[row] = w;
+        } else if ((s0 | s1) != 0) {
+            w = dst[row] + half2_t{fixed_to_half((long long)s0), fixed_to_half((long long)s1)};
+            dst[row] = w;
+        }
+        if (tab.found_inf && half2_nonfinite(w)) *tab.found_inf = 1.0f;
+    } else {
+        typedef float float2_t __attribute__((ext_vector_type(2)));
+        float2_t* dst = reinterpret_cast<float2_t*>(grad_grid) + (size_t)(uint32_t)tab.offsets[level];
+        const float2_t v = float2_t{from_fixed_f32((long long)s0, fx), from_fixed_f32((long long)s1, fx)};
+        if (overwrite) dst[row] = v;
+        else if ((s0 | s1) != 0) dst[row] = dst[row] + v;
     }
-    if (tab.found_inf && half2_nonfinite(w)) *tab.found_inf = 1.0f;
 }
 
 // ---- host: cached copy of the level table -----------------------------------------------------------------------------
@@ -786,7 +897,7 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         items += nt * sl;
         dt.split_base[l] = split_tiles;
         dt.part_base[l] = part_tiles;
-        if (sl > 1 && sizeof(T) == 2) {
+        if (sl > 1) {
             split_tiles += nt;
             part_tiles += nt * sl;
         }
@@ -823,10 +934,13 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
     const size_t part_bytes = (size_t)part_tiles * kTileBytes;  // exact integer partial sums of the tiles several work items share
     constexpr size_t kConstBytes = 256;  // one AdamStep (tile-owner update), in front of everything
     static_assert(sizeof(AdamStep) <= kConstBytes, "scratch slot of the step constants");
-    char* dbase0 = static_cast<char*>(workspace(kWsGridBins, kConstBytes + dir_bytes + part_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
+    const size_t max_bytes = sizeof(T) == 4 ? (sizeof(float) * (size_t)L * nchunks + 255) / 256 * 256 : 0;  // fp32 tables: the K3d workgroups' largest gradients
+    char* dbase0 = static_cast<char*>(workspace(kWsGridBins, kConstBytes + max_bytes + dir_bytes + part_bytes + sizeof(Rec<T>) * (size_t)L * nchunks * kRegionRecords, st));
     if (!dbase0) return NERFTEX_ERR_HIP;
     ad.step_consts = reinterpret_cast<AdamStep*>(dbase0);
-    char* dbase = dbase0 + kConstBytes;
+    dt.nchunks = nchunks;
+    dt.chunk_max = reinterpret_cast<float*>(dbase0 + kConstBytes);
+    char* dbase = dbase0 + kConstBytes + max_bytes;
     uint32_t* dir = reinterpret_cast<uint32_t*>(dbase);
     unsigned long long* partials = reinterpret_cast<unsigned long long*>(dbase + dir_bytes);
     Rec<T>* recs = reinterpret_cast<Rec<T>*>(dbase + dir_bytes + part_bytes);
@@ -859,35 +973,38 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         if constexpr (sizeof(T) == 2) {
             if (ta) {
                 auto kernel = sum_tiles_dir_kernel<T, true>;
-                NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
+                NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes + kPoisonWords * 4)), "hipFuncSetAttribute");
                 KernelTimer kt("sum_tiles_adam_kernel", st, kTimeGrid);
-                hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite,
+                hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes + kPoisonWords * 4, st, recs, dir, L, dt, nchunks, grad_grid, overwrite,
                                    partials, offsets_dev, probe, item_lo, ad);
             }
         }
         if (!ta) {
             auto kernel = sum_tiles_dir_kernel<T, false>;
-            NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes)), "hipFuncSetAttribute");
+            NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTileBytes + kDirLdsBytes + kPoisonWords * 4)), "hipFuncSetAttribute");
             KernelTimer kt("sum_tiles_dir_kernel", st, kTimeGrid);
-            hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials,
+            hipLaunchKernelGGL(kernel, dim3(item_hi - item_lo), dim3(kSumThreads), kTileBytes + kDirLdsBytes + kPoisonWords * 4, st, recs, dir, L, dt, nchunks, grad_grid, overwrite, partials,
                                offsets_dev, probe, item_lo, NoAdam{});
         }
     }
     if ((rc = check_launch("grid_encode_backward(sum)")) != NERFTEX_OK) return rc;
-    if constexpr (sizeof(T) == 2) {
+    {
         const uint32_t split_lo = dt.split_base[lv_lo], split_hi = lv_hi < L ? dt.split_base[lv_hi] : split_tiles;
         if (split_hi > split_lo) {
             KernelTimer kt("combine_tiles_kernel", st, kTimeGrid);
-            if (ta)
-                hipLaunchKernelGGL(combine_tiles_kernel<true>, dim3((split_hi - split_lo) * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
-                                   reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev, split_lo, ad);
-            else
-                hipLaunchKernelGGL(combine_tiles_kernel<false>, dim3((split_hi - split_lo) * (kRows / kCombineRows)), dim3(kCombineThreads), 0, st, partials, dt, L,
-                                   reinterpret_cast<half_t*>(grad_grid), overwrite, offsets_dev, split_lo, NoAdam{});
+            const dim3 grid((split_hi - split_lo) * (kRows / kCombineRows));
+            if constexpr (sizeof(T) == 2) {
+                if (ta)
+                    hipLaunchKernelGGL((combine_tiles_kernel<T, true>), grid, dim3(kCombineThreads), 0, st, partials, dt, L, grad_grid, overwrite, offsets_dev, split_lo, ad);
+                else
+                    hipLaunchKernelGGL((combine_tiles_kernel<T, false>), grid, dim3(kCombineThreads), 0, st, partials, dt, L, grad_grid, overwrite, offsets_dev, split_lo,
+                                       NoAdam{});
+            } else {
+                hipLaunchKernelGGL((combine_tiles_kernel<T, false>), grid, dim3(kCombineThreads), 0, st, partials, dt, L, grad_grid, overwrite, offsets_dev, split_lo, NoAdam{});
+            }
         }
         return check_launch("grid_encode_backward(combine)");
     }
-    return NERFTEX_OK;
 }
 
 template int grid_backward_binned<float, 2>(const float*, bool, const float*, const int*, float*, uint32_t, uint32_t, const LevelConsts&, uint32_t, bool, bool, hipStream_t);
