@@ -1,5 +1,5 @@
 #!/bin/bash
-# the two judged measurements only: the default bench line and the rocprofv3 kernel statistics of the same command (tools/gpu_profiles_r04.sh has the rest)
+# the two judged measurements only: the default bench line and the rocprofv3 kernel statistics of the same command (tools/gpu_profiles_r06.sh has the rest)
 tag=${1:-r04final}
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
