@@ -81,7 +81,9 @@ class HalfLeafAdam(torch.optim.Optimizer):
         self._m = [list(self.exp_avg), [torch.empty_like(t) for t in self.exp_avg]]
         self._v = [list(self.exp_avg_sq), [torch.empty_like(t) for t in self.exp_avg_sq]]
         self.live = torch.zeros((), dtype=torch.int32, device=dev)
+        # reading OR loading an owner's state dict must see / land in the live set (a checkpoint loaded into the stale set would be lost at the next sync)
         self._hooks = [mod.register_state_dict_pre_hook(lambda *_a, **_k: self.sync()) for mod in self._owners]
+        self._hooks += [mod.register_load_state_dict_pre_hook(lambda *_a, **_k: self.sync()) for mod in self._owners]
         return self
 
     def sync(self):

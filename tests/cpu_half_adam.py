@@ -13,6 +13,8 @@ class CpuHalfLeafAdam(HalfLeafAdam):
 
     def _launch(self, step_offset, grad_scale, found_inf, amp=None, exclude=()):
         idx = [i for i, leaf in enumerate(self.leaves) if leaf.grad is not None and i not in exclude]
+        if self.live is not None:
+            return self._launch_double_buffered(idx, amp, exclude)
         grp = self.param_groups[0]
         lr, (b1, b2), eps = float(grp["lr"]), grp["betas"], grp["eps"]
         if amp is not None:
@@ -46,6 +48,46 @@ class CpuHalfLeafAdam(HalfLeafAdam):
                     tracker.fill_(ok)
                 self.step_count += 1
             found.zero_()
+
+
+    # ---- double-buffered form (round 6): the stand-in of nerftex_adam_mixed_step_amp_db -- reads the live set, writes the other one, flips `live` iff the
+    # step is applied; a table whose rows from `first_row` on an earlier kernel of the step has updated already is passed up to that row only, and on a
+    # skipped step the 16-bit copy of the rows behind it is re-derived from the live set (the repair)
+    def _launch_double_buffered(self, idx, amp, exclude):
+        assert amp is not None and not exclude and idx == list(range(len(self.leaves)))
+        fused, self.fused_table = self.fused_table, None
+        grp = self.param_groups[0]
+        lr, (b1, b2), eps = float(grp["lr"]), grp["betas"], grp["eps"]
+        scale, tracker, found, _ticket, growth, backoff, interval = amp
+        live = int(self.live) & 1
+        skip = float(found) == 1.0
+        if not skip:
+            steps = float(self.step_count) + 1.0
+            bc1, bc2_sqrt = 1 - b1 ** steps, (1 - b2 ** steps) ** 0.5
+            for i in idx:
+                rows = slice(0, fused[1]) if (fused is not None and fused[0] == i) else slice(None)
+                g = self.leaves[i].grad.float()[rows] / float(scale)
+                m = self._m[live][i][rows].clone().lerp_(g, 1 - b1)  # (the single-buffered stand-in's operations, on copies)
+                v = self._v[live][i][rows].clone().mul_(b2).addcmul_(g, g, value=1 - b2)
+                p = self._p[live][i][rows].clone().addcdiv_(m, (v.sqrt() / bc2_sqrt).add_(eps), value=-lr / bc1)
+                self._m[live ^ 1][i][rows], self._v[live ^ 1][i][rows], self._p[live ^ 1][i][rows] = m, v, p
+                self.leaves[i].data[rows] = p.to(self.leaves[i].dtype)
+        elif fused is not None:
+            i, first = fused
+            self.leaves[i].data[first:] = self._p[live][i][first:].to(self.leaves[i].dtype)
+        if float(found) != 0.0:
+            scale.mul_(backoff)
+            tracker.zero_()
+        else:
+            ok = int(tracker) + 1
+            if ok == interval:
+                scale.mul_(growth)
+                tracker.zero_()
+            else:
+                tracker.fill_(ok)
+            self.step_count += 1
+            self.live ^= 1
+        found.zero_()
 
 
 class CpuFusedAmp(FusedAmp):
