@@ -623,6 +623,19 @@ int nerftex_field_mid_backward(const float* grad_sigma, const void* grad_cin, co
                                void* stream);
 /* hc [B,16] fp16 (colour-net outputs) -> rgbs [B,3] fp32 = sigmoid(hc[:,:3]) rounded through fp16 (network_ff.py:99-100) */
 int nerftex_field_out_forward(const void* hc, uint32_t B, float* rgbs, void* stream);
+/* Extension (round 6): the same kind of glue for the CURVED field (network_curvedfield.py:283-306 around tools/map.py:620-641's MeshFeatureField):
+ *   nerftex_curved_pack_inputs   x_embed [B,16] half, z_embed [B,25] fp32 -> [B,48] half = [x_embed | half(z_embed) | 1 x 7] (the sigma net's padded input)
+ *   nerftex_curved_mid_forward   h [B,16] half, normal [B,3] fp32, dirs [B,3] fp32 -> sigma [B] half = exp(h[:,0]) (trunc_exp),
+ *                                cin [B,32] half = [SH4 of the view direction reflected about the normal | h[:,1:16] | 1]; eval != 0: the
+ *                                fc_weight blend + renormalisation of :289-291
+ *   nerftex_curved_out_forward   hc rows of row_stride halfs, sigma_raw [B] half, mask [B] bytes -> sigma = mask ? sigma_raw : 0,
+ *                                color [B,3] half = mask ? sigmoid(hc[:, :3]) : 0
+ * Forward only: their backward passes are slices / the sigmoid derivative (nerftex_field_mid_backward serves the middle one).               */
+int nerftex_curved_pack_inputs(const void* x_embed, const float* z_embed, uint32_t B, void* out, void* stream);
+int nerftex_curved_mid_forward(const void* h, const float* normal, const float* dirs, uint32_t B, float fc_weight, int eval, void* sigma, void* cin,
+                               void* stream);
+int nerftex_curved_out_forward(const void* hc, uint32_t row_stride, const void* sigma_raw, const uint8_t* mask, uint32_t B, void* sigma, void* color,
+                               void* stream);
 /* grad_hc [B,16] fp16 = sigmoid backward of the fp16-narrowed grad_rgbs, columns 3..15 zero                      */
 int nerftex_field_out_backward(const float* grad_rgbs, const float* rgbs, uint32_t B, void* grad_hc, void* stream);
 

@@ -103,10 +103,143 @@ __global__ __launch_bounds__(256) void field_out_backward_kernel(const float* __
     out[0] = o0; out[1] = o1;
 }
 
+// ---- the curved field's glue (round 6) -------------------------------------------------------------------------------
+// network_curvedfield.py:283-306 + tools/map.py:620-641 string MeshFeatureField, the sigma net and the colour net together with ~30 small framework
+// ops per forward (normalisations, the view direction reflected about the normal, SH, pads, concatenations, masks): ~200 us of launch-latency-
+// bound kernels per 262 k points.  Three streaming kernels instead, the framework's fp32 arithmetic step by step.
+
+// x_embed [B,16] half, z_embed [B,25] fp32 -> [B,48] half = [x_embed | half(z_embed) | 1 x 7]  (tcnn pads its inputs with ones)
+__global__ __launch_bounds__(256) void curved_pack_inputs_kernel(const half_t* __restrict__ x_embed, const float* __restrict__ z_embed, uint32_t B,
+                                                                half_t* __restrict__ out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    half8_t o[6];
+    o[0] = *reinterpret_cast<const half8_t*>(x_embed + (size_t)b * 16);
+    o[1] = *reinterpret_cast<const half8_t*>(x_embed + (size_t)b * 16 + 8);
+    const float* z = z_embed + (size_t)b * 25;
+#pragma unroll
+    for (int i = 0; i < 32; i++) o[2 + i / 8][i % 8] = i < 25 ? (half_t)z[i] : (half_t)1.0f;
+    half8_t* dst = reinterpret_cast<half8_t*>(out + (size_t)b * 48);
+#pragma unroll
+    for (int i = 0; i < 6; i++) dst[i] = o[i];
+}
+
+// h [B,16] half (the sigma net's output), normal [B,3] fp32 (MeshFeatureField's normalised coarse normal), dirs [B,3] fp32
+//   -> sigma [B] half = half(exp(h[:,0]))  (trunc_exp forward, tools/activation.py:5-17, on a half tensor)
+//      cin [B,32] half = [SH4(2 ((wr + 1) / 2) - 1) | h[:,1:16] | 1],  wr = the view direction reflected about the normal (:283-306)
+__global__ __launch_bounds__(256) void curved_mid_forward_kernel(const half_t* __restrict__ h, const float* __restrict__ normal, const float* __restrict__ dirs,
+                                                                uint32_t B, const float fc, const int eval, half_t* __restrict__ sigma,
+                                                                half_t* __restrict__ cin) {
+#pragma clang fp contract(off)  // every framework op rounds on its own
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const half8_t h0 = *reinterpret_cast<const half8_t*>(h + (size_t)b * 16);
+    const half8_t h1 = *reinterpret_cast<const half8_t*>(h + (size_t)b * 16 + 8);
+    sigma[b] = narrow(expf((float)h0[0]));
+    float n[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        n[c] = normal[(size_t)b * 3 + c];
+        d[c] = dirs[(size_t)b * 3 + c];
+    }
+    auto unit = [](float (&v)[3]) {  // v / (|v| + 1e-5)
+        const float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + 1e-5f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = v[c] / len;
+    };
+    unit(n);
+    if (eval) {  // :289-291 with the coarse normal on both sides
+#pragma unroll
+        for (int c = 0; c < 3; c++) n[c] = fc * n[c] + (1 - fc) * n[c];
+        unit(n);
+    }
+    unit(d);
+    const float dot = ((-d[0] * n[0]) + (-d[1] * n[1])) + (-d[2] * n[2]);
+    float wr[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float w = (2 * dot) * n[c] + d[c];
+        wr[c] = ((w + 1) / 2) * 2 - 1;  // tcnn's SH takes [0, 1]; the encoder maps it back
+    }
+    float r[16];
+    sh::eval<4>(wr[0], wr[1], wr[2], r);
+    half8_t o0, o1, o2, o3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        o0[i] = narrow(r[i]);
+        o1[i] = narrow(r[8 + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) o2[i] = h0[1 + i];
+    o2[7] = h1[0];
+#pragma unroll
+    for (int i = 0; i < 7; i++) o3[i] = h1[1 + i];
+    o3[7] = (half_t)1.0f;
+    half8_t* out = reinterpret_cast<half8_t*>(cin + (size_t)b * 32);
+    out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
+}
+
+// hc: the colour net's output rows (3 of `stride` halfs used), sigma_raw [B] half, mask [B] bytes
+//   -> sigma [B] half = mask ? sigma_raw : 0,  color [B,3] half = mask ? half(sigmoid(hc)) : 0
+__global__ __launch_bounds__(256) void curved_out_forward_kernel(const half_t* __restrict__ hc, uint32_t stride, const half_t* __restrict__ sigma_raw,
+                                                                const uint8_t* __restrict__ mask, uint32_t B, half_t* __restrict__ sigma,
+                                                                half_t* __restrict__ color) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool m = mask[b] != 0;
+    sigma[b] = m ? sigma_raw[b] : (half_t)0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float x = (float)hc[(size_t)b * stride + c];
+        color[(size_t)b * 3 + c] = m ? narrow(1.0f / (1.0f + expf(-x))) : (half_t)0.0f;
+    }
+}
+
 }  // namespace
 }  // namespace nerftex
 
 using namespace nerftex;
+
+extern "C" int nerftex_curved_pack_inputs(const void* x_embed, const float* z_embed, uint32_t B, void* out, void* stream) {
+    clear_error();
+    if (B == 0) return NERFTEX_OK;
+    hipStream_t st = as_stream(stream);
+    {
+        KernelTimer kt("curved_pack_inputs_kernel", st);
+        hipLaunchKernelGGL(curved_pack_inputs_kernel, dim3(div_up(B, 256u)), dim3(256), 0, st, static_cast<const half_t*>(x_embed), z_embed, B, static_cast<half_t*>(out));
+    }
+    return check_launch("curved_pack_inputs");
+}
+
+extern "C" int nerftex_curved_mid_forward(const void* h, const float* normal, const float* dirs, uint32_t B, float fc_weight, int eval, void* sigma, void* cin,
+                                          void* stream) {
+    clear_error();
+    if (B == 0) return NERFTEX_OK;
+    hipStream_t st = as_stream(stream);
+    {
+        KernelTimer kt("curved_mid_forward_kernel", st);
+        hipLaunchKernelGGL(curved_mid_forward_kernel, dim3(div_up(B, 256u)), dim3(256), 0, st, static_cast<const half_t*>(h), normal, dirs, B, fc_weight, eval,
+                           static_cast<half_t*>(sigma), static_cast<half_t*>(cin));
+    }
+    return check_launch("curved_mid_forward");
+}
+
+extern "C" int nerftex_curved_out_forward(const void* hc, uint32_t row_stride, const void* sigma_raw, const uint8_t* mask, uint32_t B, void* sigma, void* color,
+                                          void* stream) {
+    clear_error();
+    if (B == 0) return NERFTEX_OK;
+    if (row_stride < 3) {
+        set_error("curved_out_forward: the colour rows hold at least 3 values");
+        return NERFTEX_ERR_INVALID;
+    }
+    hipStream_t st = as_stream(stream);
+    {
+        KernelTimer kt("curved_out_forward_kernel", st);
+        hipLaunchKernelGGL(curved_out_forward_kernel, dim3(div_up(B, 256u)), dim3(256), 0, st, static_cast<const half_t*>(hc), row_stride,
+                           static_cast<const half_t*>(sigma_raw), mask, B, static_cast<half_t*>(sigma), static_cast<half_t*>(color));
+    }
+    return check_launch("curved_out_forward");
+}
 
 extern "C" int nerftex_field_mid_forward(const void* h, const float* dirs, uint32_t B, float* sigma, void* cin, void* stream) {
     clear_error();

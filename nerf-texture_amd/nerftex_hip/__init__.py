@@ -43,6 +43,9 @@ _SIGNATURES = {
     "nerftex_field_forward_rows": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "nerftex_grid_encode_forward_rows": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _u32, _vp],
     "nerftex_field_mid_forward": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "nerftex_curved_pack_inputs": [_vp, _vp, _u32, _vp, _vp],
+    "nerftex_curved_mid_forward": [_vp, _vp, _vp, _u32, _f32, _i, _vp, _vp, _vp],
+    "nerftex_curved_out_forward": [_vp, _u32, _vp, _vp, _u32, _vp, _vp, _vp],
     "nerftex_field_mid_backward": [_vp, _vp, _vp, _u32, _vp, _vp],
     "nerftex_field_out_forward": [_vp, _u32, _vp, _vp],
     "nerftex_field_out_backward": [_vp, _vp, _u32, _vp, _vp],

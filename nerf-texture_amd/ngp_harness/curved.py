@@ -362,6 +362,78 @@ class _TruncExp(torch.autograd.Function):  # tools/activation.py:5-17
         return g * torch.exp(x.clamp(-15, 15))
 
 
+class _CurvedPack(torch.autograd.Function):
+    """[x_embed | half(z_embed) | ones] -- the sigma net's padded input (tools/map.py:641 `torch.cat` + tcnn's padding with ones) as one launch."""
+
+    @staticmethod
+    def forward(ctx, x_embed, z_embed):
+        from nerftex_hip import check, lib, ptr, stream
+
+        x_embed, z_embed = x_embed.contiguous(), z_embed.contiguous()
+        out = torch.empty(x_embed.shape[0], 48, dtype=torch.float16, device=x_embed.device)
+        check(lib.nerftex_curved_pack_inputs(ptr(x_embed), ptr(z_embed), x_embed.shape[0], ptr(out), stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :16].contiguous(), None
+
+
+class _CurvedMid(torch.autograd.Function):
+    """sigma net output h -> (sigma = trunc_exp(h[:, 0]), the colour net's input [SH4(reflected view direction) | h[:, 1:16] | 1]): the ~20 framework ops
+    of network_curvedfield.py:283-306 as one launch; the backward is the ngp field's (nerftex_field_mid_backward: trunc_exp's derivative + the slice)."""
+
+    @staticmethod
+    def forward(ctx, h, normal, dirs, fc_weight, eval_mode):
+        from nerftex_hip import check, lib, ptr, stream
+
+        h, normal, dirs = h.contiguous(), normal.contiguous().float(), dirs.contiguous().float()
+        B = h.shape[0]
+        sigma = torch.empty(B, dtype=torch.float16, device=h.device)
+        cin = torch.empty(B, 32, dtype=torch.float16, device=h.device)
+        check(lib.nerftex_curved_mid_forward(ptr(h), ptr(normal), ptr(dirs), B, float(fc_weight), int(bool(eval_mode)), ptr(sigma), ptr(cin), stream()))
+        ctx.save_for_backward(h)
+        ctx.set_materialize_grads(False)
+        return sigma, cin
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_cin):
+        from nerftex_hip import check, lib, ptr, stream
+
+        (h,) = ctx.saved_tensors
+        B = h.shape[0]
+        g_sigma = torch.zeros(B, dtype=torch.float32, device=h.device) if g_sigma is None else g_sigma.contiguous().float()
+        g_cin = torch.zeros(B, 32, dtype=torch.float16, device=h.device) if g_cin is None else g_cin.contiguous().half()
+        g_h = torch.empty_like(h)
+        check(lib.nerftex_field_mid_backward(ptr(g_sigma), ptr(g_cin), ptr(h), B, ptr(g_h), stream()))
+        return g_h, None, None, None, None
+
+
+class _CurvedOut(torch.autograd.Function):
+    """(colour net output, sigma, h_mask) -> (masked sigma, masked sigmoid colour): sigmoid + two zeros_like + two where as one launch."""
+
+    @staticmethod
+    def forward(ctx, hc, sigma_raw, mask):
+        from nerftex_hip import check, lib, ptr, stream
+
+        assert hc.dtype == torch.float16 and hc.shape[1] == 3 and hc.stride(1) == 1
+        B = hc.shape[0]
+        sigma_raw, mask_b = sigma_raw.contiguous(), mask.contiguous().view(torch.uint8)
+        sigma = torch.empty(B, dtype=torch.float16, device=hc.device)
+        color = torch.empty(B, 3, dtype=torch.float16, device=hc.device)
+        check(lib.nerftex_curved_out_forward(ptr(hc), int(hc.stride(0)), ptr(sigma_raw), ptr(mask_b), B, ptr(sigma), ptr(color), stream()))
+        ctx.save_for_backward(color, mask)
+        ctx.set_materialize_grads(False)
+        return sigma, color
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_color):
+        color, mask = ctx.saved_tensors
+        g_raw = None if g_sigma is None else torch.where(mask, g_sigma, torch.zeros_like(g_sigma))
+        g_hc = None if g_color is None else (g_color * (1 - color)) * color  # (0 where masked: the colour is 0 there)
+        return g_hc, g_raw, None
+
+
 class CurvedField(torch.nn.Module):
     """The curved-field network with the static light model (see the module docstring), over a MeshProjector.
 
@@ -466,7 +538,21 @@ class CurvedField(torch.nn.Module):
         h_mask = torch.logical_and(h_mask, torch.logical_not(normal_grad.isnan()).all(dim=-1))
         return sigma, normal_grad, h_mask
 
+    def _glue_fused(self, x_dtype_ok=True):
+        """The three glue launches (csrc/fieldglue.hip, round 6) serve the default shapes under fp16 autocast without the probabilistic table."""
+        return (getattr(self, "fused_glue", True) and self.encoder_var is None and self.in_dim == 41 and self.in_pad == 48 and self.color_pad == 32
+                and self.geo_feat_dim == 15 and self.encoder_dir.output_dim == 16 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16)
+
     def forward(self, x, d, **kwargs):
+        if self._glue_fused():
+            p_sur, sdf, h_mask, normal, local_tbn, _, z_embed = self.projector.project_fused(x, multires=self.multires)
+            x_embed = self.encoder(p_sur, bound=self.bound)
+            if x_embed.dtype == torch.float16 and z_embed.dtype == torch.float32:
+                h = self.sigma_net(_CurvedPack.apply(x_embed, z_embed))
+                normal = normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)  # tools/map.py:720 (MeshFeatureField's normal_coarse)
+                sigma_raw, cin = _CurvedMid.apply(h, normal, d, self.fc_weight, not self.training)
+                sigma, color = _CurvedOut.apply(self.color_net(cin), sigma_raw, h_mask)
+                return sigma, color, {}
         embed, normal_coarse, h_mask = self.embed(x)
         sigma, geo = self._sigma(embed)
         normal = normal_coarse / (normal_coarse.norm(dim=-1, keepdim=True) + 1e-5)  # network_curvedfield.py:283-285 (normal = normal_coarse)

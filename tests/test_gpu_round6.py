@@ -468,3 +468,43 @@ def test_curved_field_forward_as_one_graph_equals_the_eager_forward(dev):
         want_s, _, _ = field(x, d)
         got_s, _, _ = field.forward_graphed(x, d)
     assert field._fwd_graph["graph"] is not graph and torch.equal(got_s, want_s)
+
+
+def test_curved_field_glue_kernels_equal_the_framework_ops(dev):
+    """CurvedField.forward with the three glue launches (nerftex_curved_pack_inputs / _mid_forward / _out_forward) against the same forward on framework ops
+    (fused_glue = False: network_curvedfield.py:283-306 + tools/map.py:620-641 op by op): sigma, colour and the parameter gradients, eval and training."""
+    from ngp_harness.curved import CurvedField
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, p = np.load(os.path.join(golden, "ref_python_curvedfield.npz")), np.load(os.path.join(golden, "ref_python_projector.npz"))
+    field = CurvedField(p["vertices"], p["faces"], bound=1.0, h_threshold=float(p["h_threshold"]), vertex_normals=p["vertex_normals"], tbn=p["tbn"])
+    gen = torch.Generator().manual_seed(int(g["table_seed"]))
+    with torch.no_grad():
+        field.encoder.embeddings.copy_(torch.rand(field.encoder.embeddings.shape, generator=gen) - 0.5)
+        field.sigma_net.weights.copy_(torch.from_numpy(g["w_sigma"]))
+        field.color_net.weights.copy_(torch.from_numpy(g["w_color"]))
+    field = field.to(dev)
+    x, d = torch.from_numpy(g["xyz"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)
+    gs = torch.randn(x.shape[0], generator=gen).to(dev) * 1e-2
+    gc = torch.randn(x.shape[0], 3, generator=gen).to(dev) * 1e-2
+    out = {}
+    for mode in ("eval", "train"):
+        field.train(mode == "train")
+        for fused in (False, True):
+            field.fused_glue = fused
+            for q in field.parameters():
+                q.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigma, color, _ = field(x, d)
+                if mode == "train":
+                    torch.autograd.backward([sigma, color], [gs.to(sigma.dtype), gc.to(color.dtype)])
+            out[(mode, fused)] = (sigma.detach().float(), color.detach().float(), [q.grad.detach().float().clone() for q in field.parameters() if q.grad is not None])
+        a, b = out[(mode, False)], out[(mode, True)]
+        assert a[0].dtype == b[0].dtype and float(a[0].abs().max()) > 0
+        # one half-ulp: a normalisation's sum order, the fp32 exp that trunc_exp's derivative is taken from
+        assert float(((a[0] - b[0]).abs() / (a[0].abs() + 1e-3)).max()) <= 2e-3, mode
+        assert float((a[1] - b[1]).abs().max()) <= 2e-3, mode
+        assert torch.equal(a[0] == 0, b[0] == 0), "the same samples are masked"
+        for ga, gb in zip(a[2], b[2]):
+            assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max()) + 1e-7, mode
+    assert len(out[("train", True)][2]) == 3
