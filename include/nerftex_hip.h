@@ -626,8 +626,9 @@ int nerftex_field_out_forward(const void* hc, uint32_t B, float* rgbs, void* str
 /* Extension (round 6): the same kind of glue for the CURVED field (network_curvedfield.py:283-306 around tools/map.py:620-641's MeshFeatureField):
  *   nerftex_curved_pack_inputs   x_embed [B,16] half, z_embed [B,25] fp32 -> [B,48] half = [x_embed | half(z_embed) | 1 x 7] (the sigma net's padded input)
  *   nerftex_curved_mid_forward   h [B,16] half, normal [B,3] fp32, dirs [B,3] fp32 -> sigma [B] half = exp(h[:,0]) (trunc_exp),
- *                                cin [B,32] half = [SH4 of the view direction reflected about the normal | h[:,1:16] | 1]; eval != 0: the
- *                                fc_weight blend + renormalisation of :289-291
+ *                                cin [B,32] half = [SH4 of the view direction reflected about the normal | h[:,1:16] | 1]; eval bit 0: the
+ *                                fc_weight blend + renormalisation of :289-291; bit 1: `normal` is the projector's raw normal and is normalised
+ *                                first as MeshFeatureField does (tools/map.py:720)
  *   nerftex_curved_out_forward   hc rows of row_stride halfs, sigma_raw [B] half, mask [B] bytes -> sigma = mask ? sigma_raw : 0,
  *                                color [B,3] half = mask ? sigmoid(hc[:, :3]) : 0
  * Forward only: their backward passes are slices / the sigmoid derivative (nerftex_field_mid_backward serves the middle one).               */

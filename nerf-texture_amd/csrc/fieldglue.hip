@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void curved_pack_inputs_kernel(const half_t* _
     for (int i = 0; i < 6; i++) dst[i] = o[i];
 }
 
-// h [B,16] half (the sigma net's output), normal [B,3] fp32 (MeshFeatureField's normalised coarse normal), dirs [B,3] fp32
+// h [B,16] half (the sigma net's output), normal [B,3] fp32 (MeshFeatureField's normalised coarse normal; eval bit 1: the projector's RAW normal), dirs [B,3] fp32
 //   -> sigma [B] half = half(exp(h[:,0]))  (trunc_exp forward, tools/activation.py:5-17, on a half tensor)
 //      cin [B,32] half = [SH4(2 ((wr + 1) / 2) - 1) | h[:,1:16] | 1],  wr = the view direction reflected about the normal (:283-306)
 __global__ __launch_bounds__(256) void curved_mid_forward_kernel(const half_t* __restrict__ h, const float* __restrict__ normal, const float* __restrict__ dirs,
@@ -147,8 +147,9 @@ __global__ __launch_bounds__(256) void curved_mid_forward_kernel(const half_t* _
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = v[c] / len;
     };
+    if (eval & 2) unit(n);  // bit 1: `normal` is the projector's raw normal -- MeshFeatureField's own normalisation (tools/map.py:720) first
     unit(n);
-    if (eval) {  // :289-291 with the coarse normal on both sides
+    if (eval & 1) {  // :289-291 with the coarse normal on both sides
 #pragma unroll
         for (int c = 0; c < 3; c++) n[c] = fc * n[c] + (1 - fc) * n[c];
         unit(n);

@@ -391,7 +391,7 @@ class _CurvedMid(torch.autograd.Function):
         B = h.shape[0]
         sigma = torch.empty(B, dtype=torch.float16, device=h.device)
         cin = torch.empty(B, 32, dtype=torch.float16, device=h.device)
-        check(lib.nerftex_curved_mid_forward(ptr(h), ptr(normal), ptr(dirs), B, float(fc_weight), int(bool(eval_mode)), ptr(sigma), ptr(cin), stream()))
+        check(lib.nerftex_curved_mid_forward(ptr(h), ptr(normal), ptr(dirs), B, float(fc_weight), int(eval_mode), ptr(sigma), ptr(cin), stream()))
         ctx.save_for_backward(h)
         ctx.set_materialize_grads(False)
         return sigma, cin
@@ -549,8 +549,8 @@ class CurvedField(torch.nn.Module):
             x_embed = self.encoder(p_sur, bound=self.bound)
             if x_embed.dtype == torch.float16 and z_embed.dtype == torch.float32:
                 h = self.sigma_net(_CurvedPack.apply(x_embed, z_embed))
-                normal = normal / (normal.norm(dim=-1, keepdim=True) + 1e-5)  # tools/map.py:720 (MeshFeatureField's normal_coarse)
-                sigma_raw, cin = _CurvedMid.apply(h, normal, d, self.fc_weight, not self.training)
+                # (mode bit 1: the kernel also does MeshFeatureField's own normalisation of the projector's normal, tools/map.py:720)
+                sigma_raw, cin = _CurvedMid.apply(h, normal, d, self.fc_weight, 2 | int(not self.training))
                 sigma, color = _CurvedOut.apply(self.color_net(cin), sigma_raw, h_mask)
                 return sigma, color, {}
         embed, normal_coarse, h_mask = self.embed(x)
