@@ -101,6 +101,8 @@ def parse():
                     "the table with the streaming Adam launch (rounds 1-5) instead of applying Adam from the summing kernel's tiles (round 6)")
     ap.add_argument("--no-skip-dead-samples", action="store_true", help="walk every 32-sample step in the MLP / hash-grid backward instead of the steps the compositing "
                     "backward flagged as carrying a gradient (round 6; no difference on the headline's young field, see other_config 'trained state')")
+    ap.add_argument("--no-fused-composite-step", action="store_true", help="compositing forward, render tail and their backward as the three launches of rounds 3-5 "
+                    "instead of one (round 6: the forward's launch forms the loss gradient itself; same outputs and gradients bit for bit)")
     ap.add_argument("--trained-steps", type=int, default=1008, help="training steps against rendered targets of the analytic scene before the 'trained state' entry "
                     "of other_config is timed (0 = skip it)")
     ap.add_argument("--no-occupancy-timing", action="store_true", help="skip timing the every-16-steps occupancy-grid update (reported separately, SURVEY 8(d))")
@@ -304,6 +306,8 @@ def measure_training(args, mlp, rays, steps, warmup, dev, rank, world, sc, grid,
     # gradients of ~1e-6 sit in fp16's subnormal range (measured: 38 % L1 error of the table gradient without scaling, tools/precision_table.py)
     scaler = None if fused_amp else torch.amp.GradScaler("cuda", enabled=dtype in ("fp16", "bf16"))
     one = torch.ones((), dtype=torch.float32, device=dev)  # root gradient, so that autograd does not fill one per step
+    renderer.root_one = one if (fused_amp and not args.no_fused_composite_step) else None  # (round 6; as accelerate() does: compositing + tail + backward = one launch)
+    renderer.defer_step_loss = renderer.root_one is not None  # (... and the loss finished by the field's backward: nobody reads it before)
 
     def march(ro, rd, **kw):
         with torch.autocast("cuda", dtype=amp_dtype, enabled=use_amp):
@@ -716,7 +720,7 @@ def _replay_child_cmd(args, mlp, rays, dtype, steps):
            "--dtype", dtype, "--bound", str(args.bound), "--steps-per-graph", str(args.steps_per_graph), "--no-cpu-baseline", "--no-other", "--no-infer",
            "--no-kernel-timing", "--baked-pool", "--no-occupancy-timing"]
     for flag in ("no_fused_glue", "no_fused_tail", "no_fused_opt", "no_fused_amp", "no_lean_march", "no_march_ahead", "no_perturb", "no_fused_table_update",
-                 "no_skip_dead_samples"):
+                 "no_skip_dead_samples", "no_fused_composite_step"):
         if getattr(args, flag, False):
             cmd.append("--" + flag.replace("_", "-"))
     return cmd
@@ -869,7 +873,7 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     field.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
     renderer = Renderer(field, bound=args.bound, min_near=0.2, density_thresh=10.0).to(dev)
     renderer.set_occupancy(torch.from_numpy(grid).to(dev))
-    n_pool = 8
+    n_pool = max(8, group)
     pool = []
     for k in range(n_pool):
         o, d = scene.train_batch(rays, seed=100 + k, n_views=4)
@@ -881,7 +885,8 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     trainer = accelerate(renderer, dt_gamma=1 / 128, steps_per_call=group, march_across_ring_end=group > 1, amp_dtype=amp_dt,
                          pipeline_adam=getattr(args, "pipeline_adam", 0),
                          fused_table_update=False if getattr(args, "no_fused_table_update", False) else fused_table_update,
-                         skip_dead_samples=False if getattr(args, "no_skip_dead_samples", False) else None)
+                         skip_dead_samples=False if getattr(args, "no_skip_dead_samples", False) else None,
+                         fused_composite_step=False if getattr(args, "no_fused_composite_step", False) else None)
     if group > 1:
         assert n_pool % group == 0 and steps % group == 0
         po = [torch.stack([pool[c * group + i][0] for i in range(group)]).contiguous() for c in range(n_pool // group)]
@@ -1031,15 +1036,17 @@ def measure_trained_state(args, dev, sc, grid, rays=8192, train_steps=1008, time
         trainer.use_graph = False
         nerftex_hip.lib.nerftex_profile_reset()
         nerftex_hip.lib.nerftex_profile_enable(1)
+        renderer.keep_step_live = True  # (the one-launch compositing hands its flags to the backward that zeroes them: keep a copy of the last step's to count)
         for _ in range(8 // k):
             call(c, ahead=False)
             c += 1
         torch.cuda.synchronize()
+        renderer.keep_step_live = False
         prof = nerftex_hip.kernel_profile()
         nerftex_hip.lib.nerftex_profile_enable(0)
         trainer.use_graph = trainer_eager
         want = ("field_color_backward_kernel", "field_sigma_backward_kernel", "bin_fill_dir_kernel", "sum_tiles_adam_kernel", "sum_tiles_dir_kernel", "combine_tiles_kernel",
-                "composite_tail_bwd_kernel", "grid_forward_level_kernel", "field_forward_train_kernel")
+                "composite_tail_bwd_kernel", "composite_step_kernel", "composite_step_loss_kernel", "grid_forward_level_kernel", "field_forward_train_kernel")
         kern = {n: round(prof[n]["avg_us"], 1) for n in want if n in prof}
         mlp_bwd = sum(v for n, v in kern.items() if n.startswith("field_") and "backward" in n)
         return {"ms_per_step": dt / timed_steps * 1e3, "value": sum(rings) / dt if rings else None, "samples_per_step": (sum(rings) / (len(rings) * 16)) if rings else None,

@@ -345,6 +345,27 @@ int nerftex_field_backward_live_bf16(const float* grad_sigma, const float* grad_
                                      const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                                      void* grad_x, void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live, float* found_inf,
                                      void* stream);
+/* ... and the same as the LAST stage of a step's loss side: CONSUMING the flags -- when the call's launches have run, step_live[0 .. B / 32) is zero
+ * again (the weight-gradient reduction clears what the two backward kernels have walked) -- and, with `loss`, finishing the step's loss: one extra
+ * workgroup of that reduction launch adds the rays' squared errors nerftex_composite_step left in err[] (called with loss = NULL) in
+ * nerftex_render_tail_forward's order -- off the step's critical path, where a launch of its own costs 5 us.  The counterpart of
+ * nerftex_composite_step, which sets flags and has no launch before it to clear them.  step_live NULL: the plain backward; loss NULL: none.        */
+typedef struct nerftex_step_loss {
+    const float* err;    /* [n_rays] squared error per ray (nerftex_composite_step) */
+    uint32_t n_rays;     /* 1 .. 262144 */
+    float loss_mul;
+    const float* scale;  /* device float or NULL */
+    float* loss;         /* [1] out: mean squared error * loss_mul */
+    float* scaled_loss;  /* [1] out or NULL: loss * *scale */
+} nerftex_step_loss;
+int nerftex_field_backward_live_consume(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                        const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                        void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                        const nerftex_step_loss* loss, float* found_inf, void* stream);
+int nerftex_field_backward_live_consume_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                             const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                             void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                             const nerftex_step_loss* loss, float* found_inf, void* stream);
 /* ... and the two no-grad forms of the bf16 field: the density query of the occupancy-grid update (nerftex_field_density) and the inference
  * iteration sized by a device count (nerftex_field_forward_rows, declared below), weights bf16, feats_lbc fp16, outputs fp32.  Same values as
  * nerftex_field_forward_bf16's sigma / (sigma, rgbs) on the rows they compute. */
@@ -679,6 +700,22 @@ int nerftex_composite_tail_backward_live(const float* grad_loss, const float* sc
                                          float bg, const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                          const float* weights_sum, const float* image, uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs,
                                          uint32_t* step_live, void* stream);
+
+/* Extension (round 6): the compositing of a TRAINING STEP as one launch -- nerftex_composite_rays_train_forward, nerftex_render_tail_forward and
+ * nerftex_composite_tail_backward (raymarching.cu:739-767 + :843-880 with nerf/renderer.py:417-425 and the MSE between them): the wave that walks a
+ * ray forward keeps what the backward walk needs in registers, forms the blend, the depth normalisation, the squared error and the loss gradient
+ * when the ray's sums are complete, and writes grad_sigmas / grad_rgbs.  All outputs of the three calls, bit for bit: weights_sum, depth [N],
+ * image [N,3] (raw), image_out [N,3], depth_out [N], loss and scaled_loss (= loss * *scale; scale NULL: = loss) [1], and grad_sigmas [M],
+ * grad_rgbs [M,3] = the gradient of scaled_loss for a ROOT GRADIENT OF ONE (any other: nerftex_composite_tail_backward with the outputs of this
+ * call).  The gradient buffers need not be zero-filled (as for nerftex_composite_tail_backward: this library's ordered ray records).  err [N]:
+ * scratch (the rays' squared errors; a second, one-workgroup launch adds them in nerftex_render_tail_forward's order).  step_live: NULL or
+ * ceil(M / 32) words that are ZERO ON ENTRY -- set as nerftex_composite_tail_backward_live sets them; nerftex_field_backward_live_consume
+ * zeroes them again.  loss NULL: the second launch is not made (err[] goes to nerftex_field_backward_live_consume's nerftex_step_loss).
+ * N <= 262144, N > 0, M > 0.                                                                                          */
+int nerftex_composite_step(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
+                           const float* nears, const float* fars, const float* target, float bg, float loss_mul, const float* scale,
+                           float* weights_sum, float* depth, float* image, float* image_out, float* depth_out, float* err, float* loss,
+                           float* scaled_loss, float* grad_sigmas, float* grad_rgbs, uint32_t* step_live, void* stream);
 
 /* One Adam step (main_nerf.py:128: betas (0.9, 0.99), eps 1e-15, no weight decay) of an fp32 master table from the
  * fp16 gradient the encoder backward produced, writing the fp16 copy the next forward reads: param, exp_avg,

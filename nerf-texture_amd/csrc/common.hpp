@@ -69,6 +69,7 @@ enum Knob {
     kKnobMarchLean,      // 1: the training march's count pass compiled for 64 registers (spills; slower alone, a better neighbour on a shared CU)
     kKnobFfmlpBwdTr,     // 1: fused MLP backward builds its weight-gradient operands with ds_read_b64_tr_b16 instead of selection-matrix MFMAs (slower: A/B)
     kKnobGridBwdStage,   // binning: LDS record slots per fill workgroup (0 = default; the rest of a workgroup's block goes straight to memory)
+    kKnobCompositeKeep,  // composite_step_kernel: 64-sample chunks a wave keeps in registers between its forward and backward walk (1..4; 0 = default 2)
     kKnobCount
 };
 extern long g_knobs[kKnobCount];

@@ -26,6 +26,7 @@
 // with >= 6) the forward / inference / dgrad kernels stage ONE layer at a time between two barriers (round 5: the
 // STREAM forms), as the reference's threadblock_layer reads each layer from global memory (ffmlp.cu:47-129).
 #include "common.hpp"
+#include "step_loss.hpp"
 #include "sh_common.hpp"  // the SH basis of the fused field kernel (switches fp contraction off for what follows ...)
 #include "workspace.hpp"
 
@@ -98,6 +99,16 @@ extern "C" int nerftex_field_backward_live(const float* grad_sigma, const float*
                                            void* grad_sigma_weights, void* grad_color_weights, const uint32_t* step_live, float* found_inf, void* stream) {
     return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                            grad_sigma_weights, grad_color_weights, found_inf, stream, step_live);
+}
+// ... and leaves the flags ZERO again (the weight-gradient reduction launch clears the words the two kernels have walked): the protocol of
+// nerftex_composite_step, which sets flags and has no launch before it to clear them
+extern "C" int nerftex_field_backward_live_consume(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                                   const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                                   void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                                   const nerftex_step_loss* loss, float* found_inf, void* stream) {
+    const nerftex::StepLossJob job = loss ? nerftex::StepLossJob{loss->err, loss->n_rays, loss->loss_mul, loss->scale, loss->loss, loss->scaled_loss} : nerftex::StepLossJob{};
+    return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                           grad_sigma_weights, grad_color_weights, found_inf, stream, step_live, true, loss ? &job : nullptr);
 }
 extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
                                           float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {

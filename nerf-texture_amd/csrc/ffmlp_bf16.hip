@@ -2,6 +2,7 @@
 // names bf16.  Same exponent range as fp32, 8 significand bits instead of 11; fp32 accumulation on the matrix cores.  A translation unit of its
 // own since round 5 (build time: the two instantiations compile side by side).
 #include "common.hpp"
+#include "step_loss.hpp"
 #include "sh_common.hpp"  // the SH basis of the fused field kernel (switches fp contraction off for what follows ...)
 #include "workspace.hpp"
 
@@ -60,6 +61,14 @@ extern "C" int nerftex_field_backward_live_bf16(const float* grad_sigma, const f
                                                 float* found_inf, void* stream) {
     return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                             grad_sigma_weights, grad_color_weights, found_inf, stream, step_live);
+}
+extern "C" int nerftex_field_backward_live_consume_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                                        const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B,
+                                                        void* grad_cin, void* grad_x, void* grad_sigma_weights, void* grad_color_weights,
+                                                        uint32_t* step_live, const nerftex_step_loss* loss, float* found_inf, void* stream) {
+    const nerftex::StepLossJob job = loss ? nerftex::StepLossJob{loss->err, loss->n_rays, loss->loss_mul, loss->scale, loss->loss, loss->scaled_loss} : nerftex::StepLossJob{};
+    return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                            grad_sigma_weights, grad_color_weights, found_inf, stream, step_live, true, loss ? &job : nullptr);
 }
 extern "C" int nerftex_field_density_bf16(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream) {
     return ffmlp_bf16::field_density_entry(feats_lbc, sigma_weights, B, sigma, stream);

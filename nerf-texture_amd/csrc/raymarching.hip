@@ -16,6 +16,7 @@
 //    the voxel coordinate keeps the reference's float->double->float promotion.  Per-ray step
 //    counts and sample positions are therefore bit-identical to the oracle.
 #include "common.hpp"
+#include "step_loss.hpp"
 #include "workspace.hpp"
 
 #include <cstdlib>
@@ -834,36 +835,78 @@ __global__ __launch_bounds__(kExpandThreads) void march_expand_kernel(const floa
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }  // v_exp_f32 path, as the reference's __expf
 
-// wave64 inclusive scans over lanes (sum / product)
+// wave64 inclusive scans over lanes (sum / product) on the DPP cross-lane paths of the VALU -- no LDS permute: rows of 16 lanes by row_shr 1, 2, 4, 8
+// (a lane without a source keeps the identity), then the row totals carried over by row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).
+// Six dependent VALU operations where the ds_bpermute form of rounds 1-5 made six LDS round trips (~100 clocks each): these kernels are bounded by
+// the latency of one wave's walk along its ray, and most of that walk was these scans (round 6: 12.4 -> @BWD us for the backward launch).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_from(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
 __device__ __forceinline__ float wave_scan_add(float v) {
-    const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const float o = __shfl_up(v, off, kWave);
-        if (lane >= off) v += o;
-    }
+    v += dpp_from<kDppRowShr + 1, 0xf>(0.0f, v);
+    v += dpp_from<kDppRowShr + 2, 0xf>(0.0f, v);
+    v += dpp_from<kDppRowShr + 4, 0xf>(0.0f, v);
+    v += dpp_from<kDppRowShr + 8, 0xf>(0.0f, v);
+    v += dpp_from<kDppBcast15, 0xa>(0.0f, v);
+    v += dpp_from<kDppBcast31, 0xc>(0.0f, v);
     return v;
 }
 __device__ __forceinline__ float wave_scan_mul(float v) {
-    const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const float o = __shfl_up(v, off, kWave);
-        if (lane >= off) v *= o;
-    }
+    v *= dpp_from<kDppRowShr + 1, 0xf>(1.0f, v);
+    v *= dpp_from<kDppRowShr + 2, 0xf>(1.0f, v);
+    v *= dpp_from<kDppRowShr + 4, 0xf>(1.0f, v);
+    v *= dpp_from<kDppRowShr + 8, 0xf>(1.0f, v);
+    v *= dpp_from<kDppBcast15, 0xa>(1.0f, v);
+    v *= dpp_from<kDppBcast31, 0xc>(1.0f, v);
     return v;
 }
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+__device__ __forceinline__ float wave_last(float v) {  // lane 63's value, in every lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kWave - 1));
 }
 
 // The reference walks each ray's samples serially in one thread (raymarching.cu:739-767 / :843-880): 4096 threads, each
 // striding through its own segment.  Here ONE WAVE takes a ray, its 64 lanes take 64 consecutive samples (coalesced
-// loads), transmittance T_i = prod_{j<i}(1 - alpha_j) comes from a multiplicative wave scan carried across chunks, the
-// running sums the backward needs from additive scans.  Same quantities, tree instead of serial summation order.
+// loads), transmittance T_i = prod_{j<i}(1 - alpha_j) comes from a multiplicative wave scan carried across chunks, every
+// running sum (colour, opacity, depth) from an additive one -- the ray's totals are the last lane's running sums, so the
+// forward and the backward launch form them the same way.  Same quantities, tree instead of serial summation order.
 constexpr uint32_t kCompBlock = 256;
+
+struct ChunkIn { float sg, d0, d1, c0, c1, c2; };  // one sample per lane (idle lanes: zeros)
+struct RayCarry { float T = 1.0f, t = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f, ws = 0.0f, d = 0.0f; };  // the walk's state at the start of a chunk
+struct ChunkOut { float weight, T, r, g, b, ws; };  // per sample: its weight, the transmittance AFTER it (the reference's post-update T, :855-868), the running sums including it
+template <bool DEPTH>
+__device__ __forceinline__ ChunkOut chunk_walk(const ChunkIn& in, RayCarry& c) {
+    const float alpha = 1.0f - fast_exp(-in.sg * in.d0);  // 0 for idle lanes
+    const float incl = wave_scan_mul(1.0f - alpha);
+    const float excl = dpp_from<kDppWaveShr1, 0xf>(1.0f, incl);  // (lane 0 has no source: the identity)
+    ChunkOut o;
+    o.weight = alpha * (c.T * excl);
+    o.T = c.T * incl;
+    o.r = c.r + wave_scan_add(o.weight * in.c0);
+    o.g = c.g + wave_scan_add(o.weight * in.c1);
+    o.b = c.b + wave_scan_add(o.weight * in.c2);
+    o.ws = c.ws + wave_scan_add(o.weight);
+    if constexpr (DEPTH) {
+        const float t = c.t + wave_scan_add(in.d1);
+        c.d = wave_last(c.d + wave_scan_add(o.weight * t));
+        c.t = wave_last(t);
+    }
+    c.T *= wave_last(incl);
+    c.r = wave_last(o.r); c.g = wave_last(o.g); c.b = wave_last(o.b); c.ws = wave_last(o.ws);
+    return o;
+}
+__device__ __forceinline__ ChunkIn load_chunk(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas, size_t i, bool on) {
+    ChunkIn in;
+    in.sg = on ? sigmas[i] : 0.0f;
+    in.d0 = on ? deltas[2 * i] : 0.0f;
+    in.d1 = on ? deltas[2 * i + 1] : 0.0f;
+    in.c0 = on ? rgbs[3 * i] : 0.0f;
+    in.c1 = on ? rgbs[3 * i + 1] : 0.0f;
+    in.c2 = on ? rgbs[3 * i + 2] : 0.0f;
+    return in;
+}
 
 // The backward half of the render tail (harness level, trainstep.hip: nerf/renderer.py:417-425 + the MSE of nerf/utils.py:602-640)
 // riding on the compositing backward: the wave about to walk a ray backwards first forms the gradient of the mean squared error with
@@ -889,43 +932,79 @@ __global__ __launch_bounds__(kCompBlock) void composite_train_fwd_kernel(const f
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
                    num_steps = (uint32_t)rays[3 * (size_t)n + 2];
-    if (num_steps == 0 || offset + num_steps >= M) {
-        if (lane == 0) {
-            weights_sum[index] = 0;
-            depth[index] = 0;
-            image[3 * (size_t)index] = 0; image[3 * (size_t)index + 1] = 0; image[3 * (size_t)index + 2] = 0;
+    RayCarry c;  // (a ray without samples, or cut off by the budget: zeros)
+    if (num_steps != 0 && offset + num_steps < M)
+        for (uint32_t c0 = 0; c0 < num_steps; c0 += kWave) {
+            const uint32_t k = c0 + lane;
+            chunk_walk<true>(load_chunk(sigmas, rgbs, deltas, (size_t)offset + k, k < num_steps), c);
         }
-        return;
-    }
-    float T_carry = 1.0f, t_carry = 0.0f;
-    float r = 0, g = 0, b = 0, ws = 0, d = 0;
-    for (uint32_t c0 = 0; c0 < num_steps; c0 += kWave) {
-        const uint32_t k = c0 + lane;
-        const bool on = k < num_steps;
-        const size_t i = (size_t)offset + k;
-        const float sg = on ? sigmas[i] : 0.0f;
-        const float d0 = on ? deltas[2 * i] : 0.0f, d1 = on ? deltas[2 * i + 1] : 0.0f;
-        const float alpha = 1.0f - fast_exp(-sg * d0);  // 0 for idle lanes
-        const float incl = wave_scan_mul(1.0f - alpha);
-        float excl = __shfl_up(incl, 1, kWave);
-        if (lane == 0) excl = 1.0f;
-        const float weight = alpha * (T_carry * excl);
-        const float t = t_carry + wave_scan_add(d1);
-        if (on) {
-            r = fmaf(weight, rgbs[3 * i], r);
-            g = fmaf(weight, rgbs[3 * i + 1], g);
-            b = fmaf(weight, rgbs[3 * i + 2], b);
-            d = fmaf(weight, t, d);
-            ws += weight;
-        }
-        T_carry *= __shfl(incl, kWave - 1, kWave);
-        t_carry = __shfl(t, kWave - 1, kWave);
-    }
-    r = wave_sum_f(r); g = wave_sum_f(g); b = wave_sum_f(b); ws = wave_sum_f(ws); d = wave_sum_f(d);
     if (lane == 0) {
-        weights_sum[index] = ws;
-        depth[index] = d;
-        image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+        weights_sum[index] = c.ws;
+        depth[index] = c.d;
+        image[3 * (size_t)index] = c.r; image[3 * (size_t)index + 1] = c.g; image[3 * (size_t)index + 2] = c.b;
+    }
+}
+
+// rows no ray covers get zero gradients from the launch itself (the callers of the TAIL forms hand over UNINITIALISED buffers): with this
+// library's ordered records (record n = ray n, offsets = exclusive prefix sums) those rows are [total, M) -- every wave takes a slice -- or,
+// when the budget cut rays off (raymarching.cu:418-419), [offset of the first cut ray, M).
+__device__ __forceinline__ void zero_uncovered_rows(const int* __restrict__ rays, uint32_t n, uint32_t lane, uint32_t offset, uint32_t num_steps, uint32_t M,
+                                                    uint32_t N, float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    const uint32_t total = (uint32_t)rays[3 * (size_t)(N - 1) + 1] + (uint32_t)rays[3 * (size_t)(N - 1) + 2];
+    uint32_t z0 = M, z1 = M;
+    if (total < M) {
+        const uint32_t per = (M - total + N - 1) / N;
+        z0 = total + n * per < M ? total + n * per : M;
+        z1 = z0 + per < M ? z0 + per : M;
+    } else if (num_steps != 0 && offset < M && offset + num_steps >= M) {
+        z0 = offset;
+    }
+    for (size_t i = (size_t)4 * z0 + lane; i < (size_t)4 * z1; i += kWave) {  // 4 floats per row: 1 of grad_sigmas, 3 of grad_rgbs
+        const size_t row = i >> 2, c = i & 3;
+        if (c == 0) grad_sigmas[row] = 0.0f;
+        else grad_rgbs[3 * row + c - 1] = 0.0f;
+    }
+}
+
+// the gradient of the mean squared error with respect to a ray's raw image and opacity sum (render_tail_backward_kernel's expressions)
+struct RayGrad { float gi0, gi1, gi2, gws; };
+__device__ __forceinline__ RayGrad ray_loss_gradient(float norm, float gl, float bg, const float* out, const float* tgt) {
+    RayGrad q;
+    q.gi0 = norm * (out[0] - tgt[0]) * gl;
+    q.gi1 = norm * (out[1] - tgt[1]) * gl;
+    q.gi2 = norm * (out[2] - tgt[2]) * gl;
+    float sum = 0.0f;
+    sum += q.gi0; sum += q.gi1; sum += q.gi2;
+    q.gws = -(sum * bg);
+    return q;
+}
+
+// one sample's gradients (raymarching.cu:855-870) + its step flag: the first live lane of a 32-sample step (the lanes of one step are consecutive
+// inside the 64-sample window that starts at row `window0`) sets the step's word
+__device__ __forceinline__ void sample_backward(bool on, size_t i, uint32_t window0, uint32_t lane, float d0, const ChunkOut& o, float c0r, float c1g, float c2b,
+                                                const RayGrad& q, const RayCarry& fin, float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs,
+                                                uint32_t* __restrict__ step_live) {
+    bool live = false;
+    if (on) {
+        const float g0w = q.gi0 * o.weight, g1w = q.gi1 * o.weight, g2w = q.gi2 * o.weight;
+        grad_rgbs[3 * i] = g0w;
+        grad_rgbs[3 * i + 1] = g1w;
+        grad_rgbs[3 * i + 2] = g2w;
+        float acc = q.gi0 * fmaf(o.T, c0r, -(fin.r - o.r));
+        acc = fmaf(q.gi1, fmaf(o.T, c1g, -(fin.g - o.g)), acc);
+        acc = fmaf(q.gi2, fmaf(o.T, c2b, -(fin.b - o.b)), acc);
+        acc = fmaf(q.gws, o.T - (fin.ws - o.ws), acc);
+        const float gs = d0 * acc;
+        grad_sigmas[i] = gs;
+        live = !(gs == 0.0f && g0w == 0.0f && g1w == 0.0f && g2w == 0.0f);  // (+-0 are zeros; nan / inf are not)
+    }
+    if (step_live != nullptr) {
+        const unsigned long long mask = __ballot(live);
+        const uint32_t s = (uint32_t)(i >> 5);
+        const int lo = (int)(s << 5) - (int)window0;  // first lane of this lane's step inside the window (may be < 0)
+        const uint32_t first_lane = lo > 0 ? (uint32_t)lo : 0u;
+        const unsigned long long before = (mask >> first_lane) & ((1ull << (lane - first_lane)) - 1ull);
+        if (live && before == 0ull) step_live[s] = 1u;
     }
 }
 
@@ -942,90 +1021,146 @@ __global__ __launch_bounds__(kCompBlock) void composite_train_bwd_kernel(const f
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
                    num_steps = (uint32_t)rays[3 * (size_t)n + 2];
-    if constexpr (TAIL) {
-        // The gradient buffers arrive UNINITIALISED here (the caller's zero fill is not made): the rows no ray covers are zeroed by this
-        // launch.  With this library's ordered records (record n = ray n, offsets = exclusive prefix sums) those rows are [total, M) --
-        // every wave takes a slice -- or, when the budget cut rays off (raymarching.cu:418-419), [offset of the first cut ray, M).
-        const uint32_t total = (uint32_t)rays[3 * (size_t)(N - 1) + 1] + (uint32_t)rays[3 * (size_t)(N - 1) + 2];
-        uint32_t z0 = M, z1 = M;
-        if (total < M) {
-            const uint32_t per = (M - total + N - 1) / N;
-            z0 = total + n * per < M ? total + n * per : M;
-            z1 = z0 + per < M ? z0 + per : M;
-        } else if (num_steps != 0 && offset < M && offset + num_steps >= M) {
-            z0 = offset;
-        }
-        for (size_t i = (size_t)4 * z0 + lane; i < (size_t)4 * z1; i += kWave) {  // 4 floats per row: 1 of grad_sigmas, 3 of grad_rgbs
-            const size_t row = i >> 2, c = i & 3;
-            if (c == 0) grad_sigmas[row] = 0.0f;
-            else grad_rgbs[3 * row + c - 1] = 0.0f;
-        }
-    }
+    if constexpr (TAIL) zero_uncovered_rows(rays, n, lane, offset, num_steps, M, N, grad_sigmas, grad_rgbs);
     if (num_steps == 0 || offset + num_steps >= M) return;
-    float gws, gi0, gi1, gi2;
+    RayGrad q;
     if constexpr (TAIL) {
         // grad_image = (2 / 3N) (image_out - target) g,  grad_ws = -(sum_c grad_image) bg   (render_tail_backward_kernel)
         const float gl = (tail.scale ? *tail.grad_loss * *tail.scale : *tail.grad_loss) * tail.loss_mul;
         const float norm = (float)(2.0 / (double)((size_t)N * 3));
-        gi0 = norm * (tail.image_out[(size_t)index * 3] - tail.target[(size_t)index * 3]) * gl;
-        gi1 = norm * (tail.image_out[(size_t)index * 3 + 1] - tail.target[(size_t)index * 3 + 1]) * gl;
-        gi2 = norm * (tail.image_out[(size_t)index * 3 + 2] - tail.target[(size_t)index * 3 + 2]) * gl;
-        float sum = 0.0f;
-        sum += gi0; sum += gi1; sum += gi2;
-        gws = -(sum * tail.bg);
+        const float out[3] = {tail.image_out[(size_t)index * 3], tail.image_out[(size_t)index * 3 + 1], tail.image_out[(size_t)index * 3 + 2]};
+        const float tgt[3] = {tail.target[(size_t)index * 3], tail.target[(size_t)index * 3 + 1], tail.target[(size_t)index * 3 + 2]};
+        q = ray_loss_gradient(norm, gl, tail.bg, out, tgt);
     } else {
-        gws = grad_weights_sum[index];
-        gi0 = grad_image[3 * (size_t)index]; gi1 = grad_image[3 * (size_t)index + 1]; gi2 = grad_image[3 * (size_t)index + 2];
+        q.gws = grad_weights_sum[index];
+        q.gi0 = grad_image[3 * (size_t)index]; q.gi1 = grad_image[3 * (size_t)index + 1]; q.gi2 = grad_image[3 * (size_t)index + 2];
     }
-    const float r_final = image[3 * (size_t)index], g_final = image[3 * (size_t)index + 1], b_final = image[3 * (size_t)index + 2];
-    const float ws_final = weights_sum[index];
-    float T_carry = 1.0f, r_c = 0, g_c = 0, b_c = 0, ws_c = 0;
+    RayCarry fin;  // the ray's totals, as the forward launch left them (= the last lane's running sums of this walk)
+    fin.r = image[3 * (size_t)index]; fin.g = image[3 * (size_t)index + 1]; fin.b = image[3 * (size_t)index + 2];
+    fin.ws = weights_sum[index];
+    RayCarry c;
     for (uint32_t c0 = 0; c0 < num_steps; c0 += kWave) {
         const uint32_t k = c0 + lane;
         const bool on = k < num_steps;
         const size_t i = (size_t)offset + k;
-        const float sg = on ? sigmas[i] : 0.0f;
-        const float d0 = on ? deltas[2 * i] : 0.0f;
-        const float c0r = on ? rgbs[3 * i] : 0.0f, c1g = on ? rgbs[3 * i + 1] : 0.0f, c2b = on ? rgbs[3 * i + 2] : 0.0f;
-        const float alpha = 1.0f - fast_exp(-sg * d0);
-        const float incl = wave_scan_mul(1.0f - alpha);
-        float excl = __shfl_up(incl, 1, kWave);
-        if (lane == 0) excl = 1.0f;
-        const float weight = alpha * (T_carry * excl);
-        const float T = T_carry * incl;  // transmittance AFTER this sample, as in the reference's post-update T (:855-868)
-        const float r = r_c + wave_scan_add(weight * c0r);
-        const float g = g_c + wave_scan_add(weight * c1g);
-        const float b = b_c + wave_scan_add(weight * c2b);
-        const float ws = ws_c + wave_scan_add(weight);
-        bool live = false;
-        if (on) {
-            const float g0w = gi0 * weight, g1w = gi1 * weight, g2w = gi2 * weight;
-            grad_rgbs[3 * i] = g0w;
-            grad_rgbs[3 * i + 1] = g1w;
-            grad_rgbs[3 * i + 2] = g2w;
-            float acc = gi0 * fmaf(T, c0r, -(r_final - r));
-            acc = fmaf(gi1, fmaf(T, c1g, -(g_final - g)), acc);
-            acc = fmaf(gi2, fmaf(T, c2b, -(b_final - b)), acc);
-            acc = fmaf(gws, T - (ws_final - ws), acc);
-            const float gs = d0 * acc;
-            grad_sigmas[i] = gs;
-            live = !(gs == 0.0f && g0w == 0.0f && g1w == 0.0f && g2w == 0.0f);  // (+-0 are zeros; nan / inf are not)
-        }
-        if constexpr (TAIL) {
-            if (tail.step_live != nullptr) {
-                // ballot + leader per 32-sample step: the first live lane of a step (the lanes of one step are consecutive) sets its word
-                const unsigned long long mask = __ballot(live);
-                const uint32_t s = (uint32_t)(i >> 5);
-                const int lo = (int)(s << 5) - (int)(offset + c0);  // first lane of this lane's step inside the 64-sample window (may be < 0)
-                const uint32_t first_lane = lo > 0 ? (uint32_t)lo : 0u;
-                const unsigned long long before = (mask >> first_lane) & ((1ull << (lane - first_lane)) - 1ull);
-                if (live && before == 0ull) tail.step_live[s] = 1u;
-            }
-        }
-        T_carry *= __shfl(incl, kWave - 1, kWave);
-        r_c = __shfl(r, kWave - 1, kWave); g_c = __shfl(g, kWave - 1, kWave); b_c = __shfl(b, kWave - 1, kWave);
-        ws_c = __shfl(ws, kWave - 1, kWave);
+        const ChunkIn in = load_chunk(sigmas, rgbs, deltas, i, on);
+        const ChunkOut o = chunk_walk<false>(in, c);
+        sample_backward(on, i, offset + c0, lane, in.d0, o, in.c0, in.c1, in.c2, q, fin, grad_sigmas, grad_rgbs, TAIL ? tail.step_live : nullptr);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the compositing of a TRAINING STEP as one launch.  composite_train_fwd_kernel, render_tail_forward_kernel and
+// composite_train_bwd_kernel<TAIL> are adjacent in a step's stream (nothing of the field runs between the loss and its gradient) and each is
+// bounded by the latency of one wave's walk along its ray, not by bytes: three launches = three ramps, three tails, and the backward reads
+// sigmas / rgbs / deltas a second time and redoes the walk.  Here the wave that walks a ray forward KEEPS what the backward needs (per
+// 64-sample chunk: weight, transmittance, the running sums, the colours -- ten registers a lane, the first KEEP chunks; longer rays walk
+// the rest again), forms the tail (blend, depth, squared error: render_tail_forward_kernel's arithmetic) and the loss gradient
+// (TailBackward's) as soon as the ray's totals are complete, and writes grad_sigmas / grad_rgbs from its registers.  The gradient is that of
+// `scaled_loss` for a root gradient of ONE (what loss.backward() sends): the caller falls back to nerftex_composite_tail_backward for any
+// other.  Same expressions in the same order as the three kernels: outputs and gradients are bit-identical to theirs
+// (tests/test_gpu_round6.py).  The loss: every ray leaves its squared error in err[]; composite_step_loss_kernel (one workgroup) adds them in
+// the order render_tail_forward_kernel's blocks + ticket would have (a ticket in this kernel costs every workgroup a device-scope release
+// with the gradient rows still dirty in its L2 -- the 20 us of the attempt noted above).
+// ------------------------------------------------------------------------------------------------
+struct StepTail {
+    const float *nears, *fars, *target, *scale;
+    float bg, loss_mul, norm;  // norm = (float)(2 / 3N): the MSE's gradient factor, formed on the host as TailBackward's kernel forms it
+    float *image_out, *depth_out, *err;
+    uint32_t* step_live;  // optional; ZERO on entry (nerftex_field_backward_live_consume leaves it so); set as TailBackward::step_live is
+};
+
+struct RayTail { float out[3], depth_out, err; };
+__device__ __forceinline__ RayTail ray_tail_forward(float ws, float d, float i0, float i1, float i2, float near, float far, const float* tgt, float bg) {
+#pragma clang fp contract(off)  // (render_tail_forward_kernel: the framework's blend is a multiply, then an add)
+    RayTail t;
+    const float back = (1.0f - ws) * bg;
+    const float img[3] = {i0, i1, i2};
+    float err = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float v = img[c] + back;
+        t.out[c] = v;
+        const float e = v - tgt[c];
+        err += e * e;
+    }
+    t.err = err;
+    t.depth_out = fmaxf(d - near, 0.0f) / (far - near);
+    return t;
+}
+
+template <int KEEP>
+__global__ __launch_bounds__(kCompBlock) void composite_step_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                    const float* __restrict__ deltas, const int* __restrict__ rays, uint32_t M,
+                                                                    uint32_t N, float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                    float* __restrict__ image, float* __restrict__ grad_sigmas,
+                                                                    float* __restrict__ grad_rgbs, const StepTail tail) {
+    const uint32_t n = blockIdx.x * (kCompBlock / kWave) + threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
+                   num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    const bool dead = num_steps == 0 || offset + num_steps >= M;
+    const uint32_t steps = dead ? 0u : num_steps;
+    // everything the wave will read is requested NOW -- the loss scale, the ray's tail inputs, the samples of every kept chunk: one memory round trip
+    // behind the ray record instead of one per use (the compiler sinks a load to its first use: the scale's sat behind the tail's stores)
+    const float scale_now = tail.scale ? *tail.scale : 1.0f;
+    const float near = tail.nears[index], far = tail.fars[index];
+    const float tgt[3] = {tail.target[3 * (size_t)index], tail.target[3 * (size_t)index + 1], tail.target[3 * (size_t)index + 2]};
+    ChunkIn in[KEEP];
+#pragma unroll
+    for (int c = 0; c < KEEP; c++) {
+        const uint32_t k = (uint32_t)c * kWave + lane;
+        in[c] = load_chunk(sigmas, rgbs, deltas, (size_t)offset + k, k < steps);
+    }
+    asm volatile("" ::"v"(scale_now), "v"(near), "v"(far), "v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]));  // (issued here, not where they are used)
+    zero_uncovered_rows(rays, n, lane, offset, num_steps, M, N, grad_sigmas, grad_rgbs);
+
+    RayCarry c;
+    ChunkOut kept[KEEP];
+#pragma unroll
+    for (int j = 0; j < KEEP; j++)
+        if ((uint32_t)j * kWave < steps) kept[j] = chunk_walk<true>(in[j], c);  // (wave-uniform)
+    const RayCarry at_keep = c;
+    for (uint32_t c0 = (uint32_t)KEEP * kWave; c0 < steps; c0 += kWave) {  // chunks past the kept ones: the totals now, their gradients by a second walk below
+        const uint32_t k = c0 + lane;
+        chunk_walk<true>(load_chunk(sigmas, rgbs, deltas, (size_t)offset + k, k < steps), c);
+    }
+    const RayCarry fin = c;
+    const RayTail rt = ray_tail_forward(fin.ws, fin.d, fin.r, fin.g, fin.b, near, far, tgt, tail.bg);
+    if (lane == 0) {
+        weights_sum[index] = fin.ws;
+        depth[index] = fin.d;
+        image[3 * (size_t)index] = fin.r; image[3 * (size_t)index + 1] = fin.g; image[3 * (size_t)index + 2] = fin.b;
+        tail.image_out[3 * (size_t)index] = rt.out[0]; tail.image_out[3 * (size_t)index + 1] = rt.out[1]; tail.image_out[3 * (size_t)index + 2] = rt.out[2];
+        tail.depth_out[index] = rt.depth_out;
+        tail.err[index] = rt.err;
+    }
+    if (dead) return;
+    const RayGrad q = ray_loss_gradient(tail.norm, scale_now * tail.loss_mul, tail.bg, rt.out, tgt);  // (TailBackward with grad_loss = 1: 1.0f * scale is scale)
+#pragma unroll
+    for (int j = 0; j < KEEP; j++)
+        if ((uint32_t)j * kWave < steps) {
+            const uint32_t k = (uint32_t)j * kWave + lane;
+            sample_backward(k < steps, (size_t)offset + k, offset + (uint32_t)j * kWave, lane, in[j].d0, kept[j], in[j].c0, in[j].c1, in[j].c2, q, fin, grad_sigmas,
+                            grad_rgbs, tail.step_live);
+        }
+    c = at_keep;
+    for (uint32_t c0 = (uint32_t)KEEP * kWave; c0 < steps; c0 += kWave) {
+        const uint32_t k = c0 + lane;
+        const bool on = k < steps;
+        const size_t i = (size_t)offset + k;
+        const ChunkIn more = load_chunk(sigmas, rgbs, deltas, i, on);
+        const ChunkOut o = chunk_walk<false>(more, c);
+        sample_backward(on, i, offset + c0, lane, more.d0, o, more.c0, more.c1, more.c2, q, fin, grad_sigmas, grad_rgbs, tail.step_live);
+    }
+}
+
+// err[N] -> loss: step_loss.hpp (one workgroup)
+constexpr uint32_t kLossThreads = 1024;
+__global__ __launch_bounds__(kLossThreads) void composite_step_loss_kernel(const StepLossJob job) {
+    __shared__ StepLossLds lds;
+    step_loss_sum<kLossThreads>(job, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1420,6 +1555,45 @@ extern "C" int nerftex_composite_tail_backward_live(const float* grad_loss, cons
                            sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs, tail);
     }
     return check_launch("composite_tail_backward");
+}
+
+// [extension, round 6] nerftex_composite_rays_train_forward + nerftex_render_tail_forward + nerftex_composite_tail_backward as ONE launch (+ a
+// one-workgroup launch for the loss): composite_step_kernel above.  grad_sigmas / grad_rgbs are the gradients of `scaled_loss` for a root
+// gradient of one; err[N] is scratch; step_live as in nerftex_composite_tail_backward_live but ZERO ON ENTRY is the caller's business.
+extern "C" int nerftex_composite_step(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
+                                      const float* nears, const float* fars, const float* target, float bg, float loss_mul, const float* scale,
+                                      float* weights_sum, float* depth, float* image, float* image_out, float* depth_out, float* err, float* loss,
+                                      float* scaled_loss, float* grad_sigmas, float* grad_rgbs, uint32_t* step_live, void* stream) {
+    clear_error();
+    if (N == 0 || M == 0) {
+        set_error("composite_step: no rays / no samples (use the three entries it replaces)");
+        return NERFTEX_ERR_INVALID;
+    }
+    if (N > kStepLossMaxRays) {
+        set_error("composite_step: at most %u rays per launch, got %u", kStepLossMaxRays, N);
+        return NERFTEX_ERR_INVALID;
+    }
+    const StepTail tail{nears, fars, target, scale, bg, loss_mul, (float)(2.0 / (double)((size_t)N * 3)), image_out, depth_out, err, step_live};
+    {
+        KernelTimer kt("composite_step_kernel", as_stream(stream));
+        const int keep = knob(kKnobCompositeKeep);
+        const dim3 grid(div_up(N, kCompBlock / (uint32_t)kWave)), block(kCompBlock);
+#define NERFTEX_STEP(K) \
+    hipLaunchKernelGGL(composite_step_kernel<K>, grid, block, 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image, grad_sigmas, \
+                       grad_rgbs, tail)
+        if (keep == 1) NERFTEX_STEP(1);
+        else if (keep == 3) NERFTEX_STEP(3);
+        else if (keep == 4) NERFTEX_STEP(4);
+        else NERFTEX_STEP(2);
+#undef NERFTEX_STEP
+    }
+    int rc = check_launch("composite_step");
+    if (rc != NERFTEX_OK || loss == nullptr) return rc;  // (loss NULL: the caller hands err[] to nerftex_field_backward_live_consume's nerftex_step_loss)
+    {
+        KernelTimer kt("composite_step_loss_kernel", as_stream(stream));
+        hipLaunchKernelGGL(composite_step_loss_kernel, dim3(1), dim3(kLossThreads), 0, as_stream(stream), StepLossJob{err, N, loss_mul, scale, loss, scaled_loss});
+    }
+    return check_launch("composite_step(loss)");
 }
 
 static int march_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,

@@ -29,7 +29,7 @@ long g_knobs[kKnobCount] = {0};
 namespace {
 const char* const kKnobNames[kKnobCount] = {"grid_fwd", "grid_bwd", "grid_bwd_sweep", "grid_bwd_items", "grid_bwd_slice", "grid_bwd_nomerge",
                                             "grid_bwd_probe", "march", "march_serial", "ffmlp_wg_per_cu",
-                                            "ffmlp_bwd_split", "march_lean", "ffmlp_bwd_tr", "grid_bwd_stage"};
+                                            "ffmlp_bwd_split", "march_lean", "ffmlp_bwd_tr", "grid_bwd_stage", "composite_keep"};
 int knob_index(const char* name, size_t n) {
     for (int k = 0; k < kKnobCount; k++)
         if (strlen(kKnobNames[k]) == n && strncmp(kKnobNames[k], name, n) == 0) return k;

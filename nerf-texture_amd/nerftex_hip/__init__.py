@@ -63,6 +63,9 @@ _SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _u64, _vp],
     "nerftex_field_backward_live": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_field_backward_live_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_backward_live_consume": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_backward_live_consume_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_composite_step": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_render_tail_forward_live": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "nerftex_composite_tail_backward_live": [_vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "nerftex_grid_encode_backward_adam": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _vp, _vp],
@@ -125,6 +128,11 @@ class TableAdam(C.Structure):
     """nerftex_table_adam of include/nerftex_hip.h, field for field."""
     _fields_ = [("param", _vp * 2), ("exp_avg", _vp * 2), ("exp_avg_sq", _vp * 2), ("param_half", _vp), ("live", _vp), ("step", _vp),
                 ("grad_scale", _vp), ("found_inf", _vp), ("lr", _f64), ("beta1", _f64), ("beta2", _f64), ("eps", _f64)]
+
+
+class StepLoss(C.Structure):
+    """nerftex_step_loss of include/nerftex_hip.h, field for field."""
+    _fields_ = [("err", _vp), ("n_rays", _u32), ("loss_mul", _f32), ("scale", _vp), ("loss", _vp), ("scaled_loss", _vp)]
 
 
 EXPORTS = ["nerftex_last_error", "nerftex_version", "nerftex_tune_get", "nerftex_workspace_slots_touched"] + list(_SIGNATURES)

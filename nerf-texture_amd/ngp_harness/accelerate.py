@@ -42,7 +42,7 @@ RING = 16
 class AcceleratedTrainer:
     def __init__(self, renderer, rays_per_batch=None, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, dt_gamma=1 / 128, bg_color=1, perturb=True, max_steps=1024,
                  amp_dtype=torch.float16, graph=True, steps_per_call=1, march_across_ring_end=False, pipeline_adam=0, skip_dead_samples=None,
-                 fused_table_update=None):
+                 fused_table_update=None, fused_composite_step=None):
         from .model import NGPField
 
         field = renderer.field
@@ -109,6 +109,14 @@ class AcceleratedTrainer:
         if self.fused_table_update:
             self.amp.fuse_table_update(field.encoder)
         self._one = torch.ones((), dtype=torch.float32, device=self.dev)
+        # fused_composite_step (round 6; None = on under the fused AMP step): compositing forward, render tail and their backward -- three adjacent,
+        # latency-bound launches -- as ONE (fused.composite_tail's `one`: the step's root gradient is the tensor `_one`, so the forward's launch can
+        # form the loss gradient itself).  Same outputs and gradients bit for bit (tests/test_gpu_round6.py).
+        can_step = bool(self.fused and self.amp is not None)
+        self.fused_composite_step = can_step if fused_composite_step is None else bool(fused_composite_step)
+        assert not self.fused_composite_step or can_step, "fused_composite_step needs the fused AMP step (the root gradient must be known to be one)"
+        renderer.root_one = self._one if self.fused_composite_step else None
+        renderer.defer_step_loss = bool(self.fused_composite_step)  # (`_shade` reads the loss after the backward: the field's backward may finish it)
         self._graphs, self._M = None, 0
         # steps_per_call = k > 1: `step_group` takes the batches of k consecutive steps at once and replays ONE graph for their shade + backward +
         # optimizer (the hand-over between two graph launches idles the device ~10 us: bench.py's --steps-per-graph), their k marches being

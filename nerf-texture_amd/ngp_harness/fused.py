@@ -127,6 +127,8 @@ class _ngp_field(Function):
             ctx.grad_chunker = getattr(enc, "grad_chunker", None)  # dp.TableGradChunks: the table gradient is finished level group by level group
             ctx.table_adam = getattr(enc, "table_adam", None)  # optim.FusedAmp.fuse_table_update: the summing kernel applies Adam to the tiles it owns
             ctx.live_holder = getattr(enc, "step_live_holder", None)  # Renderer.shade_train(skip_dead_samples): where composite_tail's backward leaves its step flags
+            if ctx.live_holder is not None and (FIELD_BACKWARD_FUSED or mlp_dtype == torch.bfloat16) and ws_h.dtype == wc_h.dtype == mlp_dtype:
+                ctx.live_holder["field_consumes"] = True  # this node's backward is nerftex_field_backward_live_consume: it also finishes the step's loss
         else:
             check(field_forward(ptr(feats), ptr(dirs), ptr(ws_h), ptr(wc_h), B, ptr(sigma), ptr(rgbs), None, None, None, None, stream()))
         ctx.set_materialize_grads(False)
@@ -153,9 +155,26 @@ class _ngp_field(Function):
         # issue no loads and no MFMAs; their rows of grad_x are written as zeros (what the plain kernels compute: the hash-grid backward drops them).
         holder = ctx.live_holder
         flags = holder.pop("flags", None) if holder is not None else None
+        # consume (composite_tail's one-launch form set the flags in the FORWARD, in a buffer that lives across steps): this call leaves them zero again
+        consume = holder.pop("consume", False) if holder is not None else False
+        loss_job = holder.pop("loss_job", None) if holder is not None else None  # (composite_tail's one-launch form left the loss for this call to finish)
         if flags is not None and not (flags.numel() * 32 >= B and (FIELD_BACKWARD_FUSED or bf16) and ws_dtype == wc_dtype == mlp_dtype):
+            if consume:
+                flags.zero_()
             flags = None
-        if flags is not None:
+        if consume or loss_job is not None:
+            assert (FIELD_BACKWARD_FUSED or bf16) and ws_dtype == wc_dtype == mlp_dtype, "announced in the forward (field_consumes)"
+            field_backward = lib.nerftex_field_backward_live_consume_bf16 if bf16 else lib.nerftex_field_backward_live_consume
+            job = None
+            if loss_job is not None:
+                from nerftex_hip import StepLoss
+                import ctypes
+
+                err, n_rays, loss_mul, scale, losses = loss_job
+                job = ctypes.byref(StepLoss(ptr(err), n_rays, loss_mul, ptr(scale), ptr(losses), losses.data_ptr() + 4))
+            check(field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin), ptr(grad_x),
+                                 ptr(grad_ws), ptr(grad_wc), ptr(flags), job, found, stream()))
+        elif flags is not None:
             field_backward = lib.nerftex_field_backward_live_bf16 if bf16 else lib.nerftex_field_backward_live
             check(field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin), ptr(grad_x),
                                  ptr(grad_ws), ptr(grad_wc), ptr(flags), found, stream()))
@@ -350,10 +369,14 @@ class _render_tail(Function):
 class _composite_tail(Function):
     """raymarching.composite_rays_train + render_tail as ONE autograd node: two launches forward (the two kernels as they are), one
     launch backward (nerftex_composite_tail_backward: the render tail's backward rides on the compositing backward).
-    -> (image_out, depth_out, loss * loss_mul, that times `scale`); backward through the last one reaches sigmas and rgbs."""
+    -> (image_out, depth_out, loss * loss_mul, that times `scale`); backward through the last one reaches sigmas and rgbs.
+
+    one (round 6): the tensor the caller will hand to `scaled.backward(one)` -- a device float holding 1.0.  With it (and a gradient wanted) the
+    forward is nerftex_composite_step: ONE launch computes the outputs AND the gradients for a root gradient of one (+ a one-workgroup launch for
+    the loss); the backward returns them when the root gradient is that very tensor, and runs the backward launch as before for any other."""
 
     @staticmethod
-    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale, live_holder=None):
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale, live_holder=None, one=None):
         sigmas, rgbs, deltas = sigmas.contiguous().float(), rgbs.contiguous().float(), deltas.contiguous().float()
         nears, fars, target = nears.contiguous().float(), fars.contiguous().float(), target.contiguous().float()
         rays = rays.contiguous()
@@ -364,6 +387,37 @@ class _composite_tail(Function):
         weights_sum, depth, depth_out = per_ray[0], per_ray[1], per_ray[2]
         image, image_out = per_ray[3:6].view(N, 3), per_ray[6:9].view(N, 3)
         losses = torch.empty(2, dtype=torch.float32, device=dev)
+        ctx.step_grads = None
+        if one is not None and 0 < N <= 262144 and M > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            assert one.dtype == torch.float32 and one.numel() == 1 and one.device == dev
+            grads = torch.empty(4 * M, dtype=torch.float32, device=dev)
+            err = torch.empty(N, dtype=torch.float32, device=dev)
+            # the step flags: zero on entry, set by this launch, zeroed again by the field's backward (nerftex_field_backward_live_consume) -- so the
+            # buffer lives across steps (holder["buffer"], Renderer.shade_train); without one: a zero fill
+            flags = None
+            if live_holder is not None:
+                buf = live_holder.get("buffer")
+                words = (M + 31) // 32
+                flags = buf[:words] if buf is not None and buf.numel() >= words else torch.zeros(words, dtype=torch.int32, device=dev)
+            # the loss: the field's backward finishes it (an extra workgroup of its weight-gradient reduction: `loss` and `scaled` are COMPLETE AFTER THE
+            # BACKWARD, which is when a training step reads them) when it has announced that it will; else a one-workgroup launch of this call's
+            defer = live_holder is not None and live_holder.get("field_consumes", False) and live_holder.get("defer_loss", False)
+            check(lib.nerftex_composite_step(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(nears), ptr(fars), ptr(target), float(bg),
+                                             float(loss_mul), ptr(scale), ptr(weights_sum), ptr(depth), ptr(image), ptr(image_out), ptr(depth_out), ptr(err),
+                                             None if defer else ptr(losses), losses.data_ptr() + 4, ptr(grads), grads.data_ptr() + 4 * M, ptr(flags), stream()))
+            if defer:
+                live_holder["loss_job"] = (err, N, float(loss_mul), scale, losses)
+            ctx.step_grads, ctx.one_ptr = (grads[:M], grads[M:].view(M, 3)), one.data_ptr()
+            ctx.live_holder, ctx.step_live = live_holder, flags
+            if flags is not None:
+                live_holder["flags"], live_holder["consume"] = flags, True
+                live_holder["last"] = flags.clone() if live_holder.get("keep_last") else None
+            ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, image_out, target, scale)
+            ctx.consts = (float(bg), float(loss_mul))
+            loss, scaled = losses[0], losses[1]
+            ctx.mark_non_differentiable(image_out, depth_out, loss)
+            ctx.set_materialize_grads(False)
+            return image_out, depth_out, loss, scaled
         scratch = _tail_scratch(dev, (N + 255) // 256)
         check(lib.nerftex_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(weights_sum), ptr(depth), ptr(image), stream()))
         # live_holder (a dict the field's backward shares: Renderer.shade_train): this node's backward leaves one flag per 32 samples in it -- 0 = all 32
@@ -385,11 +439,13 @@ class _composite_tail(Function):
     def backward(ctx, _gi, _gd, _gl, grad_scaled):
         sigmas, rgbs, deltas, rays, weights_sum, image, image_out, target, scale = ctx.saved_tensors
         if grad_scaled is None:
-            return (None,) * 11
+            return (None,) * 12
+        if ctx.step_grads is not None and grad_scaled.data_ptr() == ctx.one_ptr and grad_scaled.numel() == 1:
+            return (*ctx.step_grads, None, None, None, None, None, None, None, None, None, None)  # computed by the forward's launch
         bg, loss_mul = ctx.consts
         M, N = sigmas.shape[0], rays.shape[0]
         if N == 0 or M == 0:
-            return torch.zeros_like(sigmas), torch.zeros_like(rgbs), None, None, None, None, None, None, None, None, None
+            return torch.zeros_like(sigmas), torch.zeros_like(rgbs), None, None, None, None, None, None, None, None, None, None
         grad_scaled = grad_scaled.contiguous().float()
         # PRECONDITION of the uninitialised gradient buffers below: `rays` are the records of THIS library's march with the counter at zero
         # on entry (march_rays_train / march_rays_train_fresh: record n = ray n, offsets an exclusive prefix sum from 0), so that the rows past
@@ -400,15 +456,16 @@ class _composite_tail(Function):
         grad_sigmas, grad_rgbs = grads[:M], grads[M:].view(M, 3)
         check(lib.nerftex_composite_tail_backward_live(ptr(grad_scaled), ptr(scale), loss_mul, ptr(image_out), ptr(target), bg, ptr(sigmas), ptr(rgbs), ptr(deltas),
                                                        ptr(rays), ptr(weights_sum), ptr(image), M, N, ptr(grad_sigmas), ptr(grad_rgbs), ptr(ctx.step_live), stream()))
-        if ctx.step_live is not None:
+        if ctx.step_live is not None and ctx.step_grads is None:
             ctx.live_holder["flags"] = ctx.live_holder["last"] = ctx.step_live  # ("last" stays for whoever wants to look: bench.py's dead-step fraction)
-        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None, None
 
 
-def composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, bg=1.0, loss_mul=1.0, scale=None, live_holder=None):
+def composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, bg=1.0, loss_mul=1.0, scale=None, live_holder=None, one=None):
     """-> (image_out, depth_out, loss, scaled_loss): compositing, background blend, depth normalisation and MSE; one backward launch.
-    live_holder: a dict shared with the fused field's backward (Renderer.shade_train, skip_dead_samples): the backward leaves its step flags there."""
-    return _composite_tail.apply(sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale, live_holder)
+    live_holder: a dict shared with the fused field's backward (Renderer.shade_train, skip_dead_samples): the backward leaves its step flags there.
+    one: the root-gradient tensor of the coming `scaled_loss.backward(one)` (a device 1.0): forward + backward become one launch."""
+    return _composite_tail.apply(sigmas, rgbs, deltas, rays, nears, fars, target, bg, loss_mul, scale, live_holder, one)
 
 
 _SCRATCH = {}

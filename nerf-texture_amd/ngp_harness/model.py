@@ -441,6 +441,14 @@ class Renderer(nn.Module):
         if (target is not None and getattr(self, "skip_dead_samples", False) and getattr(self, "fused_composite_tail", True) and enc is not None
                 and torch.is_grad_enabled()):
             holder = {}
+            if getattr(self, "root_one", None) is not None:  # composite_tail's one-launch form sets the flags in a buffer that lives across steps
+                words = (xyzs.shape[0] + 31) // 32
+                buf = getattr(self, "_live_words", None)
+                if buf is None or buf.numel() < words or buf.device != xyzs.device:
+                    buf = self._live_words = torch.zeros(words, dtype=torch.int32, device=xyzs.device)
+                holder["buffer"] = buf
+                holder["defer_loss"] = getattr(self, "defer_step_loss", False)  # (accelerate: the loss is read after the backward -- the field's backward finishes it)
+                holder["keep_last"] = getattr(self, "keep_step_live", False)  # (a copy of the flags for whoever counts them: bench.py's dead-step fraction)
             enc.step_live_holder = holder
             self.last_step_live = holder  # (after the backward: holder["last"] = the step's flags)
         try:
@@ -454,7 +462,9 @@ class Renderer(nn.Module):
             from . import fused
 
             if getattr(self, "fused_composite_tail", True):  # compositing + blend + depth + MSE: one launch per direction
-                return fused.composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, float(bg_color), loss_mul, scale, holder)
+                # root_one (accelerate, fused AMP step): the tensor `scaled.backward(one)` will be called with -- forward + backward in one launch
+                return fused.composite_tail(sigmas, rgbs, deltas, rays, nears, fars, target, float(bg_color), loss_mul, scale, holder,
+                                            getattr(self, "root_one", None))
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
             return fused.render_tail(weights_sum, depth, image, nears, fars, target, float(bg_color), loss_mul, scale)
         weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)

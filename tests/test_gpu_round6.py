@@ -508,3 +508,156 @@ def test_curved_field_glue_kernels_equal_the_framework_ops(dev):
         for ga, gb in zip(a[2], b[2]):
             assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max()) + 1e-7, mode
     assert len(out[("train", True)][2]) == 3
+
+
+# ------------------------------------------------------------------------------------------------- the compositing of a training step as one launch
+@pytest.mark.parametrize("case", ["opaque", "thin", "budget_cut"])
+def test_composite_step_equals_the_three_launches(dev, knobs, case):
+    """nerftex_composite_step against nerftex_composite_rays_train_forward + nerftex_render_tail_forward_live + nerftex_composite_tail_backward_live
+    (raymarching.cu:739-767 / :843-880 around the blend and the MSE): every output, the loss, the gradients and the step flags bit for bit -- for every
+    number of 64-sample chunks a wave keeps in registers (rays longer than that reload), with and without a loss scale, with rows no ray covers and
+    with rays the sample budget cut off."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    field, r, ro, rd = _opaque_case(dev, density_scale={"opaque": 400.0, "thin": 3.0, "budget_cut": 30.0}[case])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        marched, _ = r.march_train(ro, rd, dt_gamma=1 / 128 if case != "thin" else 0.0, perturb=True, mean_count={"opaque": 300000, "thin": 700000, "budget_cut": 60000}[case])
+        nears, fars, xyzs, dirs, deltas, rays = marched
+        sigmas, rgbs, _ = field(xyzs, dirs)
+    sigmas = (sigmas.float() * r.density_scale).contiguous()
+    rgbs = rgbs.float().contiguous()
+    M, N = sigmas.shape[0], rays.shape[0]
+    counts = rays[:, 2]
+    total = int(rays[-1, 1] + rays[-1, 2])
+    if case == "budget_cut":
+        assert total >= M, "some rays must have been cut off by the budget"
+    else:
+        assert total < M and int(counts.max()) > 128, "rows no ray covers, and rays longer than two chunks"
+    tgt = torch.rand(N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    one = torch.ones((), device=dev)
+    words = (M + 31) // 32
+    for scale in (None, torch.full((), 1024.0, device=dev)):
+        # the three launches
+        per_ray = torch.empty(9, N, device=dev)
+        ws, depth, depth_out, image, image_out = per_ray[0], per_ray[1], per_ray[2], per_ray[3:6].view(N, 3), per_ray[6:9].view(N, 3)
+        losses = torch.empty(2, device=dev)
+        ticket, partial = torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1024, device=dev)
+        flags = torch.full((words,), 7, dtype=torch.int32, device=dev)
+        check(lib.nerftex_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(ws), ptr(depth), ptr(image), stream()))
+        check(lib.nerftex_render_tail_forward_live(ptr(ws), ptr(depth), ptr(image), ptr(nears), ptr(fars), ptr(tgt), 1.0, 0.5, N, ptr(image_out), ptr(depth_out),
+                                                   ptr(partial), ptr(ticket), ptr(losses), ptr(scale), losses.data_ptr() + 4, ptr(flags), words, stream()))
+        g = torch.full((4 * M,), float("nan"), device=dev)
+        check(lib.nerftex_composite_tail_backward_live(ptr(one), ptr(scale), 0.5, ptr(image_out), ptr(tgt), 1.0, ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(ws),
+                                                       ptr(image), M, N, ptr(g[:M]), ptr(g[M:]), ptr(flags), stream()))
+        assert 0 < int((flags != 0).sum()) and float(g[:M].abs().max()) > 0
+        for keep in (0, 1, 3, 4):
+            knobs(composite_keep=keep)
+            per_ray2 = torch.full((9, N), float("nan"), device=dev)
+            ws2, depth2, depth_out2, image2, image_out2 = per_ray2[0], per_ray2[1], per_ray2[2], per_ray2[3:6].view(N, 3), per_ray2[6:9].view(N, 3)
+            losses2 = torch.full((2,), float("nan"), device=dev)
+            err = torch.empty(N, device=dev)
+            flags2 = torch.zeros(words, dtype=torch.int32, device=dev)
+            g2 = torch.full((4 * M,), float("nan"), device=dev)
+            check(lib.nerftex_composite_step(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(nears), ptr(fars), ptr(tgt), 1.0, 0.5, ptr(scale), ptr(ws2),
+                                             ptr(depth2), ptr(image2), ptr(image_out2), ptr(depth_out2), ptr(err), ptr(losses2), losses2.data_ptr() + 4, ptr(g2[:M]),
+                                             ptr(g2[M:]), ptr(flags2), stream()))
+            assert torch.equal(_bits(per_ray), _bits(per_ray2)), f"per-ray outputs (keep {keep})"
+            assert torch.equal(_bits(losses), _bits(losses2)), f"loss, scaled loss (keep {keep}): {losses.tolist()} {losses2.tolist()}"
+            assert torch.equal(_bits(g), _bits(g2)), f"gradients (keep {keep})"
+            assert torch.equal(flags != 0, flags2 != 0), f"step flags (keep {keep})"
+
+
+def test_field_backward_consume_leaves_the_step_flags_zero(dev):
+    """nerftex_field_backward_live_consume = nerftex_field_backward_live + the flags zeroed by its last launch + (with a nerftex_step_loss) the loss
+    nerftex_composite_step would have formed from the same squared errors with its second launch, bit for bit."""
+    import ctypes
+
+    from nerftex_hip import StepLoss, check, lib, ptr, stream
+
+    B = 128 * 64
+    g = torch.Generator(device=dev).manual_seed(2)
+    ws = ((torch.rand(64 * (32 + 64 + 16), device=dev, generator=g) - 0.5) * 0.3).half()
+    wc = ((torch.rand(64 * (32 + 128 + 16), device=dev, generator=g) - 0.5) * 0.3).half()
+    feats = ((torch.rand(16, B, 2, device=dev, generator=g) - 0.5)).half()
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g), dim=-1)
+    sigma, rgbs = torch.empty(B, device=dev), torch.empty(B, 3, device=dev)
+    x_rows, h, cin = (torch.empty(B, 32, dtype=torch.float16, device=dev), torch.empty(B, 16, dtype=torch.float16, device=dev),
+                      torch.empty(B, 32, dtype=torch.float16, device=dev))
+    check(lib.nerftex_field_forward(ptr(feats), ptr(dirs), ptr(ws), ptr(wc), B, ptr(sigma), ptr(rgbs), ptr(x_rows), ptr(h), ptr(cin), None, stream()))
+    live = torch.rand(B // 32, device=dev, generator=g) < 0.5
+    rows_live = live.repeat_interleave(32)
+    gs = torch.randn(B, device=dev, generator=g) * 1e-2 * rows_live
+    gc = torch.randn(B, 3, device=dev, generator=g) * 1e-2 * rows_live.unsqueeze(-1)
+    out = []
+    for consume in (False, True):
+        flags = torch.cat([live.to(torch.int32), torch.full((5,), 9, dtype=torch.int32, device=dev)])  # (words past B / 32 are not this call's)
+        grad_cin, grad_x = torch.zeros(B, 32, dtype=torch.float16, device=dev), torch.empty(B, 32, dtype=torch.float16, device=dev)
+        gws, gwc = torch.empty_like(ws), torch.empty_like(wc)
+        common = (ptr(gs), ptr(gc), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws), ptr(wc), B, ptr(grad_cin), ptr(grad_x), ptr(gws), ptr(gwc), ptr(flags))
+        if consume:
+            check(lib.nerftex_field_backward_live_consume(*common, None, None, stream()))
+        else:
+            check(lib.nerftex_field_backward_live(*common, None, stream()))
+        out.append((grad_x, gws, gwc))
+        if consume:
+            assert int(flags[:B // 32].abs().sum()) == 0 and (flags[B // 32:] == 9).all()
+        else:
+            assert torch.equal(flags[:B // 32] != 0, live)
+    for a, b in zip(*out):
+        assert torch.equal(_bits(a), _bits(b))
+    # the loss job: a real step's squared errors (ray counts that are and are not multiples of 64 / 256)
+    field, r, ro, rd = _opaque_case(dev, n_rays=2048 + 77, density_scale=30.0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        marched, _ = r.march_train(ro, rd, dt_gamma=1 / 128, perturb=True, mean_count=300000)
+        nears, fars, xyzs, dirs_, deltas, rays = marched
+        sg, rgb, _ = field(xyzs, dirs_)
+    sg, rgb = (sg.float() * r.density_scale).contiguous(), rgb.float().contiguous()
+    M, N = sg.shape[0], rays.shape[0]
+    tgt = torch.rand(N, 3, device=dev, generator=g)
+    scale = torch.full((), 512.0, device=dev)
+    per_ray, err, grads = torch.empty(9, N, device=dev), torch.empty(N, device=dev), torch.empty(4 * M, device=dev)
+    for n_rays in (N, 2048, 300):  # (the job's own ray count: a prefix of the errors)
+        want, got = torch.empty(2, device=dev), torch.full((2,), float("nan"), device=dev)
+        args = (ptr(sg), ptr(rgb), ptr(deltas), ptr(rays), M, N, ptr(nears), ptr(fars), ptr(tgt), 1.0, 0.25, ptr(scale), ptr(per_ray[0]), ptr(per_ray[1]), ptr(per_ray[3:6]),
+                ptr(per_ray[6:9]), ptr(per_ray[2]), ptr(err))
+        if n_rays == N:
+            check(lib.nerftex_composite_step(*args, ptr(want), want.data_ptr() + 4, ptr(grads[:M]), ptr(grads[M:]), None, stream()))
+        check(lib.nerftex_composite_step(*args, None, None, ptr(grads[:M]), ptr(grads[M:]), None, stream()))  # loss NULL: left to the job
+        job = StepLoss(ptr(err), n_rays, 0.25, ptr(scale), ptr(got), got.data_ptr() + 4)
+        flags = live.to(torch.int32)
+        check(lib.nerftex_field_backward_live_consume(*common[:-1], ptr(flags), ctypes.byref(job), None, stream()))
+        if n_rays == N:
+            assert torch.equal(_bits(want), _bits(got)), (want.tolist(), got.tolist())
+        else:
+            ref = float(err[:n_rays].double().sum() / (n_rays * 3) * 0.25)
+            assert abs(float(got[0]) - ref) <= 1e-5 * ref and float(got[1]) == float(got[0]) * 512.0
+        assert torch.equal(_bits(out[0][1]), _bits(gws)) and int(flags.abs().sum()) == 0
+    bad = StepLoss(ptr(err), 0, 1.0, None, ptr(got), None)
+    assert lib.nerftex_field_backward_live_consume(*common[:-1], ptr(flags), ctypes.byref(bad), None, stream()) != 0
+
+
+def test_fused_composite_step_trains_like_the_three_launch_step(dev):
+    """accelerate(fused_composite_step=True) against False, replayed graphs included, on a field dense enough to have dead steps: the same losses and
+    parameters bit for bit, and the flag buffer is clean between steps."""
+    from ngp_harness.accelerate import accelerate
+
+    out = {}
+    for fused_step in (False, True):
+        field, r, ro, rd = _opaque_case(dev, n_rays=4096, density_scale=300.0)
+        tgt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+        tr = accelerate(r, dt_gamma=1 / 128, fused_composite_step=fused_step)
+        assert (r.root_one is not None) == fused_step and r.skip_dead_samples
+        losses = []
+        for _ in range(16 + 2 + 14):
+            tr.step(ro, rd, tgt)
+            losses.append(tr.loss.clone())
+        torch.cuda.synchronize()
+        assert tr._graphs is not None
+        if fused_step:
+            assert int(r._live_words.abs().sum()) == 0, "consumed by the field's backward"
+        tr.sync()
+        out[fused_step] = (losses, {n_: p.detach().clone() for n_, p in field.named_parameters()})
+    for i, (la, lb) in enumerate(zip(out[False][0], out[True][0])):
+        assert torch.equal(la, lb), f"loss of step {i}"
+    for name in out[False][1]:
+        assert torch.equal(out[False][1][name], out[True][1][name]), name

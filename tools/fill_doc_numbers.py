@@ -25,7 +25,7 @@ vals = {
     "G2": f"{sum(g2.values()):.0f}",
     "BWD": f"{2 * k['ffmlp_backward_fused_kernel']:.0f}", "RED": f"{k['ffmlp_wgrad_reduce2_kernel']:.1f}", "G1": f"{k['grid_forward_level_kernel']:.0f}",
     "FWD": f"{k['field_forward_kernel']:.0f}",
-    "COMPOSITE": f"{k['composite_train_fwd_kernel'] + k['composite_train_bwd_kernel'] + k['render_tail_forward_kernel']:.0f}",
+    "COMPOSITE": f"{sum(v for n, v in k.items() if n.startswith('composite_') or n == 'render_tail_forward_kernel'):.0f}",
     "ADAM": f"{k['adam_half_kernel']:.0f}", "MARCH": f"{k['march_count_parallel_kernel']:.0f} + {k['march_expand_kernel']:.0f}",
     "ACH": f"{r['achieved']:.0f}", "FRAC": f"{r['frac']:.3f}", "FRAC_BWD": f"{r['frac_backward_bytes_only']:.3f}",
     "TRAFFIC": f"{r['traffic'] / 1e6:.0f}", "TOA": f"{r['traffic_over_algorithmic']:.2f}",

@@ -24,6 +24,12 @@ case $mode in
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $GRAFT_REPO_ROOT/tools/table_update_ab.py --reps 1 --steps 416 > $out/ab.json 2> $out/ab.err )
     find $out -name "*_kernel_trace.csv" -size +40M -delete; find $out -name "*_agent_info.csv" -delete
     f=$(find $out/prof -name "*kernel_stats.csv" | head -1); head -30 $f | cut -c1-200 ;;
+  comp)     # the one-launch compositing of a training step against the three launches, per composite_keep
+    timeout 900 python tools/composite_step_ab.py > $out/comp.json 2> $out/comp.err; tail -3 $out/comp.err; cat $out/comp.json ;;
+  comp-prof)
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $GRAFT_REPO_ROOT/tools/composite_step_ab.py --reps 1 --keeps ${KEEPS:-2} > $out/comp.json 2> $out/comp.err )
+    find $out -name "*_kernel_trace.csv" -size +40M -delete; find $out -name "*_agent_info.csv" -delete
+    f=$(find $out/prof -name "*kernel_stats.csv" | head -1); grep -i "composite\|render_tail\|reduce2\|Name" $f | cut -c1-260 ;;
   probe)    # the tile-owner Adam alone, per mode of the grid_adam_mode knob
     timeout 600 python tools/tile_adam_probe.py > $out/probe.json 2> $out/probe.err; tail -3 $out/probe.err; cat $out/probe.json ;;
   trained)  # only the 'trained state' entry of the bench (train against rendered targets, then time with / without the dead-sample skip)
