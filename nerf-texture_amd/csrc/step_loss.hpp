@@ -24,9 +24,10 @@ struct StepLossLds {
 template <uint32_t THREADS>
 __device__ __forceinline__ void step_loss_sum(const StepLossJob& job, StepLossLds& lds) {
     static_assert(THREADS >= 256 && THREADS % 64 == 0, "");
-    constexpr uint32_t kWaves = THREADS / 64, kAhead = 8;  // (8192 rays, 1024 threads: every value is requested before the first is used)
+    constexpr uint32_t kWaves = THREADS / 64, kAhead = 8192 / THREADS;  // (8192 rays: every value is requested before the first is used -- one memory round trip)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x / 64u;
     const uint32_t N = job.n, groups = (N + 63u) / 64u, parts = (N + 255u) / 256u;
+    const float scale = (threadIdx.x == 0 && job.scaled_loss && job.scale) ? *job.scale : 1.0f;  // (requested with the errors, not behind the last barrier)
     for (uint32_t q0 = wave; q0 < parts * 4; q0 += kWaves * kAhead) {
         float v[kAhead];
 #pragma unroll
@@ -35,11 +36,12 @@ __device__ __forceinline__ void step_loss_sum(const StepLossJob& job, StepLossLd
             v[j] = q < groups && m < N ? job.err[m] : 0.0f;
         }
 #pragma unroll
-        for (uint32_t j = 0; j < kAhead; j++) {
+        for (int o = 32; o > 0; o >>= 1)  // (level by level over all the trees: kAhead independent shuffles in flight, not one chain after the other)
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_down(v[j], o, 64);
+            for (uint32_t j = 0; j < kAhead; j++) v[j] += __shfl_down(v[j], o, 64);
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; j++)
             if (lane == 0 && q0 + j * kWaves < parts * 4) lds.group[q0 + j * kWaves] = v[j];
-        }
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < parts; p += THREADS) {
@@ -61,7 +63,7 @@ __device__ __forceinline__ void step_loss_sum(const StepLossJob& job, StepLossLd
         for (uint32_t i = 0; i < 4; i++) total += lds.last[i];
         const float l = total / (float)((size_t)N * 3) * job.loss_mul;
         *job.loss = l;
-        if (job.scaled_loss) *job.scaled_loss = job.scale ? l * *job.scale : l;
+        if (job.scaled_loss) *job.scaled_loss = job.scale ? l * scale : l;
     }
 }
 
