@@ -21,6 +21,8 @@ timeout 200 python tools/bench_kernels.py --rays 8192 --kernels > $out/kernels.j
 timeout 300 python tools/tile_adam_probe.py > $out/tile_adam.json 2> $out/tile_adam.err
 timeout 300 python tools/table_update_ab.py > $out/table_update_ab.json 2> $out/table_update_ab.err
 timeout 300 python tools/dead_skip_probe.py > $out/dead_skip.json 2> $out/dead_skip.err
+timeout 300 python tools/composite_step_ab.py --keeps 1,2,4 > $out/composite_step_ab.json 2> $out/composite_step_ab.err
+timeout 200 python tools/composite_step_probe.py 1,2,4 > $out/composite_step_probe.json 2> $out/composite_step_probe.err
 # the parity suite beside a training process (any kernel whose result depends on co-scheduling fails an oracle comparison)
 bash tools/gpu_soak_beside_neighbour.sh > $out/soak.log 2>&1
 cp gpurun_out/soak/pytest_tail.txt $out/soak_pytest_tail.txt 2>/dev/null
