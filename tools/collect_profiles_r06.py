@@ -22,7 +22,8 @@ cp("kernels.json", "r06_kernel_microbench.json")
 cp("timeline/step.txt", "r06_step_timeline.txt")
 cp("occupancy.json", "r06_occupancy_update.json")
 cp("pytest.log", "r06_gpu_suite.txt")
-for a, b in (("tile_adam.json", "r06_tile_adam_final.json"), ("table_update_ab.json", "r06_table_update_ab.json"), ("dead_skip.json", "r06_dead_skip_probe.json")):
+for a, b in (("tile_adam.json", "r06_tile_adam_final.json"), ("table_update_ab.json", "r06_table_update_ab.json"), ("dead_skip.json", "r06_dead_skip_probe.json"),
+             ("composite_step_ab.json", "r06_composite_step_ab.json"), ("composite_step_probe.json", "r06_composite_step_probe.json")):
     if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 10:
         cp(a, b)
 cp("soak_pytest_tail.txt", "r06_gpu_suite_beside_a_training_neighbour.txt")
