@@ -366,6 +366,22 @@ int nerftex_field_backward_live_consume_bf16(const float* grad_sigma, const floa
                                              const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
                                              void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
                                              const nerftex_step_loss* loss, float* found_inf, void* stream);
+/* ... and nerftex_field_backward_live_consume WITHOUT its reduction launch (round 6): `_deferred` runs the two backward kernels and DESCRIBES the rest --
+ * the weight-gradient reduction (+ found_inf), the flags' clearing, the step's loss -- in *trailer (opaque; the partial sums wait in the library's
+ * scratch: no other nerftex_ffmlp_* / nerftex_field_* backward call in between).  nerftex_grid_encode_backward_adam_trailer, the step's next long
+ * launch, runs the trailer on the first workgroups of its fill kernel: nothing before the optimizer reads what the trailer writes, and as a launch of
+ * its own it sat 8 us on the step's critical path.  nerftex_step_trailer_run runs it as that launch of its own (what the caller does when the
+ * hash-grid call returned an error -- it has launched nothing then).  Same sums in the same order either way.                                  */
+typedef struct nerftex_step_trailer { uint64_t opaque[16]; } nerftex_step_trailer;
+int nerftex_field_backward_live_deferred(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                         const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                         void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                         const nerftex_step_loss* loss, float* found_inf, nerftex_step_trailer* trailer, void* stream);
+int nerftex_field_backward_live_deferred_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                              const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                              void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                              const nerftex_step_loss* loss, float* found_inf, nerftex_step_trailer* trailer, void* stream);
+int nerftex_step_trailer_run(const nerftex_step_trailer* trailer, void* stream);
 /* ... and the two no-grad forms of the bf16 field: the density query of the occupancy-grid update (nerftex_field_density) and the inference
  * iteration sized by a device count (nerftex_field_forward_rows, declared below), weights bf16, feats_lbc fp16, outputs fp32.  Same values as
  * nerftex_field_forward_bf16's sigma / (sigma, rgbs) on the rows they compute. */
@@ -422,6 +438,12 @@ int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, con
                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                                       int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
                                       void* stream);
+/* ... with the step's trailer (nerftex_field_backward_live_deferred, above) run by the first workgroups of the fill launch.  An error return has
+ * launched nothing.                                                                                                                              */
+int nerftex_grid_encode_backward_adam_trailer(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                              int dtype, int layout, float in_add, float in_mul, const nerftex_table_adam* adam,
+                                              uint32_t* first_updated_row, const nerftex_step_trailer* trailer, void* stream);
 
 /* Extension (round 4): the density query of the field alone -- nerf/network_ff.py:103-117 `density`: hash-grid features -> sigma net ->
  * trunc_exp -- for the occupancy-grid update (nerf/renderer.py:566-660 queries 2-4 M cell positions every 16 steps).

@@ -25,8 +25,9 @@
 // fit the 160 KB LDS of a CU they are staged once per workgroup; otherwise (hidden 256 with >= 3 layers, hidden 128
 // with >= 6) the forward / inference / dgrad kernels stage ONE layer at a time between two barriers (round 5: the
 // STREAM forms), as the reference's threadblock_layer reads each layer from global memory (ffmlp.cu:47-129).
+#include <cstring>
 #include "common.hpp"
-#include "step_loss.hpp"
+#include "step_trailer.hpp"
 #include "sh_common.hpp"  // the SH basis of the fused field kernel (switches fp contraction off for what follows ...)
 #include "workspace.hpp"
 
@@ -109,6 +110,39 @@ extern "C" int nerftex_field_backward_live_consume(const float* grad_sigma, cons
     const nerftex::StepLossJob job = loss ? nerftex::StepLossJob{loss->err, loss->n_rays, loss->loss_mul, loss->scale, loss->loss, loss->scaled_loss} : nerftex::StepLossJob{};
     return ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                            grad_sigma_weights, grad_color_weights, found_inf, stream, step_live, true, loss ? &job : nullptr);
+}
+// nerftex_field_backward_live_consume WITHOUT its reduction launch: the two backward kernels run, the rest -- the weight-gradient reduction (+ found_inf),
+// the flags' clearing, the loss -- is DESCRIBED in *trailer for nerftex_grid_encode_backward_adam_trailer (the next long kernel of the step runs it on
+// its first workgroups) or nerftex_step_trailer_run.  Nothing else of the nerftex_ffmlp_* / nerftex_field_* backward family between the two calls
+// (the partial sums wait in the library's scratch).
+extern "C" int nerftex_field_backward_live_deferred(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                                    const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                                    void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                                    const nerftex_step_loss* loss, float* found_inf, nerftex_step_trailer* trailer, void* stream) {
+    if (!trailer) {
+        clear_error();
+        set_error("field_backward_live_deferred: trailer must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    static_assert(sizeof(nerftex::StepTrailer) <= sizeof(nerftex_step_trailer), "the opaque struct of the header holds a StepTrailer");
+    const nerftex::StepLossJob job = loss ? nerftex::StepLossJob{loss->err, loss->n_rays, loss->loss_mul, loss->scale, loss->loss, loss->scaled_loss} : nerftex::StepLossJob{};
+    nerftex::StepTrailer t{};
+    const int rc = ffmlp_f16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                                 grad_sigma_weights, grad_color_weights, found_inf, stream, step_live, true, loss ? &job : nullptr, &t);
+    memset(trailer, 0, sizeof(*trailer));
+    if (rc == NERFTEX_OK) memcpy(trailer, &t, sizeof(t));
+    return rc;
+}
+// the trailer as a launch of its own (what nerftex_field_backward_live_consume's last launch is)
+extern "C" int nerftex_step_trailer_run(const nerftex_step_trailer* trailer, void* stream) {
+    clear_error();
+    nerftex::StepTrailer t{};
+    if (trailer) memcpy(&t, trailer, sizeof(t));
+    if (!trailer || t.groups == 0 || t.set[0].partials == nullptr) {
+        set_error("step_trailer_run: an empty trailer");
+        return NERFTEX_ERR_INVALID;
+    }
+    return ffmlp_f16::run_trailer(t, stream);
 }
 extern "C" int nerftex_field_forward_rows(const void* feats_lbc, const float* dirs, const void* sigma_weights, const void* color_weights, uint32_t B,
                                           float* sigma, float* rgbs, const int32_t* units_dev, uint32_t rows_per_unit, void* stream) {

@@ -1,8 +1,9 @@
 // The bf16 instantiation of the fully-fused MLP (see ffmlp.hip for the design notes; ffmlp_body.inc is the shared source): BASELINE.json configs[2]
 // names bf16.  Same exponent range as fp32, 8 significand bits instead of 11; fp32 accumulation on the matrix cores.  A translation unit of its
 // own since round 5 (build time: the two instantiations compile side by side).
+#include <cstring>
 #include "common.hpp"
-#include "step_loss.hpp"
+#include "step_trailer.hpp"
 #include "sh_common.hpp"  // the SH basis of the fused field kernel (switches fp contraction off for what follows ...)
 #include "workspace.hpp"
 
@@ -69,6 +70,28 @@ extern "C" int nerftex_field_backward_live_consume_bf16(const float* grad_sigma,
     const nerftex::StepLossJob job = loss ? nerftex::StepLossJob{loss->err, loss->n_rays, loss->loss_mul, loss->scale, loss->loss, loss->scaled_loss} : nerftex::StepLossJob{};
     return ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
                                             grad_sigma_weights, grad_color_weights, found_inf, stream, step_live, true, loss ? &job : nullptr);
+}
+// nerftex_field_backward_live_consume_bf16 WITHOUT its reduction launch: the two backward kernels run, the rest -- the weight-gradient reduction (+ found_inf),
+// the flags' clearing, the loss -- is DESCRIBED in *trailer for nerftex_grid_encode_backward_adam_trailer (the next long kernel of the step runs it on
+// its first workgroups) or nerftex_step_trailer_run.  Nothing else of the nerftex_ffmlp_* / nerftex_field_* backward family between the two calls
+// (the partial sums wait in the library's scratch).
+extern "C" int nerftex_field_backward_live_deferred_bf16(const float* grad_sigma, const float* grad_rgbs, const float* rgbs, const void* h, const void* cin,
+                                                    const void* x_rows, const void* sigma_weights, const void* color_weights, uint32_t B, void* grad_cin,
+                                                    void* grad_x, void* grad_sigma_weights, void* grad_color_weights, uint32_t* step_live,
+                                                    const nerftex_step_loss* loss, float* found_inf, nerftex_step_trailer* trailer, void* stream) {
+    if (!trailer) {
+        clear_error();
+        set_error("field_backward_live_deferred: trailer must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    static_assert(sizeof(nerftex::StepTrailer) <= sizeof(nerftex_step_trailer), "the opaque struct of the header holds a StepTrailer");
+    const nerftex::StepLossJob job = loss ? nerftex::StepLossJob{loss->err, loss->n_rays, loss->loss_mul, loss->scale, loss->loss, loss->scaled_loss} : nerftex::StepLossJob{};
+    nerftex::StepTrailer t{};
+    const int rc = ffmlp_bf16::field_backward_entry(grad_sigma, grad_rgbs, rgbs, h, cin, x_rows, sigma_weights, color_weights, B, grad_cin, grad_x,
+                                                 grad_sigma_weights, grad_color_weights, found_inf, stream, step_live, true, loss ? &job : nullptr, &t);
+    memset(trailer, 0, sizeof(*trailer));
+    if (rc == NERFTEX_OK) memcpy(trailer, &t, sizeof(t));
+    return rc;
 }
 extern "C" int nerftex_field_density_bf16(const void* feats_lbc, const void* sigma_weights, uint32_t B, float* sigma, void* stream) {
     return ffmlp_bf16::field_density_entry(feats_lbc, sigma_weights, B, sigma, stream);

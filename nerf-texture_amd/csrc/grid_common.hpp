@@ -8,6 +8,7 @@
 #pragma clang fp contract(off)  // only explicit fmaf() may fuse: the hash-grid float path is bit-exact vs the oracle
 
 namespace nerftex {
+struct StepTrailer;  // step_trailer.hpp
 namespace gridenc {
 
 constexpr int kMaxLevels = 32;
@@ -40,6 +41,7 @@ struct LevelConsts {
 
 // nerftex_table_adam of include/nerftex_hip.h (the header is C and knows no namespaces) without found_inf, which travels as LevelConsts::found_inf
 struct TableAdamArgs {
+    const struct nerftex::StepTrailer* trailer;  // optional (HOST pointer): the step's small jobs, run by the first workgroups of the fill launch (step_trailer.hpp)
     float* param[2];
     float* exp_avg[2];
     float* exp_avg_sq[2];

@@ -24,8 +24,10 @@
 // bit-exact; interpolation weights are products in dimension order; accumulation
 // is fmaf(w, g, acc) over corners 0..2^D-1 in fp32.  For fp16 tables the sum is
 // kept in fp32 and rounded once (the reference rounds to half after every corner).
+#include <cstring>
 #include "common.hpp"
 #include "grid_common.hpp"
+#include "step_trailer.hpp"
 #include "workspace.hpp"
 
 #include <cmath>
@@ -1092,10 +1094,9 @@ extern "C" int nerftex_grid_encode_backward_phase_amp(const void* grad, const fl
 // main_nerf.py:128).  The tiles of the hashed levels -- one owner each -- never leave LDS as a gradient: their owner rounds the row sums to fp16 and
 // runs Adam on the rows (gridencoder_binned.hip TileAdam).  grad_embeddings receives ONLY rows [0, *first_updated_row) -- the coarse levels whose
 // tiles several work items share -- and the caller finishes the step with nerftex_adam_mixed_step_amp_db over those rows and its other tensors.
-extern "C" int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
-                                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
-                                                 int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
-                                                 void* stream) {
+static int backward_adam_entry(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                               uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype, int layout, float in_add, float in_mul,
+                               const nerftex_table_adam* adam, uint32_t* first_updated_row, const nerftex_step_trailer* trailer, void* stream) {
     clear_error();
     if (affine_ok(in_mul) != NERFTEX_OK) return NERFTEX_ERR_INVALID;
     if (!adam || !first_updated_row || !adam->param[0] || !adam->param[1] || !adam->exp_avg[0] || !adam->exp_avg[1] || !adam->exp_avg_sq[0] ||
@@ -1114,6 +1115,16 @@ extern "C" int nerftex_grid_encode_backward_adam(const void* grad, const float* 
             return NERFTEX_ERR_INVALID;
         }
     gridenc::TableAdamArgs ta{};
+    static_assert(sizeof(StepTrailer) <= sizeof(nerftex_step_trailer), "the opaque struct of the header holds a StepTrailer");
+    StepTrailer tr{};
+    if (trailer) {
+        memcpy(&tr, trailer, sizeof(tr));
+        if (tr.groups == 0 || tr.set[0].partials == nullptr) {
+            set_error("grid_encode_backward_adam_trailer: an empty trailer (fill it with nerftex_field_backward_live_deferred)");
+            return NERFTEX_ERR_INVALID;
+        }
+        ta.trailer = &tr;
+    }
     for (int i = 0; i < 2; i++) {
         ta.param[i] = adam->param[i];
         ta.exp_avg[i] = adam->exp_avg[i];
@@ -1129,6 +1140,28 @@ extern "C" int nerftex_grid_encode_backward_adam(const void* grad, const float* 
     ta.eps = adam->eps;
     return grid_backward_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, 0, nullptr, nullptr, gridtype, align_corners, dtype, layout, true,
                                in_add, in_mul, stream, adam->found_inf, 0, 0, 0, &ta, first_updated_row);
+}
+extern "C" int nerftex_grid_encode_backward_adam(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                                                 int layout, float in_add, float in_mul, const nerftex_table_adam* adam, uint32_t* first_updated_row,
+                                                 void* stream) {
+    return backward_adam_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners, dtype, layout, in_add, in_mul, adam,
+                               first_updated_row, nullptr, stream);
+}
+// ... and the step's trailer -- what nerftex_field_backward_live_deferred left undone: the MLP weight-gradient reduction, the step flags' clearing, the
+// loss -- run by the first workgroups of this call's fill launch.  A call that returns an error has launched nothing: the trailer is then the
+// caller's to run (nerftex_step_trailer_run).
+extern "C" int nerftex_grid_encode_backward_adam_trailer(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                                         uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                                         int dtype, int layout, float in_add, float in_mul, const nerftex_table_adam* adam,
+                                                         uint32_t* first_updated_row, const nerftex_step_trailer* trailer, void* stream) {
+    if (!trailer) {
+        clear_error();
+        set_error("grid_encode_backward_adam_trailer: trailer must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    return backward_adam_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, gridtype, align_corners, dtype, layout, in_add, in_mul, adam,
+                               first_updated_row, trailer, stream);
 }
 
 namespace {

@@ -33,6 +33,7 @@
 #include "common.hpp"
 #include "grid_common.hpp"
 #include "grid_record.hpp"  // Sample / make_sample: the records of one (sample, level); kTileBytes, rows_per_tile
+#include "step_trailer.hpp"  // the step's small jobs, run by the first workgroups of the fill launch
 #include "workspace.hpp"
 
 #include <algorithm>
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
                                                                   const int* __restrict__ offsets, uint32_t B, uint32_t L, const LevelConsts lc,
                                                                   uint32_t gridtype, bool align_corners, const DirTable tab,
                                                                   uint32_t* __restrict__ dir, Rec<T>* __restrict__ records, uint32_t merge_res,
-                                                                  uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe, const uint32_t stage_cap) {
+                                                                  uint32_t nchunks, T* __restrict__ zero_grid, uint32_t probe, const uint32_t stage_cap, const StepTrailer trailer,
+                                                                  const uint32_t trailer_wgs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t hist[kMaxTilesPerLevel], lbase[kMaxTilesPerLevel + 1];
     __shared__ float s_wmax[kBinSamples / kWave];
@@ -227,7 +229,15 @@ __global__ __launch_bounds__(kBinSamples) void bin_fill_dir_kernel(const T* __re
     static_assert(sizeof(Bits) == sizeof(Rec<T>), "record size");
     typedef Bits __attribute__((address_space(3))) LdsBits;
     LdsBits* stage = (LdsBits*)smem;
-    const uint32_t group = blockIdx.x / (kXcds * L), rem = blockIdx.x % (kXcds * L);
+    // the step's trailer (step_trailer.hpp: the MLP backward's weight-gradient reduction, the step flags' clearing, the loss) on the launch's FIRST
+    // workgroups, a multiple of 8 of them (the workgroup -> XCD mapping of the fill behind them is unchanged): small, latency-bound jobs whose
+    // results nothing before the optimizer reads -- beside 7000 workgroups of fill instead of 8 us of their own on the step's critical path
+    if (trailer_wgs != 0u && blockIdx.x < trailer_wgs) {
+        run_step_trailer<kBinSamples>(trailer, blockIdx.x, trailer_wgs, smem);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - trailer_wgs;
+    const uint32_t group = bid / (kXcds * L), rem = bid % (kXcds * L);
     const uint32_t level = rem / kXcds, chunk = group * kXcds + rem % kXcds;  // id % 8 = chunk % 8 = the XCD that runs it
     if (chunk >= nchunks || probe == 5) return;  // ablation 5: launch only
     if (!table_matches(tab, offsets, level)) return;  // stale host copy: deferred error, nothing written
@@ -960,11 +970,13 @@ int grid_backward_binned(const T* grad, bool blc, const float* inputs, const int
         // grid_bwd_stage: LDS slots of a fill workgroup (a multiple of 16 records = whole 128-byte lines, at most the region)
         const long sk = knob(kKnobGridBwdStage);
         const uint32_t stage_cap = sk > 0 ? std::min<uint32_t>(((uint32_t)sk + 15u) & ~15u, kRegionRecords / 16u * 16u) : kStageRecords;
-        const size_t lds = sizeof(Rec<T>) * (size_t)stage_cap;
+        const StepTrailer* tr = ta ? ta->trailer : nullptr;
+        const uint32_t trailer_wgs = tr ? trailer_blocks<kBinSamples>(tr->groups) : 0u;
+        const size_t lds = std::max(sizeof(Rec<T>) * (size_t)stage_cap, tr ? sizeof(StepLossLds) : (size_t)0);
         NERFTEX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         KernelTimer kt("bin_fill_dir_kernel", st, kTimeGrid);
-        hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L), dim3(kBinSamples), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype,
-                           align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr, probe, stage_cap);
+        hipLaunchKernelGGL(fill, dim3(div_up(nchunks, kXcds) * kXcds * L + trailer_wgs), dim3(kBinSamples), lds, st, grad, inputs, offsets_dev, B, L, lc, gridtype,
+                           align_corners, dt, dir, recs, merge, nchunks, overwrite ? grad_grid : (T*)nullptr, probe, stage_cap, tr ? *tr : StepTrailer{}, trailer_wgs);
     }
     if ((rc = check_launch("grid_encode_backward(fill)")) != NERFTEX_OK) return rc;
     if (!do_sum || lv_lo >= lv_hi) return NERFTEX_OK;

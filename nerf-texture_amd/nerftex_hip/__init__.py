@@ -65,6 +65,10 @@ _SIGNATURES = {
     "nerftex_field_backward_live_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_field_backward_live_consume": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_field_backward_live_consume_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_backward_live_deferred": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_field_backward_live_deferred_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nerftex_step_trailer_run": [_vp, _vp],
+    "nerftex_grid_encode_backward_adam_trailer": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i, _i, _i, _f32, _f32, _vp, _vp, _vp, _vp],
     "nerftex_composite_step": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_render_tail_forward_live": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "nerftex_composite_tail_backward_live": [_vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
@@ -128,6 +132,11 @@ class TableAdam(C.Structure):
     """nerftex_table_adam of include/nerftex_hip.h, field for field."""
     _fields_ = [("param", _vp * 2), ("exp_avg", _vp * 2), ("exp_avg_sq", _vp * 2), ("param_half", _vp), ("live", _vp), ("step", _vp),
                 ("grad_scale", _vp), ("found_inf", _vp), ("lr", _f64), ("beta1", _f64), ("beta2", _f64), ("eps", _f64)]
+
+
+class StepTrailer(C.Structure):
+    """nerftex_step_trailer of include/nerftex_hip.h: opaque, filled by nerftex_field_backward_live_deferred."""
+    _fields_ = [("opaque", C.c_uint64 * 16)]
 
 
 class StepLoss(C.Structure):

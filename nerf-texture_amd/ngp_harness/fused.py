@@ -65,6 +65,7 @@ import os
 
 # False (NERFTEX_FIELD_BACKWARD=split): the six launches (glue, MLP + reduce, glue, MLP + reduce) nerftex_field_backward's three replace --
 # same gradients, for A/B
+STEP_TRAILER = True  # the field backward's reduction launch rides on the hash-grid backward's fill launch (round 6; False: its own launch)
 FIELD_BACKWARD_FUSED = os.environ.get("NERFTEX_FIELD_BACKWARD", "fused") != "split"
 DEBUG_TAP = None  # debugging aid (tools/determinism_probe.py): a callable that is shown the field backward's intermediate gradients
 
@@ -162,18 +163,28 @@ class _ngp_field(Function):
             if consume:
                 flags.zero_()
             flags = None
+        trailer = None
         if consume or loss_job is not None:
             assert (FIELD_BACKWARD_FUSED or bf16) and ws_dtype == wc_dtype == mlp_dtype, "announced in the forward (field_consumes)"
-            field_backward = lib.nerftex_field_backward_live_consume_bf16 if bf16 else lib.nerftex_field_backward_live_consume
+            import ctypes
+
             job = None
             if loss_job is not None:
                 from nerftex_hip import StepLoss
-                import ctypes
 
                 err, n_rays, loss_mul, scale, losses = loss_job
                 job = ctypes.byref(StepLoss(ptr(err), n_rays, loss_mul, ptr(scale), ptr(losses), losses.data_ptr() + 4))
-            check(field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin), ptr(grad_x),
-                                 ptr(grad_ws), ptr(grad_wc), ptr(flags), job, found, stream()))
+            args = (ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin), ptr(grad_x), ptr(grad_ws),
+                    ptr(grad_wc), ptr(flags), job, found)
+            # the reduction launch of this call (weight gradients + found_inf, the flags' clearing, the loss) is small, latency-bound and feeds nothing before
+            # the optimizer: when the hash-grid backward below is the tile-owner form, its fill launch runs it on its first workgroups (STEP_TRAILER)
+            if STEP_TRAILER and B > 0 and ctx.table_adam is not None and ctx.table_adam is sink and ctx.grad_chunker is None and t_dtype == torch.float16:
+                from nerftex_hip import StepTrailer
+
+                trailer = StepTrailer()
+                check((lib.nerftex_field_backward_live_deferred_bf16 if bf16 else lib.nerftex_field_backward_live_deferred)(*args, ctypes.byref(trailer), stream()))
+            else:
+                check((lib.nerftex_field_backward_live_consume_bf16 if bf16 else lib.nerftex_field_backward_live_consume)(*args, stream()))
         elif flags is not None:
             field_backward = lib.nerftex_field_backward_live_bf16 if bf16 else lib.nerftex_field_backward_live
             check(field_backward(ptr(grad_sigma), ptr(grad_rgbs), ptr(rgbs), ptr(h), ptr(cin), ptr(x_rows), ptr(ws_h), ptr(wc_h), B, ptr(grad_cin), ptr(grad_x),
@@ -220,6 +231,25 @@ class _ngp_field(Function):
                 return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None, None
             chunker.begin(grad_table, None, keep=None)  # (small batch / unknown table: the one-call backward below; the groups are complete already)
         fuse = ctx.table_adam.table_adam_for(table_h) if (ctx.table_adam is not None and ctx.table_adam is sink and chunker is None) else None
+        if trailer is not None and fuse is not None:
+            import ctypes
+
+            first = ctypes.c_uint32(0)
+            rc = lib.nerftex_grid_encode_backward_adam_trailer(ptr(grad_x), ptr(x), ptr(offsets), ptr(grad_table), B, 3, 2, offsets.shape[0] - 1, S, H, gridtype, align,
+                                                               F16, LAYOUT_BLC | LAYOUT_GRAD_OVERWRITE, affine[0], affine[1], ctypes.byref(fuse), ctypes.byref(first),
+                                                               ctypes.byref(trailer), stream())
+            if rc != 0:  # (refused: nothing was launched -- the trailer as a launch of its own, then the error)
+                lib.nerftex_step_trailer_run(ctypes.byref(trailer), stream())
+            check(rc)
+            trailer = None
+            sink.opt.fused_table = (sink.table_index, int(first.value))
+            sink.covered = (grad_table.data_ptr(), grad_ws.data_ptr(), grad_wc.data_ptr())
+            return None, None, grad_table.to(t_dtype), None, grad_ws.to(ws_dtype), grad_wc.to(wc_dtype), None, None, None, None
+        if trailer is not None:  # (the hash-grid backward is not the tile-owner form after all)
+            import ctypes
+
+            check(lib.nerftex_step_trailer_run(ctypes.byref(trailer), stream()))
+            trailer = None
         if fuse is not None:
             # round 6: the hashed levels' tiles never leave LDS as a gradient -- their owners run Adam on the rows (double-buffered state, so that a
             # step GradScaler skips leaves no trace); grad_table receives the coarse levels' rows [0, first) only, the rest stays uninitialised

@@ -638,26 +638,44 @@ def test_field_backward_consume_leaves_the_step_flags_zero(dev):
 
 def test_fused_composite_step_trains_like_the_three_launch_step(dev):
     """accelerate(fused_composite_step=True) against False, replayed graphs included, on a field dense enough to have dead steps: the same losses and
-    parameters bit for bit, and the flag buffer is clean between steps."""
+    parameters bit for bit, and the flag buffer is clean between steps -- with the field backward's trailer (weight-gradient reduction, flags, loss) on
+    the first workgroups of the hash-grid backward's fill launch (nerftex_field_backward_live_deferred -> nerftex_grid_encode_backward_adam_trailer, the
+    default) and as a launch of its own (fused.STEP_TRAILER = False)."""
+    import nerftex_hip
+    from ngp_harness import fused
     from ngp_harness.accelerate import accelerate
 
     out = {}
-    for fused_step in (False, True):
-        field, r, ro, rd = _opaque_case(dev, n_rays=4096, density_scale=300.0)
-        tgt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(8)).to(dev)
-        tr = accelerate(r, dt_gamma=1 / 128, fused_composite_step=fused_step)
-        assert (r.root_one is not None) == fused_step and r.skip_dead_samples
-        losses = []
-        for _ in range(16 + 2 + 14):
-            tr.step(ro, rd, tgt)
-            losses.append(tr.loss.clone())
-        torch.cuda.synchronize()
-        assert tr._graphs is not None
-        if fused_step:
-            assert int(r._live_words.abs().sum()) == 0, "consumed by the field's backward"
-        tr.sync()
-        out[fused_step] = (losses, {n_: p.detach().clone() for n_, p in field.named_parameters()})
-    for i, (la, lb) in enumerate(zip(out[False][0], out[True][0])):
-        assert torch.equal(la, lb), f"loss of step {i}"
-    for name in out[False][1]:
-        assert torch.equal(out[False][1][name], out[True][1][name]), name
+    try:
+        for form in ("three_launches", "one_launch", "one_launch_own_trailer_launch"):
+            fused.STEP_TRAILER = form != "one_launch_own_trailer_launch"
+            fused_step = form != "three_launches"
+            field, r, ro, rd = _opaque_case(dev, n_rays=4096, density_scale=300.0)
+            tgt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+            tr = accelerate(r, dt_gamma=1 / 128, fused_composite_step=fused_step)
+            assert (r.root_one is not None) == fused_step and r.skip_dead_samples and tr.fused_table_update
+            losses = []
+            for i in range(16 + 2 + 14):
+                if i == 17:
+                    nerftex_hip.kernel_profile(reset=True)
+                    nerftex_hip.kernel_profile(True)
+                tr.step(ro, rd, tgt)
+                if i == 17:
+                    torch.cuda.synchronize()
+                    names = set(nerftex_hip.kernel_profile())
+                    nerftex_hip.kernel_profile(False)
+                    assert ("ffmlp_wgrad_reduce2_kernel" in names) == (form != "one_launch"), (form, sorted(names))
+                losses.append(tr.loss.clone())
+            torch.cuda.synchronize()
+            assert tr._graphs is not None
+            if fused_step:
+                assert int(r._live_words.abs().sum()) == 0, "consumed by the field's backward"
+            tr.sync()
+            out[form] = (losses, {n_: p.detach().clone() for n_, p in field.named_parameters()})
+    finally:
+        fused.STEP_TRAILER = True
+    for form in ("one_launch", "one_launch_own_trailer_launch"):
+        for i, (la, lb) in enumerate(zip(out["three_launches"][0], out[form][0])):
+            assert torch.equal(la, lb), f"{form}: loss of step {i}"
+        for name in out["three_launches"][1]:
+            assert torch.equal(out["three_launches"][1][name], out[form][1][name]), (form, name)
