@@ -23,7 +23,7 @@ vals = {
     "MS": f"{j['ms_per_step']:.4f}", "VAL": f"{j['value'] / 1e6:.0f}",
     "BIN": f"{g2['bin_fill_dir_kernel']:.0f}", "SUM": f"{g2['sum_tiles_dir_kernel']:.0f}", "COMB": f"{g2['combine_tiles_kernel']:.0f}",
     "G2": f"{sum(g2.values()):.0f}",
-    "BWD": f"{2 * k['ffmlp_backward_fused_kernel']:.0f}", "RED": f"{k['ffmlp_wgrad_reduce2_kernel']:.1f}", "G1": f"{k['grid_forward_level_kernel']:.0f}",
+    "BWD": f"{2 * k['ffmlp_backward_fused_kernel']:.0f}", "RED": f"{k['ffmlp_wgrad_reduce2_kernel']:.1f}" if "ffmlp_wgrad_reduce2_kernel" in k else "0 (its reduction rides on the fill launch)", "G1": f"{k['grid_forward_level_kernel']:.0f}",
     "FWD": f"{k['field_forward_kernel']:.0f}",
     "COMPOSITE": f"{sum(v for n, v in k.items() if n.startswith('composite_') or n == 'render_tail_forward_kernel'):.0f}",
     "ADAM": f"{k['adam_half_kernel']:.0f}", "MARCH": f"{k['march_count_parallel_kernel']:.0f} + {k['march_expand_kernel']:.0f}",
