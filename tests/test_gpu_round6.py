@@ -634,6 +634,20 @@ def test_field_backward_consume_leaves_the_step_flags_zero(dev):
         assert torch.equal(_bits(out[0][1]), _bits(gws)) and int(flags.abs().sum()) == 0
     bad = StepLoss(ptr(err), 0, 1.0, None, ptr(got), None)
     assert lib.nerftex_field_backward_live_consume(*common[:-1], ptr(flags), ctypes.byref(bad), None, stream()) != 0
+    # the same call in two: the backward kernels now, the trailer (reduction, flags, loss) as a launch of its own later -- same bits; an empty trailer is refused
+    from nerftex_hip import StepTrailer
+
+    got2, flags = torch.full((2,), float("nan"), device=dev), live.to(torch.int32)
+    gws2, gwc2 = torch.full_like(ws, float("nan")), torch.full_like(wc, float("nan"))
+    job = StepLoss(ptr(err), 300, 0.25, ptr(scale), ptr(got2), got2.data_ptr() + 4)
+    trailer = StepTrailer()
+    assert lib.nerftex_step_trailer_run(ctypes.byref(trailer), stream()) != 0, "empty"
+    check(lib.nerftex_field_backward_live_deferred(*common[:-3], ptr(gws2), ptr(gwc2), ptr(flags), ctypes.byref(job), None, ctypes.byref(trailer), stream()))
+    torch.cuda.synchronize()
+    assert torch.isnan(gws2.float()).all() and torch.equal(flags != 0, live), "nothing of the trailer has run yet"
+    check(lib.nerftex_step_trailer_run(ctypes.byref(trailer), stream()))
+    assert torch.equal(_bits(out[0][1]), _bits(gws2)) and torch.equal(_bits(out[0][2]), _bits(gwc2)) and int(flags.abs().sum()) == 0
+    assert torch.equal(_bits(got), _bits(got2)), "the loss of the last job above (300 rays)"
 
 
 def test_fused_composite_step_trains_like_the_three_launch_step(dev):
