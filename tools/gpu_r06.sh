@@ -5,6 +5,9 @@
 #   ab          tools/table_update_ab.py
 #   ab-prof     the same under rocprofv3 --kernel-trace --stats
 #   trained     bench.py's 'trained state' entry alone
+#   comp        tools/composite_step_ab.py (the step's compositing as one launch against the three launches, per composite_keep)
+#   comp-prof   the same under rocprofv3 --kernel-trace --stats (KEEPS=1,2,4)
+#   probe / dead   tools/tile_adam_probe.py / tools/dead_skip_probe.py
 #   bench       python bench.py (default run)
 mode=${1:-tests-new}
 tag=${2:-r06_$mode}
