@@ -7,7 +7,8 @@ whatever the inputs are, checked on the HIP path's own outputs.
   FFMLP     the backward is linear in the output gradient: doubling it doubles dL/dinputs and dL/dweights EXACTLY (a power of two)
   march     ray records are an exclusive prefix sum that adds up to the counter; every sample lies inside the box; steps are positive;
             the same call twice gives the same bits (no ordering atomics)
-  composite weights_sum in [0, 1]; colours in [0, 1] composite to [0, 1]; zero density composites to zero
+  composite weights_sum in [0, 1]; colours in [0, 1] composite to [0, 1]; zero density composites to zero; the one-launch training step equals the
+            three launches bit for bit and its gradient scales exactly with a power-of-two loss scale
   compact   the survivors keep their order (an ordered compaction of a sorted list is sorted) and their number is the counter
 """
 import numpy as np
@@ -181,6 +182,57 @@ def test_compositing_bounds_at_full_size(dev, batch):
     assert bool((image.max(dim=-1).values <= ws + 1e-5).all())
     ws0, d0, im0 = raymarching.composite_rays_train(torch.zeros_like(sigmas), rgbs, batch["deltas"], batch["rays"])
     assert float(ws0.abs().max()) == 0 and float(im0.abs().max()) == 0 and float(d0.abs().max()) == 0
+
+
+def test_composite_step_at_full_size(dev, batch):
+    """nerftex_composite_step (round 6: compositing forward + render tail + backward as one launch) on the bench's batch in full-size buffers
+    (8192 x 1024 rows, ~95 % of them covered by no ray): every output, the gradients and the step flags equal the three launches' bit for bit; the
+    gradient scales EXACTLY with a power-of-two loss scale; rows no ray covers get exact zeros and dead flags."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    M, N, total = batch["xyzs"].shape[0], batch["rays"].shape[0], batch["total"]
+    gen = torch.Generator().manual_seed(12)
+    sigmas = (torch.rand(M, generator=gen) * 40).to(dev)
+    rgbs = torch.rand(M, 3, generator=gen).to(dev)
+    tgt = torch.rand(N, 3, generator=gen).to(dev)
+    deltas, rays, nears, fars = batch["deltas"], batch["rays"], batch["nears"], batch["fars"]
+    words = (M + 31) // 32
+    one = torch.ones((), device=dev)
+
+    def three(scale):
+        per_ray, losses = torch.empty(9, N, device=dev), torch.empty(2, device=dev)
+        ticket, partial = torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(1024, device=dev)
+        flags = torch.full((words,), 3, dtype=torch.int32, device=dev)
+        g = torch.full((4 * M,), float("nan"), device=dev)
+        check(lib.nerftex_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(per_ray[0]), ptr(per_ray[1]), ptr(per_ray[3:6]), stream()))
+        check(lib.nerftex_render_tail_forward_live(ptr(per_ray[0]), ptr(per_ray[1]), ptr(per_ray[3:6]), ptr(nears), ptr(fars), ptr(tgt), 1.0, 1.0, N, ptr(per_ray[6:9]),
+                                                   ptr(per_ray[2]), ptr(partial), ptr(ticket), ptr(losses), ptr(scale), losses.data_ptr() + 4, ptr(flags), words, stream()))
+        check(lib.nerftex_composite_tail_backward_live(ptr(one), ptr(scale), 1.0, ptr(per_ray[6:9]), ptr(tgt), 1.0, ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays),
+                                                       ptr(per_ray[0]), ptr(per_ray[3:6]), M, N, ptr(g[:M]), ptr(g[M:]), ptr(flags), stream()))
+        return per_ray, losses, g, flags
+
+    def step(scale):
+        per_ray, losses = torch.full((9, N), float("nan"), device=dev), torch.full((2,), float("nan"), device=dev)
+        err, flags = torch.empty(N, device=dev), torch.zeros(words, dtype=torch.int32, device=dev)
+        g = torch.full((4 * M,), float("nan"), device=dev)
+        check(lib.nerftex_composite_step(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, ptr(nears), ptr(fars), ptr(tgt), 1.0, 1.0, ptr(scale), ptr(per_ray[0]),
+                                         ptr(per_ray[1]), ptr(per_ray[3:6]), ptr(per_ray[6:9]), ptr(per_ray[2]), ptr(err), ptr(losses), losses.data_ptr() + 4, ptr(g[:M]),
+                                         ptr(g[M:]), ptr(flags), stream()))
+        return per_ray, losses, g, flags
+
+    s1, s2 = torch.full((), 1024.0, device=dev), torch.full((), 2048.0, device=dev)
+    a, b = three(s1), step(s1)
+    for x, y, name in zip(a, b, ("per-ray outputs", "loss", "gradients", "flags")):
+        if name == "flags":
+            assert torch.equal(x != 0, y != 0), name
+        else:
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
+    g1, g2 = b[2], step(s2)[2]
+    big = g1.abs() > 1e-30  # (below that a doubled subnormal and a flushed one may differ)
+    assert torch.equal((2 * g1)[big], g2[big]), "the gradient is linear in the loss scale, exactly for a power of two"
+    assert float(g1[total:M].abs().max()) == 0 and float(g1[M + 3 * total:].abs().max()) == 0, "rows no ray covers"
+    assert int(b[3][(total + 31) // 32:].abs().sum()) == 0 and 0 < int((b[3] != 0).sum())
+    assert float(b[1][0]) > 0 and float(b[1][1]) == float(b[1][0]) * 1024.0
 
 
 def test_compaction_keeps_order_on_a_full_frame(dev):
