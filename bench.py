@@ -1195,6 +1195,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    from ngp_harness.streams import ensure_pool
+
+    ensure_pool(dev)  # (the package's streams exist before anything is recorded: a stream created after a training loop's captures can share a hardware queue)
     # N > 1: nothing is timed before the group has proven itself (world size, one all-reduce per wire type, barrier): dp.preflight raises with
     # the rank and the failing check; its report goes into config.collective
     pre = dp.preflight(world, dev) if world > 1 else None

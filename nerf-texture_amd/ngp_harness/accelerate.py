@@ -132,6 +132,10 @@ class AcceleratedTrainer:
         self._primed, self._warm = 0, 0
         self._ahead = None  # (slot, data_ptr of rays_o, data_ptr of rays_d) of a march started by `next_rays`
         self._side = None
+        if self.dev.type == "cuda":
+            from .streams import ensure_pool
+
+            ensure_pool(self.dev)  # (every stream of the package exists BEFORE this trainer's captures: streams.py)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
 
     @staticmethod

@@ -407,6 +407,11 @@ class Renderer(nn.Module):
         """First half of the training branch: everything that depends on the rays and the occupancy grid only (:361-387)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
+        if not getattr(self, "_streams_ready", False) and rays_o.is_cuda:  # every stream of the package exists before anybody records or trains: streams.py
+            from .streams import ensure_pool
+
+            ensure_pool(rays_o.device)
+            self._streams_ready = True
         if counter is None:
             counter = self.step_counter[self.local_step % 16]
             self.local_step += 1
