@@ -1195,9 +1195,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (HIP path only; there is no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    from ngp_harness.streams import ensure_pool
+    from ngp_harness.streams import ensure_pool, pool_report
 
-    ensure_pool(dev)  # (the package's streams exist before anything is recorded: a stream created after a training loop's captures can share a hardware queue)
+    ensure_pool(dev)  # (the package's streams get their hardware queues before anything else does: ngp_harness/streams.py for what the order costs otherwise)
     # N > 1: nothing is timed before the group has proven itself (world size, one all-reduce per wire type, barrier): dp.preflight raises with
     # the rank and the failing check; its report goes into config.collective
     pre = dp.preflight(world, dev) if world > 1 else None
@@ -1514,6 +1514,9 @@ def main():
                            "the step (SURVEY 8(d): synthetic, resident inputs); other_config holds the same loop with never-repeating rays drawn by torch.randint inside "
                            "the timed loop, and the baked-pool loop of rounds 1-3") if fresh is not None else (res["graph"] if res["graph"] else "eager launches"),
                 "headline_loop": "fresh rays through ngp_harness.accelerate" if fresh is not None else "pool of ray batches baked into the graphs",
+                # what ngp_harness.streams.ensure_pool measured when it placed the side stream and the range streams on hardware queues (streams.py: two
+                # queues 4 apart cost the step 0.97 ms instead of 0.52, two ranges on one queue cost the frame 14 Mpix/s)
+                "stream_pool": pool_report(dev),
                 "precision_note": "fp16 autocast = the reference's -O/--fp16 (its ffmlp is fp16-only); BASELINE configs[2] says bf16: the same loop with bf16 networks is in other_config",
             },
             "roofline": roofline,

@@ -115,3 +115,11 @@ def test_capture_section_collects_first_and_keeps_the_collector_off():
         assert not gc.isenabled()
     finally:
         gc.enable() if was else gc.disable()
+
+
+def test_stream_pool_module_is_inert_without_a_gpu():
+    """ngp_harness.streams imports and reports nothing measured until a caller on a GPU asks for the pool (the pool itself: tests/test_gpu_streams.py)."""
+    from ngp_harness import streams
+
+    assert streams.pool_report("cuda:0") is None and streams.POOL_PARTS == 3
+    assert not streams._SIDE and not streams._PARTS.get(0)

@@ -1,0 +1,74 @@
+"""GPU: ngp_harness.streams.ensure_pool (round 6) -- the side stream and the range streams end up on hardware queues that run BESIDE the caller's stream
+and beside each other, whatever streams the process used first.
+
+Hardware queues are process-wide state (a stream gets its queue at first use and keeps it), so every case is a child process: it uses some streams of
+its own first (`x` = default priority, `X` = high priority), calls ensure_pool, and prints pool_report() plus two direct measurements -- the hand-over
+latency null <-> side against null <-> the candidate that was NOT kept, and whether the three range streams execute sleep kernels at the same time.
+What the expectations rest on: tools/probes/hw_queue_log.py (the runtime's own log: at most 4 queues per priority, assigned at first use) and
+tools/hw_queue_order_probe.py / profiles/r06_hw_queue_order.json (queues 4 apart: 0.97 ms per training step instead of 0.52)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/nerf-texture_amd"]
+import torch
+from ngp_harness import streams
+dev = torch.device("cuda:0")
+torch.zeros(1, device=dev); torch.cuda.synchronize()
+own = []
+for tok in [t for t in sys.argv[2].split(",") if t]:
+    own.append(torch.cuda.Stream(device=dev, priority=-1 if tok == "X" else 0))
+    with torch.cuda.stream(own[-1]):
+        torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+streams.ensure_pool(dev)
+main, side, parts = torch.cuda.current_stream(), streams.side_stream(dev), streams.part_streams(dev, 3)
+rep = dict(streams.pool_report(dev))
+rep["side_us"] = streams._handover_us(main, side, 0)
+rep["other_candidate_us"] = streams._handover_us(main, streams._KEEP[0], 0)
+rep["ranges_beside"] = [streams._run_beside(main, parts[i], parts[j], 0) for i in range(3) for j in range(i)]
+rep["same_objects"] = side is streams.side_stream(dev) and all(a is b for a, b in zip(parts, streams.part_streams(dev, 3)))
+print(json.dumps(rep))
+"""
+
+
+def _child(own):
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT, own], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-800:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_fresh_process_first_candidates_are_kept():
+    rep = _child("")
+    assert rep["side_stream_is_candidate"] == 0 and rep["range_stream_candidates_tried"] == 3 and rep["independent_range_streams"] == 3, rep
+    assert all(rep["ranges_beside"]) and rep["same_objects"], rep
+    lat = rep["handover_us_of_the_two_candidates"]
+    assert max(lat) < 1.5 * min(lat), rep  # null is queue 0, the candidates 1 and 2: neither sits 4 apart
+
+
+def test_side_stream_avoids_the_queue_four_apart_from_the_callers():
+    """Three streams of the caller's first: the first side-stream candidate would be the process's 5th queue (null = 1st).  Measured there: 59 us per
+    round trip against 31 us, and a training step of 0.97 ms instead of 0.52 -- the pool must keep the second candidate."""
+    rep = _child("x,x,x")
+    lat = rep["handover_us_of_the_two_candidates"]
+    assert lat[0] > 1.4 * lat[1] and rep["side_stream_is_candidate"] == 1, rep
+    assert rep["side_us"] < 0.75 * rep["other_candidate_us"], rep
+    assert rep["independent_range_streams"] == 3 and all(rep["ranges_beside"]), rep
+
+
+@pytest.mark.parametrize("own", ["x", "x,x", "X,x"])
+def test_range_streams_run_beside_each_other_after_a_callers_streams(own):
+    """With one or two default-priority streams of the caller's in use, the third range candidate lands on the second's hardware queue (the runtime
+    shares the queue with the fewest users, ties to the newest): it must be set aside for a later candidate."""
+    rep = _child(own)
+    assert rep["independent_range_streams"] == 3 and all(rep["ranges_beside"]), rep
+    assert rep["side_us"] < 1.4 * min(rep["handover_us_of_the_two_candidates"]), rep
