@@ -120,12 +120,12 @@ def ensure_pool(device=None):
         pick = 1 if lat[1] < 0.75 * lat[0] else 0  # (the first unless the second is clearly better: 31 vs 59 us per round trip when one of them sits 4 queues from `main`)
         _SIDE[(idx, -1)] = cands[pick]
         rep["handover_us_of_the_two_candidates"], rep["side_stream_is_candidate"] = [round(v, 1) for v in lat], pick
-        _KEEP.append(cands[1 - pick])  # (stays alive: releasing its queue would renumber the ones created later; a last-resort range stream below)
+        _KEEP.setdefault(idx, []).append(cands[1 - pick])  # (stays alive: releasing its queue would renumber the ones created later; a last-resort range stream below)
     # range streams: up to 2 x POOL_PARTS default-priority candidates, then the unused side-stream candidate; one is kept only if it is INDEPENDENT of every
     # range stream kept so far: a sleep kernel on each runs at the same time (not one hardware queue) and a round trip between the two is not slow (not
     # queues 4 apart).  In a fresh process the first POOL_PARTS candidates pass.
     good = 1.5 * min(_handover_us(main, _SIDE[(idx, -1)], idx), *rep.get("handover_us_of_the_two_candidates", [float("inf")]))
-    cands = [None] * (2 * POOL_PARTS) + list(_KEEP[-1:])
+    cands = [None] * (2 * POOL_PARTS) + list(_KEEP.get(idx, [])[:1])
     tried, spare = 0, []
     while len(lst) < POOL_PARTS and cands:
         c = cands.pop(0)
@@ -135,12 +135,12 @@ def ensure_pool(device=None):
         tried += 1
         if all(_run_beside(main, c, o, idx) and _handover_us(c, o, idx) < good for o in lst):
             lst.append(c)
-        elif c not in _KEEP:
+        elif c not in _KEEP.get(idx, []):
             spare.append(c)
     rep["range_stream_candidates_tried"], rep["independent_range_streams"] = tried, len(lst)
     while len(lst) < POOL_PARTS and spare:  # (not enough independent hardware queues left in this process: some ranges will wait for each other)
         lst.append(spare.pop(0))
-    _KEEP.extend(spare)
+    _KEEP.setdefault(idx, []).extend(spare)
 
 
 def _run_beside(main, a, b, idx, cycles=2_000_000):
@@ -166,7 +166,7 @@ def _run_beside(main, a, b, idx, cycles=2_000_000):
     return both < 1.5 * one
 
 
-_KEEP = []
+_KEEP = {}  # device index -> streams created and used but not handed out (the side-stream candidate not chosen first, then range candidates set aside)
 
 
 def pool_report(device=None):

@@ -34,7 +34,7 @@ streams.ensure_pool(dev)
 main, side, parts = torch.cuda.current_stream(), streams.side_stream(dev), streams.part_streams(dev, 3)
 rep = dict(streams.pool_report(dev))
 rep["side_us"] = streams._handover_us(main, side, 0)
-rep["other_candidate_us"] = streams._handover_us(main, streams._KEEP[0], 0)
+rep["other_candidate_us"] = streams._handover_us(main, streams._KEEP[0][0], 0)
 rep["ranges_beside"] = [streams._run_beside(main, parts[i], parts[j], 0) for i in range(3) for j in range(i)]
 rep["same_objects"] = side is streams.side_stream(dev) and all(a is b for a, b in zip(parts, streams.part_streams(dev, 3)))
 print(json.dumps(rep))

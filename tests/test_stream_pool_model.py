@@ -47,7 +47,7 @@ def model(monkeypatch):
     monkeypatch.setattr(streams, "_SIDE", {})
     monkeypatch.setattr(streams, "_PARTS", {})
     monkeypatch.setattr(streams, "_REPORT", {})
-    monkeypatch.setattr(streams, "_KEEP", [])
+    monkeypatch.setattr(streams, "_KEEP", {})
     monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: null)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
