@@ -47,28 +47,43 @@ def _child(own):
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
 
 
+def _twice(own, check):
+    """The child's answers are device-side TIMINGS (best of 2-3 repetitions each): one more child if the first one's do not pass, and the second one's
+    assertion is the test's."""
+    try:
+        check(_child(own))
+    except AssertionError:
+        check(_child(own))
+
+
 def test_fresh_process_first_candidates_are_kept():
-    rep = _child("")
-    assert rep["side_stream_is_candidate"] == 0 and rep["range_stream_candidates_tried"] == 3 and rep["independent_range_streams"] == 3, rep
-    assert all(rep["ranges_beside"]) and rep["same_objects"], rep
-    lat = rep["handover_us_of_the_two_candidates"]
-    assert max(lat) < 1.5 * min(lat), rep  # null is queue 0, the candidates 1 and 2: neither sits 4 apart
+    def check(rep):
+        assert rep["side_stream_is_candidate"] == 0 and rep["range_stream_candidates_tried"] == 3 and rep["independent_range_streams"] == 3, rep
+        assert all(rep["ranges_beside"]) and rep["same_objects"], rep
+        lat = rep["handover_us_of_the_two_candidates"]
+        assert max(lat) < 1.5 * min(lat), rep  # null is queue 0, the candidates 1 and 2: neither sits 4 apart
+
+    _twice("", check)
 
 
 def test_side_stream_avoids_the_queue_four_apart_from_the_callers():
     """Three streams of the caller's first: the first side-stream candidate would be the process's 5th queue (null = 1st).  Measured there: 59 us per
     round trip against 31 us, and a training step of 0.97 ms instead of 0.52 -- the pool must keep the second candidate."""
-    rep = _child("x,x,x")
-    lat = rep["handover_us_of_the_two_candidates"]
-    assert lat[0] > 1.4 * lat[1] and rep["side_stream_is_candidate"] == 1, rep
-    assert rep["side_us"] < 0.75 * rep["other_candidate_us"], rep
-    assert rep["independent_range_streams"] == 3 and all(rep["ranges_beside"]), rep
+    def check(rep):
+        lat = rep["handover_us_of_the_two_candidates"]
+        assert lat[0] > 1.4 * lat[1] and rep["side_stream_is_candidate"] == 1, rep
+        assert rep["side_us"] < 0.75 * rep["other_candidate_us"], rep
+        assert rep["independent_range_streams"] == 3 and all(rep["ranges_beside"]), rep
+
+    _twice("x,x,x", check)
 
 
 @pytest.mark.parametrize("own", ["x", "x,x", "X,x"])
 def test_range_streams_run_beside_each_other_after_a_callers_streams(own):
     """With one or two default-priority streams of the caller's in use, the third range candidate lands on the second's hardware queue (the runtime
     shares the queue with the fewest users, ties to the newest): it must be set aside for a later candidate."""
-    rep = _child(own)
-    assert rep["independent_range_streams"] == 3 and all(rep["ranges_beside"]), rep
-    assert rep["side_us"] < 1.4 * min(rep["handover_us_of_the_two_candidates"]), rep
+    def check(rep):
+        assert rep["independent_range_streams"] == 3 and all(rep["ranges_beside"]), rep
+        assert rep["side_us"] < 1.4 * min(rep["handover_us_of_the_two_candidates"]), rep
+
+    _twice(own, check)
