@@ -86,7 +86,8 @@ def parse():
     ap.add_argument("--baked-pool", action="store_true", help="1 GPU: report the loop whose pool of ray batches is baked into the graphs as the headline (rounds 1-3) "
                     "instead of the fresh-ray loop through ngp_harness.accelerate")
     ap.add_argument("--no-infer", action="store_true")
-    ap.add_argument("--infer-slots", type=int, default=4, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1)")
+    ap.add_argument("--infer-slots", type=int, default=3, help="sample slots per iteration of the rendered frame, in units of N rays (reference: 1; 4 until the per-block "
+                    "copy node of the graphed loop was replaced by a store of the compaction kernel: with cheaper block boundaries 3 renders faster, 90.5 vs 88 Mpix/s)")
     ap.add_argument("--infer-parts", type=int, default=3, help="ray ranges of the rendered frame, each on its own stream")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample")
     ap.add_argument("--warm-seconds", type=float, default=0.5, help="untimed steps (beyond --warmup) until this much wall time has passed under load, right before "

@@ -1276,7 +1276,8 @@ __global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive,
                                                                const int* __restrict__ rays_alive_old, float* __restrict__ rays_t,
                                                                const float* __restrict__ rays_t_old, int* __restrict__ alive_counter,
                                                                const uint32_t* __restrict__ ws, const int* __restrict__ n_alive_dev,
-                                                               uint32_t* __restrict__ steps_done, const uint32_t max_steps, const uint32_t n_step_code) {
+                                                               uint32_t* __restrict__ steps_done, const uint32_t max_steps, const uint32_t n_step_code,
+                                                               int* __restrict__ host_mirror) {
     __shared__ uint32_t red[kBlock / kWave];
     __shared__ uint32_t wave_tot[kBlock / kWave];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1319,6 +1320,9 @@ __global__ __launch_bounds__(kBlock) void compact_write_kernel(uint32_t n_alive,
             else steps_done[0] = done + unit_rows(n_step_code, survivors);
         }
         alive_counter[0] = (int)survivors;
+        // a copy for the HOST (pinned, device-mapped memory): a posted write on the way out instead of a 4-byte copy node behind the block, which is a
+        // kernel of its own that queues for a CU slot behind every other range's launches (median 9-41 us, p95 110-171 us in a frame: DESIGN 4.6)
+        if (host_mirror != nullptr) __hip_atomic_store(host_mirror, (int)survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1655,7 +1659,7 @@ extern "C" int nerftex_composite_rays_dev(uint32_t n_alive_bound, const int32_t*
 
 static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
                              const float* rays_t_old, int32_t* alive_counter, void* stream, uint32_t* steps_done = nullptr, uint32_t max_steps = 0,
-                             uint32_t n_step_code = 0);
+                             uint32_t n_step_code = 0, int32_t* host_mirror = nullptr);
 
 extern "C" int nerftex_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
                                     const float* rays_t_old, int32_t* alive_counter, void* stream) {
@@ -1684,8 +1688,24 @@ extern "C" int nerftex_compact_rays_budget_dev(uint32_t n_alive_bound, const int
     return compact_rays_impl(n_alive_bound, n_alive_dev, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter, stream, steps_done, max_steps, n_step);
 }
 
+// The same with a copy of the survivor count written to `host_mirror[0]` by the kernel itself: pinned host memory the device can address (hipHostMalloc /
+// torch's pin_memory).  The host may read it once an event recorded behind the launch has completed; read later it may hold the count of a LATER call on the
+// same word -- in a loop whose alive count only falls, still an upper bound of what is left.  [extension, round 6]
+extern "C" int nerftex_compact_rays_budget_mirror_dev(uint32_t n_alive_bound, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old,
+                                                      float* rays_t, const float* rays_t_old, int32_t* alive_counter, uint32_t* steps_done, uint32_t max_steps,
+                                                      uint32_t n_step, int32_t* host_mirror, void* stream) {
+    if (!steps_done || !n_alive_dev || !host_mirror) {
+        clear_error();
+        set_error("compact_rays_budget_mirror_dev: steps_done, n_alive_dev and host_mirror must not be NULL");
+        return NERFTEX_ERR_INVALID;
+    }
+    return compact_rays_impl(n_alive_bound, n_alive_dev, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter, stream, steps_done, max_steps, n_step,
+                             host_mirror);
+}
+
 static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
-                             const float* rays_t_old, int32_t* alive_counter, void* stream, uint32_t* steps_done, uint32_t max_steps, uint32_t n_step_code) {
+                             const float* rays_t_old, int32_t* alive_counter, void* stream, uint32_t* steps_done, uint32_t max_steps, uint32_t n_step_code,
+                             int32_t* host_mirror) {
     clear_error();
     if (n_alive == 0) return NERFTEX_OK;
     const uint32_t nblocks = div_up(n_alive, kBlock);
@@ -1701,7 +1721,7 @@ static int compact_rays_impl(uint32_t n_alive, const int32_t* n_alive_dev, int32
     {
         KernelTimer kt("compact_write_kernel", st);
         hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kBlock), 0, st, n_alive, rays_alive, rays_alive_old, rays_t,
-                           rays_t_old, alive_counter, ws, n_alive_dev, steps_done, max_steps, n_step_code);
+                           rays_t_old, alive_counter, ws, n_alive_dev, steps_done, max_steps, n_step_code, host_mirror);
     }
     return check_launch("compact_rays(write)");
 }

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "nerftex_composite_rays_dev": [_u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_compact_rays_dev": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "nerftex_compact_rays_budget_dev": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
+    "nerftex_compact_rays_budget_mirror_dev": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
     "nerftex_occupancy_sample_full": [_vp, _u32, _u32, _f32, _vp, _u64, _vp],
     "nerftex_occupancy_sample_partial": [_vp, _u32, _u32, _f32, _u32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp],
     "nerftex_occupancy_sample_partial_ordered": [_vp, _u32, _u32, _f32, _u32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _vp],

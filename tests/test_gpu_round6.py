@@ -434,6 +434,82 @@ def test_graphed_inference_stops_at_the_step_budget_like_the_reference_loop(dev)
             assert max_steps <= done < max_steps + 8 * 4, (done, max_steps)  # the loop ran until the budget was used up, and not past it
 
 
+def test_compaction_mirrors_its_count_into_pinned_host_memory(dev):
+    """nerftex_compact_rays_budget_mirror_dev = nerftex_compact_rays_budget_dev (nerf/renderer.py:459-483's bookkeeping: the survivors of
+    raymarching.cu:1093-1106's compaction, in order) + the survivor count stored by the kernel into pinned host memory: same arrays, same device
+    counter, same step word as the plain call, and after an event behind the launch the host word holds the count -- also 0 once the step budget is
+    used up, and also for an empty survivor set.  A NULL mirror is refused."""
+    from nerftex_hip import check, lib, ptr, stream
+
+    N = 70001  # ragged last workgroup
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for frac_dead, done0, max_steps in ((0.37, 0, 1024), (0.0, 0, 1024), (1.0, 0, 1024), (0.5, 1024, 1024)):
+        t_old = torch.rand(N, device=dev, generator=gen) + 0.1
+        t_old[torch.rand(N, device=dev, generator=gen) < frac_dead] = -1.0
+        alive_old = torch.randperm(N, device=dev, generator=gen).int()
+        n_dev = torch.tensor([N - 5], dtype=torch.int32, device=dev)  # the true count lives on the device (launch sized by a bound)
+        outs = []
+        for mirror in (False, True):
+            ra, rt = torch.full((N,), -7, dtype=torch.int32, device=dev), torch.full((N,), -7.0, device=dev)
+            cnt, steps = torch.tensor([123], dtype=torch.int32, device=dev), torch.tensor([done0], dtype=torch.int32, device=dev)
+            host = torch.full((2,), -1, dtype=torch.int32).pin_memory()
+            if mirror:
+                check(lib.nerftex_compact_rays_budget_mirror_dev(N, ptr(n_dev), ptr(ra), ptr(alive_old), ptr(rt), ptr(t_old), ptr(cnt), ptr(steps), max_steps, 4,
+                                                                 host.data_ptr() + 4, stream()))
+            else:
+                check(lib.nerftex_compact_rays_budget_dev(N, ptr(n_dev), ptr(ra), ptr(alive_old), ptr(rt), ptr(t_old), ptr(cnt), ptr(steps), max_steps, 4, stream()))
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+            outs.append((ra, rt, cnt, steps, host.clone()))
+        (ra0, rt0, c0, s0, h0), (ra1, rt1, c1, s1, h1) = outs
+        assert torch.equal(ra0, ra1) and torch.equal(rt0, rt1) and torch.equal(c0, c1) and torch.equal(s0, s1)
+        keep = (t_old[:N - 5] >= 0)
+        expect = 0 if done0 >= max_steps else int(keep.sum())
+        assert int(c1) == expect and h1.tolist() == [-1, expect] and h0.tolist() == [-1, -1], (frac_dead, done0, h1.tolist(), expect)
+        if expect:
+            assert torch.equal(ra1[:expect], alive_old[:N - 5][keep])
+    rc = lib.nerftex_compact_rays_budget_mirror_dev(N, ptr(n_dev), ptr(ra), ptr(alive_old), ptr(rt), ptr(t_old), ptr(cnt), ptr(steps), 1024, 4, None, stream())
+    assert rc != 0
+
+
+def test_graphed_inference_with_the_mirrored_count_equals_the_copy_node_form(dev):
+    """Renderer.render_infer_graphed reads the alive count from the word the compaction kernel mirrors into pinned memory (possibly a LATER block's
+    count: a newer upper bound); the form with a 4-byte copy node behind every block is kept for an A/B (_InferGraphPart.COUNT_MIRROR = False).
+    Same image, depth and iteration count as that form and as the reference loop (nerf/renderer.py:436-487), bit for bit."""
+    from ngp_harness import scene
+    from ngp_harness.model import NGPField, Renderer, _InferGraphPart
+
+    sc = scene.Scene(bound=2.0, seed=0)
+    grid, _, _ = sc.bitfield()
+    torch.manual_seed(0)
+    field = NGPField(bound=2.0, mlp="ffmlp", fused_glue=True).to(dev)
+    torch.manual_seed(1)
+    field.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    field.eval()
+    r = Renderer(field, bound=2.0, min_near=0.2, density_thresh=10.0).to(dev)
+    r.set_occupancy(torch.from_numpy(grid).to(dev))
+    pose = scene.rand_poses(1, 2.0, np.random.default_rng(11))[0]
+    o, d = scene.get_rays(pose, scene.intrinsics(200, 160), 200, 160)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    res = {}
+    try:
+        with torch.autocast("cuda", dtype=torch.float16):
+            img_ref, dep_ref, _ = r.render_infer(ro, rd, dt_gamma=1 / 128, slots_per_ray=4)
+            for mirror in (True, False):
+                _InferGraphPart.COUNT_MIRROR = mirror
+                for _ in range(3):  # (the second and third frame replay the graphs over a word that still holds the last frame's final count)
+                    img, dep, _ = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=4, parts=3, block=2)
+                assert all(j.mirror == mirror for j in r._infer_graphs["jobs"])
+                res[mirror] = (img.clone(), dep.clone(), r.last_iters)
+    finally:
+        _InferGraphPart.COUNT_MIRROR = True
+    assert float(img_ref.std()) > 1e-3
+    for mirror in (True, False):
+        assert torch.equal(res[mirror][0], img_ref) and torch.equal(res[mirror][1], dep_ref), mirror
+    assert abs(res[True][2] - res[False][2]) <= 2  # (a newer count can end the loop one block earlier, never later)
+
+
 # ------------------------------------------------------------------------------------------------- curved field: the forward as one graph (item 8)
 def test_curved_field_forward_as_one_graph_equals_the_eager_forward(dev):
     """CurvedField.forward_graphed: neighbour search, projector, lookup, the two FFMLPs and the framework ops between them replayed as one HIP graph --

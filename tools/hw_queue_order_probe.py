@@ -115,12 +115,12 @@ def child(order):
     ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
     with torch.autocast("cuda", dtype=torch.float16):
         for _ in range(3):
-            img, _, n = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=4, parts=3)
+            img, _, n = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=3, parts=3)
         torch.cuda.synchronize()
         ts = []
         for _ in range(12):
             t = time.perf_counter()
-            img, _, n = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=4, parts=3)
+            img, _, n = r.render_infer_graphed(ro, rd, dt_gamma=1 / 128, slots_per_ray=3, parts=3)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t)
     med = sorted(ts)[6]
