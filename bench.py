@@ -857,7 +857,7 @@ def measure_occupancy_update(renderer, use_amp, amp_dtype, ms_per_step, samples_
     return out
 
 
-def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16", randint_rays=False, fused_table_update=None):
+def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16", randint_rays=False, fused_table_update=None, n_views=4):
     """A training loop that feeds FRESH rays every step through ngp_harness.accelerate (the one call a trainer adds to the drop-in
     packages: graph replay + fused field + HalfLeafAdam / FusedAmp, or torch's capturable Adam + GradScaler for nn.Linear MLPs).
     group = k > 1: `step_group` -- the loop has the batches of k consecutive steps at a time ([k, N, 3] tensors, copied into the graphs'
@@ -877,7 +877,7 @@ def measure_accelerated(args, mlp, rays, steps, dev, grid, group=1, dtype="fp16"
     n_pool = max(8, group)
     pool = []
     for k in range(n_pool):
-        o, d = scene.train_batch(rays, seed=100 + k, n_views=4)
+        o, d = scene.train_batch(rays, seed=100 + k, n_views=n_views)
         pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
     gt = torch.rand(n_pool, rays, 3, generator=torch.Generator().manual_seed(4321)).to(dev)
     field.train()
@@ -1343,6 +1343,14 @@ def main():
                           "loss_after_run": r5["loss"]})
         except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
             print(f"[bench] randint-ray measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
+        try:  # the headline's loop with the batch composition of the reference's own loader: all rays of a batch from ONE image
+            r6 = measure_accelerated(args, "ffmlp", 8192, 208, dev, grid, group=4, n_views=1)
+            other.append({"workload": "configs[2], the headline's loop with every batch drawn from ONE view (what the reference's loader hands its trainer: nerf/provider.py:326-366, "
+                                      "`B = len(index) # always 1`, num_rays random pixels of that image); the headline mixes 4 views per batch, which is the less coherent sample stream",
+                          "rays_per_batch": 8192, "dtype": "fp16", "value": r6["value"], "unit": "ray-samples/s", "ms_per_step": r6["ms_per_step"], "steps": 208,
+                          "ms_per_step_spread": r6["spread"], "samples_per_step": r6["samples"] / r6["steps"]})
+        except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down with it
+            print(f"[bench] one-view measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
         if args.trained_steps > 0:
             try:  # the scene trained against rendered targets, then timed with and without the dead-sample skip
                 other.append(measure_trained_state(args, dev, sc, grid, train_steps=args.trained_steps))
