@@ -2,7 +2,7 @@
 
 ROCm 7.2 gives a stream its HSA queue at first use: at most 4 per priority (tools/probes/hw_queue_log.py), later streams share one.  This probe creates
 the process's streams in a given ORDER (comma-separated: n = first use of the null stream, h = the high-priority side stream, p = a range stream,
-x = a dummy normal stream, X = a dummy high-priority stream, P = the package's own `ensure_pool` as shipped), then times the training step (accelerate().step_group, 8192 rays: the null stream + the side stream's march-ahead) and the
+x = a dummy normal stream, X = a dummy high-priority stream, s = the side stream at default priority, P = the package's own `ensure_pool` as shipped), then times the training step (accelerate().step_group, 8192 rays: the null stream + the side stream's march-ahead) and the
 800 x 800 frame (render_infer_graphed, 3 range streams).  One child process per order."""
 import json
 import os
@@ -81,6 +81,9 @@ def child(order):
             touch()
         elif tok == "h":
             streams._SIDE[(0, -1)] = torch.cuda.Stream(device=dev, priority=-1)
+            touch(streams._SIDE[(0, -1)])
+        elif tok == "s":  # the side stream at DEFAULT priority (round 4 chose high priority when queue placement was not understood yet)
+            streams._SIDE[(0, -1)] = torch.cuda.Stream(device=dev)
             touch(streams._SIDE[(0, -1)])
         elif tok == "p":
             parts.append(torch.cuda.Stream(device=dev))
