@@ -55,6 +55,7 @@ def capture_section():
 POOL_PARTS = 3  # (the null stream + three ranges = the four default-priority queues; a fourth range would share a queue with the third)
 _PARTS = {}
 _REPORT = {}
+_KEEP = {}  # device index -> streams created and used but not handed out (the side-stream candidate not chosen first, then range candidates set aside)
 
 
 def _index(device):
@@ -112,6 +113,14 @@ def ensure_pool(device=None):
     main = torch.cuda.current_stream(dev)
     _touch(main, idx)
     rep = _REPORT.setdefault(idx, {})
+    if not hasattr(torch.cuda, "_sleep"):  # (the measurements below keep the device busy with torch's sleep kernel: without it, the fresh-process order and no choice)
+        _SIDE.setdefault((idx, -1), torch.cuda.Stream(device=dev, priority=-1))
+        _touch(_SIDE[(idx, -1)], idx)
+        while len(lst) < POOL_PARTS:
+            lst.append(torch.cuda.Stream(device=dev))
+            _touch(lst[-1], idx)
+        rep["created"] = "in order (null, side, ranges), nothing measured: torch.cuda._sleep is missing"
+        return
     if (idx, -1) not in _SIDE:
         cands = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
         for c in cands:
@@ -165,8 +174,6 @@ def _run_beside(main, a, b, idx, cycles=2_000_000):
         both = min(timed([a, b]) for _ in range(2))
     return both < 1.5 * one
 
-
-_KEEP = {}  # device index -> streams created and used but not handed out (the side-stream candidate not chosen first, then range candidates set aside)
 
 
 def pool_report(device=None):
